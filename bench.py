@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the simdjson-go Parse()/ParseND() hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run,
+one rank per GPU).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): twitter.json replicated 426x inside one JSON array
+(269 025 391 B = 256.56 MiB), stage 1 (structural index) only, input resident in HBM before the
+timed region.  A "step" is one complete stage-1 pass over that document, including the
+descriptor memset, the kernel and the read-back of the structural count / verdict.  With N>1 every
+rank runs the same pass on its own replica of the document (a single JSON document does not
+shard; weak scaling, no data-path collective) and the ranks gather their structural counts
+(the same 8-byte-per-rank exchange the NDJSON tape merge needs).
+
+Extra objects on the same line:
+  roofline      stage-1 kernel: algorithmic bytes (N + 4*S) / average kernel time
+                (hipEvents on the kernel's own stream, measured live) vs the 8 TB/s HBM3E peak.
+  cpu_baseline  the oracle (C port of the reference's CPU algorithm) timed on this host, 1 core, on a
+                bounded sample of the same workload.
+  full_parse / ndjson   stage1+stage2 throughput on the same document and on parking-citations NDJSON
+                (only present once the stage-2 kernels are built).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "simdjson-go_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(copies=426, passes=5):
+    """Oracle stage 1 (scalar C port of the reference algorithm), 1 host core, bounded sample."""
+    import oracle_lib
+    import workloads
+    sample = workloads.c2_twitter_array(copies)
+    oracle_lib.stage1(sample[: 1 << 20])  # warm
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ok, pos = oracle_lib.stage1(sample)
+    dt = time.perf_counter() - t0
+    assert ok
+    return {"value": round(passes * len(sample) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"oracle stage 1, {passes} passes over twitter.json x{copies} array ({len(sample)} B each), "
+                      f"{dt:.1f} s, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--copies", type=int, default=426, help="twitter.json copies in the array (426 = 256.56 MiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as G
+    if rank == 0:
+        G.build_lib()
+        G.build_oracle()
+    if distributed:
+        dist.barrier()
+    import sjhip
+    import workloads
+
+    doc = workloads.c2_twitter_array(args.copies)
+    n_bytes = len(doc)
+    s_expect = workloads.c2_expected_structurals(args.copies)
+    d_msg = torch.empty(n_bytes + 256, dtype=torch.uint8, device=dev)
+    d_msg[:n_bytes].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
+    d_pos = torch.empty(s_expect + 1024, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = sjhip.Context(local_rank)
+
+    def step():
+        ok, n = ctx.stage1_device(d_msg.data_ptr(), n_bytes, d_pos.data_ptr(), d_pos.numel())
+        return ok, n
+
+    for _ in range(args.warmup):
+        ok, n = step()
+        assert ok and n == s_expect, (ok, n, s_expect)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok, n = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert ok and n == s_expect
+
+    # the per-shard count gather (stands for the NDJSON tape-size exchange; 8 B per rank)
+    counts = torch.tensor([n], dtype=torch.int64, device=dev)
+    if distributed:
+        allc = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(allc, counts)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # kernel-only timing with hipEvents on the kernel's stream (rank-local)
+    k_ms = ctx.stage1_time(d_msg.data_ptr(), n_bytes, d_pos.data_ptr(), d_pos.numel(), max(5, args.steps))
+    algo_bytes = n_bytes + 4 * s_expect
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * n_bytes / (dt / args.steps) / 1e9
+        line = {
+            "metric": "GB/s parsed (stage 1, structural index), twitter.json x426 array resident in HBM",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic (testdata/twitter.json replicated into one JSON array)",
+            "config": {"workload": f"configs[1]: twitter.json x{args.copies} array, {n_bytes} B, stage-1 only, "
+                                   f"one document replica per GPU", "bytes_per_gpu": n_bytes,
+                       "structurals": s_expect, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "stage1_kernel<512>", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes": algo_bytes,
+                         "input_GBps": round(n_bytes / (k_ms * 1e-3) / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

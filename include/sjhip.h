@@ -1,0 +1,91 @@
+/*
+ * sjhip.h -- C ABI of libsjhip: the MI355X (gfx950) engine behind the simdjson-go
+ * Parse()/ParseND() hot path.
+ *
+ * This is the drop-in boundary.  The reference selects its backend with build tags
+ * (simdjson_amd64.go:1 vs simdjson_other.go:1); a backend has to provide SupportedCPU,
+ * Parse, ParseND and ParseNDStream (simdjson_other.go:29-76), all of which funnel into
+ *     (*internalParsedJson).parseMessage(msg []byte, ndjson bool) error      parse_json_amd64.go:52
+ * whose only outputs are pj.Message (TrimSpace'd alias of the input), pj.Tape []uint64 and
+ * pj.Strings.B []byte.  The Go shim (simdjson-go_amd/go/simdjson_hip.go)
+ * binds exactly the functions below through cgo; the Python mirror (sjhip package) binds the
+ * same symbols through ctypes.
+ *
+ * Conventions (they mirror the Go<->asm seam of find_subroutines_amd64.go):
+ *   - plain pointers + explicit sizes; the library never retains a caller pointer after the
+ *     call returns (cgo rule), hence the two-call parse/fetch protocol;
+ *   - one sjhip_ctx per concurrent parse (it owns a HIP stream and device arenas that are
+ *     recycled across calls -- the role of the reference's `reuse *ParsedJson`);
+ *   - functions return 0 on success, SJHIP_ERR_* otherwise; sjhip_last_error() explains.
+ */
+#ifndef SJHIP_H
+#define SJHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sjhip_ctx sjhip_ctx;
+
+/* flags for sjhip_parse: parse_json_amd64.go:58-62 (ndjson) and options.go:13 (WithCopyStrings) */
+#define SJHIP_FLAG_NDJSON 1u
+#define SJHIP_FLAG_COPY_STRINGS 2u
+
+/* return codes */
+#define SJHIP_OK 0
+#define SJHIP_ERR_STAGE1 1  /* "Failed to find all structural indices for stage 1" parse_json_amd64.go:93 */
+#define SJHIP_ERR_STAGE2 2  /* "Bad parsing while executing stage 2"               parse_json_amd64.go:81 */
+#define SJHIP_ERR_NODEVICE 3 /* "Host CPU does not meet target specs" analogue     simdjson_amd64.go:43  */
+#define SJHIP_ERR_TOOBIG 4  /* message longer than 4 GiB - 64 (positions are uint32 like the reference's index stream) */
+#define SJHIP_ERR_ARG 5
+#define SJHIP_ERR_HIP (-1)  /* a HIP runtime call failed */
+
+/* ---- backend presence: replaces SupportedCPU() (simdjson_amd64.go:37) -------------------- */
+int sjhip_supported(void);      /* 1 iff a gfx950 device is visible */
+int sjhip_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+sjhip_ctx *sjhip_ctx_create(int device);          /* NULL if the device is unusable */
+void sjhip_ctx_destroy(sjhip_ctx *ctx);
+const char *sjhip_last_error(const sjhip_ctx *ctx);
+/* run the context's work on an existing HIP stream (e.g. torch's current stream); NULL = own stream */
+int sjhip_ctx_set_stream(sjhip_ctx *ctx, void *hip_stream);
+
+/* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------
+ * pos_out receives ABSOLUTE uint32 byte positions (running sum of the reference's deltas).
+ * *ok = the reference's return value (error_mask == 0 && indexTotal > 0 && end-of-doc checks). */
+int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out,
+                 size_t pos_cap, size_t *n, int *ok);
+/* device-resident variant: d_pos must hold pos_cap uint32; nothing is copied back but the counts */
+int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,
+                        size_t pos_cap, size_t *n, int *ok);
+/* launches the stage-1 kernel `iters` times back to back on the context's stream and returns the
+ * average kernel duration in milliseconds measured with hipEvents on that stream */
+int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,
+                      size_t pos_cap, int iters, float *ms_per_launch);
+
+/* ---- per-routine known-answer entry points (one 64-byte chunk, executed on the GPU) ----------
+ * Same signatures as the Go wrappers in find_subroutines_amd64.go so that the reference's
+ * per-routine tests (find_subroutines_amd64_test.go) can be replayed against the device code. */
+int sjhip_find_odd_backslash_sequences(sjhip_ctx *ctx, const uint8_t in[64],
+                                       uint64_t *prev_iter_ends_odd_backslash, uint64_t *odd_ends);      /* :86  */
+int sjhip_find_quote_mask_and_bits(sjhip_ctx *ctx, const uint8_t in[64], uint64_t odd_ends,
+                                   uint64_t *prev_iter_inside_quote, uint64_t *quote_bits,
+                                   uint64_t *error_mask, uint64_t *quote_mask);                          /* :60  */
+int sjhip_find_whitespace_and_structurals(sjhip_ctx *ctx, const uint8_t in[64], uint64_t *whitespace,
+                                          uint64_t *structurals);                                        /* :206 */
+int sjhip_finalize_structurals(sjhip_ctx *ctx, uint64_t structurals, uint64_t whitespace,
+                               uint64_t quote_mask, uint64_t quote_bits,
+                               uint64_t *prev_iter_ends_pseudo_pred, uint64_t *out);                     /* :35  */
+int sjhip_find_newline_delimiters(sjhip_ctx *ctx, const uint8_t in[64], uint64_t quote_mask,
+                                  uint64_t *mask);                                                       /* :40  */
+int sjhip_flatten_bits_incremental(sjhip_ctx *ctx, uint32_t *base, int *base_index, uint64_t mask,
+                                   uint64_t *carried, uint64_t *position);                               /* :229 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

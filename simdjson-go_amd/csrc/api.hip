@@ -1,0 +1,364 @@
+// api.hip -- the C ABI of libsjhip (include/sjhip.h): context, stage-1 entry points and the
+// per-routine known-answer kernels.  Whole-parse entry points live in parse_api.hip.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sjhip.h"
+#include "sj_chunk.h"
+#include "sj_ctx.h"
+#include "sj_device.h"
+
+using namespace sj;
+
+// ---------------------------------------------------------------------------------------------
+int sjhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sjhip_supported(void) {
+    const int n = sjhip_device_count();
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) return 1;
+    }
+    return 0;
+}
+
+void sj::ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+}
+
+int sj::ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what) {
+    ctx_set_error(ctx, "%s: %s", what, hipGetErrorString(e));
+    return SJHIP_ERR_HIP;
+}
+
+// grow-only device arena (the buffers are recycled across calls like the reference's `reuse`)
+int sj::arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return SJHIP_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return ctx_hip_fail(ctx, e, "hipMalloc");
+    b.cap = want;
+    return SJHIP_OK;
+}
+
+sjhip_ctx *sjhip_ctx_create(int device) {
+    if (device < 0 || device >= sjhip_device_count()) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    sjhip_ctx *ctx = new sjhip_ctx();
+    ctx->device = device;
+    ctx->err[0] = 0;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    if (hipHostMalloc((void **)&ctx->h_scratch, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return nullptr;
+    }
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    return ctx;
+}
+
+void sjhip_ctx_destroy(sjhip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
+                      &ctx->d_s2};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *sjhip_last_error(const sjhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+int sjhip_ctx_set_stream(sjhip_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SJHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 1
+// ---------------------------------------------------------------------------------------------
+#define HIPCHK(call, what)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return ctx_hip_fail(ctx, e_, what); \
+    } while (0)
+
+// Reads back the Stage1State and applies the reference's end-of-document verdict
+// (stage1_find_marks_amd64.go:115-129,147).  `last_byte` is msg[len-1].
+static int stage1_verdict(const Stage1State &st, size_t len, uint8_t last_byte) {
+    if (len == 0) return 0;
+    if (st.error) return 0;          // error_mask != 0
+    if (st.total == 0) return 0;     // indexTotal == 0
+    if (st.ends_in_quote) return 0;  // prev_iter_inside_quote != 0
+    // the last structural must be '}' or ']'.  The message is TrimSpace'd, so its last byte is not
+    // whitespace: outside a string that byte is a structural exactly when it is one of {}[]:, and
+    // otherwise it belongs to a token whose first byte (the last structural) is not a bracket.
+    return last_byte == '}' || last_byte == ']';
+}
+
+int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
+                          uint8_t last_byte, int have_last, size_t *n, int *ok) {
+    if (len >= 0xffffffc0ull) {
+        ctx_set_error(ctx, "message too long for uint32 positions");
+        return SJHIP_ERR_TOOBIG;
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
+    if (rc) return rc;
+    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream), "stage1 launch");
+    Stage1State *hs = (Stage1State *)ctx->h_scratch;
+    HIPCHK(hipMemcpyAsync(hs, ctx->d_ws.p, sizeof(Stage1State), hipMemcpyDeviceToHost, ctx->stream), "D2H state");
+    uint8_t *hlast = ctx->h_scratch + 128;
+    if (!have_last && len > 0)
+        HIPCHK(hipMemcpyAsync(hlast, (const uint8_t *)d_msg + len - 1, 1, hipMemcpyDeviceToHost, ctx->stream),
+               "D2H last byte");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
+    if (!have_last) last_byte = len ? *hlast : 0;
+    ctx->s1 = *hs;
+    *n = (size_t)hs->total;
+    *ok = stage1_verdict(*hs, len, last_byte);
+    return SJHIP_OK;
+}
+
+int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
+                        size_t *n, int *ok) {
+    if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
+    return stage1_run_device(ctx, d_msg, len, ndjson, d_pos, pos_cap, 0, 0, n, ok);
+}
+
+int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t pos_cap,
+                 size_t *n, int *ok) {
+    if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc = arena_reserve(ctx, ctx->d_msg, len + 128);
+    if (rc) return rc;
+    rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 16) * sizeof(uint32_t));
+    if (rc) return rc;
+    if (len) HIPCHK(hipMemcpyAsync(ctx->d_msg.p, msg, len, hipMemcpyHostToDevice, ctx->stream), "H2D msg");
+    rc = stage1_run_device(ctx, ctx->d_msg.p, len, ndjson, ctx->d_pos.p, pos_cap, len ? msg[len - 1] : 0, 1, n, ok);
+    if (rc) return rc;
+    const size_t ncopy = *n < pos_cap ? *n : pos_cap;
+    if (ncopy && pos_out) {
+        HIPCHK(hipMemcpyAsync(pos_out, ctx->d_pos.p, ncopy * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream),
+               "D2H positions");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    }
+    return SJHIP_OK;
+}
+
+int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
+                      int iters, float *ms_per_launch) {
+    if (!ctx || iters <= 0 || !ms_per_launch) return SJHIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
+    if (rc) return rc;
+    // The workspace memset is part of every launch (descriptors must be zero), but only the
+    // kernel itself is bracketed by the events: memset k+1 is issued before event pair k+1.
+    float total = 0.f;
+    for (int i = 0; i < iters; i++) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
+        (void)a;
+        HIPCHK(stage1_prepare(len, (size_t)(reinterpret_cast<uintptr_t>(d_msg) & 63), ctx->d_ws.p, ctx->stream),
+               "stage1 memset");
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream), "event");
+        HIPCHK(stage1_launch_prepared(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream),
+               "stage1 launch");
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream), "event");
+        HIPCHK(hipEventSynchronize(ctx->ev1), "event sync");
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1), "elapsed");
+        total += ms;
+    }
+    *ms_per_launch = total / (float)iters;
+    return SJHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-routine KAT kernels: a single lane runs the very same device functions as stage1_kernel
+// ---------------------------------------------------------------------------------------------
+struct KatIO {
+    uint8_t in[64];
+    uint64_t a[8];    // scalar inputs
+    uint64_t out[8];  // scalar outputs
+    uint32_t idx[80]; // flatten output
+};
+
+enum { KAT_ODD_BS, KAT_QUOTE, KAT_WS, KAT_FINALIZE, KAT_NEWLINE, KAT_FLATTEN };
+
+__global__ void kat_kernel(KatIO *io, int op) {
+    if (threadIdx.x != 0) return;
+    u32 w[16];
+    for (int j = 0; j < 16; j++)
+        w[j] = (u32)io->in[4 * j] | ((u32)io->in[4 * j + 1] << 8) | ((u32)io->in[4 * j + 2] << 16) |
+               ((u32)io->in[4 * j + 3] << 24);
+    const Classes c = classify(w);
+    switch (op) {
+    case KAT_ODD_BS: {
+        u32 co;
+        io->out[0] = odd_backslash_ends(c.bs, (u32)io->a[0], co);
+        io->out[1] = co;
+        break;
+    }
+    case KAT_QUOTE: {  // a0 = odd_ends, a1 = prev_inside_quote, a2 = error_mask (accumulated)
+        const u64 qb = c.quote & ~io->a[0];
+        const u64 qm = prefix_xor(qb) ^ io->a[1];
+        io->out[0] = qm;
+        io->out[1] = qb;
+        io->out[2] = io->a[2] | (c.ctrl & qm);
+        io->out[3] = (u64)((long long)qm >> 63);
+        break;
+    }
+    case KAT_WS:
+        io->out[0] = c.ws;
+        io->out[1] = c.structs;
+        break;
+    case KAT_FINALIZE: {  // a0 structurals a1 whitespace a2 quote_mask a3 quote_bits a4 pseudo_pred
+        io->out[0] = finalize(io->a[0], io->a[1], io->a[2], io->a[3], (u32)io->a[4]);
+        io->out[1] = (((io->a[0] & ~io->a[2]) | io->a[3] | io->a[1]) >> 63) & 1;
+        break;
+    }
+    case KAT_NEWLINE:
+        io->out[0] = c.nl & ~io->a[0];
+        break;
+    case KAT_FLATTEN: {  // a0 mask, a1 carried, a2 position (absolute of last emitted, ~0 = none)
+        u64 s = io->a[0];
+        u64 position = io->a[2];
+        const u64 start = position + io->a[1] + 1;  // absolute position of bit 0 of this mask
+        u32 n = 0;
+        while (s) {
+            const u64 abs = start + (u64)ctz64(s);
+            io->idx[n++] = (u32)(abs - position);  // the reference hands deltas to stage 2
+            position = abs;
+            s &= s - 1;
+        }
+        io->out[0] = n;
+        io->out[1] = (start + 63) - position;  // carried
+        io->out[2] = position;
+        break;
+    }
+    }
+}
+
+static int kat_run(sjhip_ctx *ctx, KatIO &h, int op) {
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc = arena_reserve(ctx, ctx->d_kat, sizeof(KatIO));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_kat.p, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream), "H2D kat");
+    hipLaunchKernelGGL(kat_kernel, dim3(1), dim3(64), 0, ctx->stream, (KatIO *)ctx->d_kat.p, op);
+    HIPCHK(hipGetLastError(), "kat launch");
+    HIPCHK(hipMemcpyAsync(&h, ctx->d_kat.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream), "D2H kat");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "kat sync");
+    return SJHIP_OK;
+}
+
+int sjhip_find_odd_backslash_sequences(sjhip_ctx *ctx, const uint8_t in[64], uint64_t *prev, uint64_t *odd_ends) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.in, in, 64);
+    h.a[0] = *prev;
+    int rc = kat_run(ctx, h, KAT_ODD_BS);
+    if (rc) return rc;
+    *odd_ends = h.out[0];
+    *prev = h.out[1];
+    return SJHIP_OK;
+}
+
+int sjhip_find_quote_mask_and_bits(sjhip_ctx *ctx, const uint8_t in[64], uint64_t odd_ends, uint64_t *prev_inside,
+                                   uint64_t *quote_bits, uint64_t *error_mask, uint64_t *quote_mask) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.in, in, 64);
+    h.a[0] = odd_ends;
+    h.a[1] = *prev_inside;
+    h.a[2] = *error_mask;
+    int rc = kat_run(ctx, h, KAT_QUOTE);
+    if (rc) return rc;
+    *quote_mask = h.out[0];
+    *quote_bits = h.out[1];
+    *error_mask = h.out[2];
+    *prev_inside = h.out[3];
+    return SJHIP_OK;
+}
+
+int sjhip_find_whitespace_and_structurals(sjhip_ctx *ctx, const uint8_t in[64], uint64_t *whitespace,
+                                          uint64_t *structurals) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.in, in, 64);
+    int rc = kat_run(ctx, h, KAT_WS);
+    if (rc) return rc;
+    *whitespace = h.out[0];
+    *structurals = h.out[1];
+    return SJHIP_OK;
+}
+
+int sjhip_finalize_structurals(sjhip_ctx *ctx, uint64_t structurals, uint64_t whitespace, uint64_t quote_mask,
+                               uint64_t quote_bits, uint64_t *pseudo_pred, uint64_t *out) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    h.a[0] = structurals;
+    h.a[1] = whitespace;
+    h.a[2] = quote_mask;
+    h.a[3] = quote_bits;
+    h.a[4] = *pseudo_pred;
+    int rc = kat_run(ctx, h, KAT_FINALIZE);
+    if (rc) return rc;
+    *out = h.out[0];
+    *pseudo_pred = h.out[1];
+    return SJHIP_OK;
+}
+
+int sjhip_find_newline_delimiters(sjhip_ctx *ctx, const uint8_t in[64], uint64_t quote_mask, uint64_t *mask) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.in, in, 64);
+    h.a[0] = quote_mask;
+    int rc = kat_run(ctx, h, KAT_NEWLINE);
+    if (rc) return rc;
+    *mask = h.out[0];
+    return SJHIP_OK;
+}
+
+int sjhip_flatten_bits_incremental(sjhip_ctx *ctx, uint32_t *base, int *base_index, uint64_t mask, uint64_t *carried,
+                                   uint64_t *position) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    KatIO h;
+    memset(&h, 0, sizeof h);
+    h.a[0] = mask;
+    h.a[1] = *carried;
+    h.a[2] = *position;
+    int rc = kat_run(ctx, h, KAT_FLATTEN);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < h.out[0]; i++) base[(*base_index)++] = h.idx[i];
+    *carried = h.out[1];
+    *position = h.out[2];
+    return SJHIP_OK;
+}

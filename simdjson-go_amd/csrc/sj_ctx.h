@@ -1,0 +1,35 @@
+// sj_ctx.h -- host-side context behind the opaque sjhip_ctx of include/sjhip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sj_device.h"
+
+namespace sj {
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+}  // namespace sj
+
+struct sjhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream all work is queued on
+    hipStream_t own_stream = nullptr;  // created with the context
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
+    sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2;
+    sj::Stage1State s1;                // last stage-1 state (host copy)
+    // last parse (kept on the device until sjhip_fetch)
+    size_t tape_len = 0, strings_len = 0;
+    char err[256];
+};
+
+namespace sj {
+void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
+int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
+int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
+int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
+                      uint8_t last_byte, int have_last, size_t *n, int *ok);
+}  // namespace sj

@@ -1,0 +1,27 @@
+// sj_device.h -- device-side state shared between the kernels and the host launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sj {
+
+// Lives at the start of the stage-1 workspace; zeroed (with the tile descriptors that
+// follow it) by a hipMemsetAsync node before every launch.
+struct Stage1State {
+    uint32_t tile_counter;   // dynamic tile id dispenser
+    uint32_t error;          // OR of (control char inside string)   -> reference error_mask != 0
+    uint64_t total;          // number of structural indexes
+    uint32_t ends_in_quote;  // reference prev_iter_inside_quote != 0 at the end
+    uint32_t pad[11];
+};
+static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
+
+size_t stage1_workspace_bytes(size_t len);
+hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
+hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
+                                  void *ws, hipStream_t stream);
+hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
+                         hipStream_t stream);
+
+}  // namespace sj

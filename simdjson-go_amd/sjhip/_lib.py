@@ -1,0 +1,56 @@
+"""ctypes binding of libsjhip.so (the C ABI declared in include/sjhip.h).
+
+The library is the product: if it is missing this module raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # simdjson-go_amd/
+LIB_PATH = os.path.join(PKG_DIR, "libsjhip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+szp = C.POINTER(C.c_size_t)
+intp = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol declared in include/sjhip.h
+SYMBOLS = {
+    "sjhip_supported": (C.c_int, []),
+    "sjhip_device_count": (C.c_int, []),
+    "sjhip_ctx_create": (C.c_void_p, [C.c_int]),
+    "sjhip_ctx_destroy": (None, [C.c_void_p]),
+    "sjhip_last_error": (C.c_char_p, [C.c_void_p]),
+    "sjhip_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
+    "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,
+                                      intp]),
+    "sjhip_stage1_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                                    C.POINTER(C.c_float)]),
+    "sjhip_find_odd_backslash_sequences": (C.c_int, [C.c_void_p, C.c_char_p, u64p, u64p]),
+    "sjhip_find_quote_mask_and_bits": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, u64p, u64p, u64p, u64p]),
+    "sjhip_find_whitespace_and_structurals": (C.c_int, [C.c_void_p, C.c_char_p, u64p, u64p]),
+    "sjhip_finalize_structurals": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u64p,
+                                             u64p]),
+    "sjhip_find_newline_delimiters": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, u64p]),
+    "sjhip_flatten_bits_incremental": (C.c_int, [C.c_void_p, u32p, intp, C.c_uint64, u64p, u64p]),
+}
+
+_LIB = None
+
+
+class SjhipMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SjhipMissing(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

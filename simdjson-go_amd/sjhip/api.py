@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference API for the Parse()/ParseND() path.
+
+Reference interface mirrored here:
+  simdjson_amd64.go:37  SupportedCPU()        -> supported()
+  simdjson_amd64.go:66  Parse(b, reuse, opts) -> parse(b, reuse=None, copy_strings=True)
+  simdjson_amd64.go:82  ParseND(...)          -> parse_nd(...)
+  options.go:13         WithCopyStrings(bool) -> copy_strings keyword
+  parsed_json.go:64     ParsedJson{Message, Tape, Strings} -> ParsedJson
+Errors follow parse_json_amd64.go:81,93 and simdjson_amd64.go:43 (same messages).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FLAG_NDJSON = 1
+FLAG_COPY_STRINGS = 2
+
+ERR_STAGE1 = "Failed to find all structural indices for stage 1"
+ERR_STAGE2 = "Bad parsing while executing stage 2"
+ERR_NODEVICE = "Host CPU does not meet target specs"  # kept verbatim from the reference
+
+
+class ParseError(Exception):
+    def __init__(self, msg, code):
+        super().__init__(msg)
+        self.code = code
+
+
+def supported() -> bool:
+    return bool(_lib.lib().sjhip_supported())
+
+
+class Context:
+    """One per concurrent parse: owns a HIP stream and recycled device arenas
+    (the role of `reuse *ParsedJson`, simdjson_amd64.go:46-51)."""
+
+    def __init__(self, device: int = 0):
+        L = _lib.lib()
+        self._h = L.sjhip_ctx_create(device)
+        if not self._h:
+            raise ParseError(ERR_NODEVICE, 3)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _lib.lib().sjhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        return _lib.lib().sjhip_last_error(self._h).decode()
+
+    def set_stream(self, stream_ptr):
+        _lib.lib().sjhip_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0))
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        if rc == 1:
+            raise ParseError(ERR_STAGE1, rc)
+        if rc == 2:
+            raise ParseError(ERR_STAGE2, rc)
+        if rc == 3:
+            raise ParseError(ERR_NODEVICE, rc)
+        raise ParseError(f"sjhip error {rc}: {self.last_error()}", rc)
+
+    # ---- stage 1 ---------------------------------------------------------------------------
+    def stage1(self, data, ndjson=False):
+        """findStructuralIndices on a host buffer -> (ok, uint32 positions)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        cap = a.size + 64
+        pos = np.empty(cap, dtype=np.uint32)
+        n = C.c_size_t(0)
+        ok = C.c_int(0)
+        rc = _lib.lib().sjhip_stage1(self._h, a.ctypes.data if a.size else None, a.size, int(ndjson),
+                                     pos.ctypes.data, cap, C.byref(n), C.byref(ok))
+        self._check(rc)
+        return bool(ok.value), pos[: n.value].copy()
+
+    def stage1_device(self, d_msg_ptr, length, d_pos_ptr, pos_cap, ndjson=False):
+        n = C.c_size_t(0)
+        ok = C.c_int(0)
+        rc = _lib.lib().sjhip_stage1_device(self._h, C.c_void_p(d_msg_ptr), length, int(ndjson),
+                                            C.c_void_p(d_pos_ptr), pos_cap, C.byref(n), C.byref(ok))
+        self._check(rc)
+        return bool(ok.value), n.value
+
+    def stage1_time(self, d_msg_ptr, length, d_pos_ptr, pos_cap, iters, ndjson=False):
+        ms = C.c_float(0)
+        rc = _lib.lib().sjhip_stage1_time(self._h, C.c_void_p(d_msg_ptr), length, int(ndjson), C.c_void_p(d_pos_ptr),
+                                          pos_cap, iters, C.byref(ms))
+        self._check(rc)
+        return ms.value
+
+    # ---- whole parse -----------------------------------------------------------------------
+    def parse(self, data, ndjson=False, copy_strings=True):
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
+        L = _lib.lib()
+        rc = L.sjhip_parse(self._h, a.ctypes.data if a.size else None, a.size, flags, C.byref(tl), C.byref(sl),
+                           C.byref(mo), C.byref(ml))
+        self._check(rc)
+        tape = np.empty(tl.value, dtype=np.uint64)
+        strings = np.empty(sl.value, dtype=np.uint8)
+        rc = L.sjhip_fetch(self._h, tape.ctypes.data, strings.ctypes.data)
+        self._check(rc)
+        msg = bytes(a[mo.value: mo.value + ml.value])
+        return ParsedJson(msg, tape, strings)
+
+    def parse_device(self, d_msg_ptr, length, ndjson=False, copy_strings=True):
+        tl, sl = C.c_size_t(0), C.c_size_t(0)
+        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
+        rc = _lib.lib().sjhip_parse_device(self._h, C.c_void_p(d_msg_ptr), length, flags, C.byref(tl), C.byref(sl))
+        self._check(rc)
+        return tl.value, sl.value
+
+    def fetch(self, tape_len, strings_len):
+        tape = np.empty(tape_len, dtype=np.uint64)
+        strings = np.empty(strings_len, dtype=np.uint8)
+        self._check(_lib.lib().sjhip_fetch(self._h, tape.ctypes.data, strings.ctypes.data))
+        return tape, strings
+
+
+class ParsedJson:
+    """parsed_json.go:64-71: Message / Tape / Strings."""
+
+    __slots__ = ("Message", "Tape", "Strings")
+
+    def __init__(self, message, tape, strings):
+        self.Message = message
+        self.Tape = tape
+        self.Strings = strings
+
+
+_DEFAULT = {}
+
+
+def _default_ctx(device=0):
+    c = _DEFAULT.get(device)
+    if c is None:
+        c = _DEFAULT[device] = Context(device)
+    return c
+
+
+def parse(b, reuse=None, copy_strings=True, ctx=None):
+    """Parse(b, reuse, WithCopyStrings(copy_strings)) -- simdjson_amd64.go:66."""
+    return (ctx or _default_ctx()).parse(b, ndjson=False, copy_strings=copy_strings)
+
+
+def parse_nd(b, reuse=None, copy_strings=True, ctx=None):
+    """ParseND(b, reuse, ...) -- simdjson_amd64.go:82."""
+    return (ctx or _default_ctx()).parse(b, ndjson=True, copy_strings=copy_strings)
+
+
+def stage1(b, ndjson=False, ctx=None):
+    return (ctx or _default_ctx()).stage1(b, ndjson=ndjson)
