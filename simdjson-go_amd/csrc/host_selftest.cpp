@@ -85,3 +85,137 @@ extern "C" uint64_t sj_selftest_prefix_xor(uint64_t x) { return prefix_xor(x); }
 extern "C" uint64_t sj_selftest_finalize(uint64_t st, uint64_t ws, uint64_t qm, uint64_t qb, uint32_t pp) {
     return finalize(st, ws, qm, qb, pp);
 }
+
+// ---- number parsing replay (sj_number.h + sj_bignum.h) ----------------------------------------
+#include "sj_bignum.h"
+#include "sj_number.h"
+
+extern "C" int sj_selftest_parse_number(const uint8_t *buf, size_t len, uint64_t *tag, uint64_t *val, int *used_bignum) {
+    u32 numlen = 0;
+    *used_bignum = 0;
+    int st = parse_number(buf, (u32)len, tag, val, &numlen);
+    if (st == NUM_NEEDS_BIGNUM) {
+        static Big X, Y;
+        *used_bignum = 1;
+        const u64 sign = *val & 0x8000000000000000ull;
+        const u64 r = bignum_round(buf, numlen, *val & ~0x8000000000000000ull, X, Y);
+        if (r == 0x7ff0000000000000ull) return 0;
+        *val = r | sign;
+        st = NUM_OK;
+    }
+    return st;
+}
+
+// ---- whole parse replay: stage 1 + the data-parallel stage 2 of sj_stage2.h ---------------------
+// Every "kernel" of stage2.hip is a plain loop over the same per-token functions here; the scans
+// are sequential sums.  Used by the CPU test-suite to check the algorithm against the oracle.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "sj_host.h"
+#include "sj_stage2.h"
+
+extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
+    trim_space(msg, len, off, out_len);
+}
+
+extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t **tape_out, size_t *tape_len,
+                                 uint8_t **strings_out, size_t *strings_len, size_t *msg_off, size_t *msg_len) {
+    const bool ndjson = flags & 1, copy = flags & 2;
+    size_t off, len;
+    trim_space(msg0, len0, &off, &len);
+    *msg_off = off;
+    *msg_len = len;
+    *tape_out = nullptr;
+    *strings_out = nullptr;
+    *tape_len = *strings_len = 0;
+    const u8 *msg = msg0 + off;
+    // stage 1
+    std::vector<u32> pos(len + 64);
+    size_t n = 0;
+    u32 err = 0, inq = 0;
+    sj_selftest_stage1(msg, len, ndjson, pos.data(), pos.size(), &n, &err, &inq);
+    if (len == 0 || err || inq || n == 0 || !(msg[len - 1] == '}' || msg[len - 1] == ']')) return 1;
+    const MsgView mv{msg, len};
+    // stage 2
+    std::vector<u8> kind(n), ctxb(n, 0);
+    std::vector<i32> depth(n);
+    std::vector<u32> toff(n), soff(n), lastbr(n), match(n, 0), dlen(n, 0), nlb;
+    std::vector<u8> needcopy(n, 0);
+    u32 bad = 0;
+    for (size_t i = 0; i < n; i++) kind[i] = token_kind(msg[pos[i]], ndjson);
+    for (size_t i = 0; i < n; i++)
+        if (kind[i] == K_STRING) {
+            u32 sl, dl;
+            if (!string_walk(mv, pos[i], nullptr, &sl, &dl)) bad = 1;
+            else {
+                dlen[i] = dl;
+                needcopy[i] = copy || sl != dl;
+            }
+        }
+    i32 d = 0;
+    u32 words = 1, sbytes = 0, lb = 0;
+    for (size_t i = 0; i < n; i++) {
+        d += depth_delta(kind[i]);
+        depth[i] = d;
+        toff[i] = words;
+        words += tape_words(kind[i], i + 1 < n ? kind[i + 1] : (u8)K_BAD, i + 1 == n);
+        soff[i] = sbytes;
+        if (kind[i] == K_STRING && needcopy[i]) sbytes += dlen[i];
+        if (is_bracket(kind[i])) lb = (u32)i + 1;
+        lastbr[i] = lb;
+        if (kind[i] == K_NL && i + 1 < n && kind[i + 1] != K_NL) nlb.push_back((u32)i);
+    }
+    const u32 tlen = words + 1;  // + final root
+    if (d != 0) bad = 1;
+    // min tree
+    MinTree mt;
+    std::vector<std::vector<i32>> levels;
+    mt.lev[0] = depth.data();
+    mt.size[0] = n;
+    mt.nlev = 1;
+    while (mt.size[mt.nlev - 1] > 64) {
+        const u64 ps = mt.size[mt.nlev - 1], ns = (ps + 63) / 64;
+        levels.emplace_back(ns);
+        for (u64 g = 0; g < ns; g++) {
+            i32 mn = 0x7fffffff;
+            for (u64 k = g * 64; k < ps && k < g * 64 + 64; k++) mn = mt.lev[mt.nlev - 1][k] < mn ? mt.lev[mt.nlev - 1][k] : mn;
+            levels.back()[g] = mn;
+        }
+        mt.lev[mt.nlev] = levels.back().data();
+        mt.size[mt.nlev] = ns;
+        mt.nlev++;
+    }
+    for (size_t i = 0; i < n; i++)
+        if (is_close(kind[i])) bracket_resolve(mt, kind.data(), depth.data(), (u32)i, match.data(), ctxb.data());
+    Tokens t{pos.data(), (u32)n, kind.data(), depth.data(), toff.data(), soff.data(), lastbr.data(), match.data(), ctxb.data()};
+    u64 *tape = (u64 *)malloc(sizeof(u64) * (tlen + 2));
+    u8 *strs = (u8 *)malloc(sbytes + 64);
+    for (size_t i = 0; i < n; i++) {
+        if (grammar_violation(t, (u32)i)) bad = 1;
+        if (emit_simple(t, mv, (u32)i, tape)) bad = 1;
+        if (kind[i] == K_STRING && !bad) emit_string(t, mv, (u32)i, needcopy[i], dlen[i], tape, strs);
+        if (kind[i] == K_NUM) {
+            u64 tag, val;
+            int ub;
+            if (!sj_selftest_parse_number(msg + pos[i], len - pos[i], &tag, &val, &ub)) bad = 1;
+            else {
+                tape[toff[i]] = tag;
+                tape[toff[i] + 1] = val;
+            }
+        }
+    }
+    for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape);
+    if (bad) {
+        free(tape);
+        free(strs);
+        return 2;
+    }
+    *tape_out = tape;
+    *tape_len = tlen;
+    *strings_out = strs;
+    *strings_len = sbytes;
+    return 0;
+}
+extern "C" void sj_selftest_free(void *p) { free(p); }

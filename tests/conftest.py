@@ -10,3 +10,14 @@ for p in (HERE, ROOT, os.path.join(ROOT, "simdjson-go_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so) while libsjhip.so links the
+    # system one (/opt/rocm).  Both can live in one process, but torch must initialise first,
+    # otherwise its device enumeration fails.  Tests only use torch for device buffers.
+    markexpr = getattr(config.option, "markexpr", "") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
