@@ -127,6 +127,56 @@ def main():
     algo_bytes = n_bytes + 4 * s_expect
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
 
+    # ---- extra legs (not the headline value): full parse of the same document, and NDJSON ----
+    extra = {}
+    try:
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps
+        reps = max(3, min(args.steps, 10))
+        tl = sl = 0
+        def full():
+            nonlocal tl, sl
+            tl, sl = ctx.parse_device(d_msg.data_ptr(), n_bytes, ndjson=False, copy_strings=True)
+        t_full = timed(full, reps)
+        extra["full_parse"] = {"workload": "same document, stage1+stage2 (tape + Strings.B left in HBM)",
+                               "GBps": round(n_bytes / t_full / 1e9, 2), "ms": round(t_full * 1e3, 3),
+                               "tape_words": tl, "strings_bytes": sl}
+        del d_pos
+        # NDJSON: parking-citations x1000 (configs[4]); with N ranks each rank parses 1/N of the records
+        nd_all = workloads.c5_parking_nd(1000)
+        lines_per_rank = 1_000_000 // world
+        per_file = 1000
+        files_per_rank = max(1, 1000 // world)
+        shard = (workloads.c5_parking_nd(files_per_rank)).rstrip(b"\n")
+        d_nd = torch.empty(len(shard) + 256, dtype=torch.uint8, device=dev)
+        d_nd[:len(shard)].copy_(torch.frombuffer(bytearray(shard), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        def ndp():
+            nonlocal tl, sl
+            tl, sl = ctx.parse_device(d_nd.data_ptr(), len(shard), ndjson=True, copy_strings=True)
+        if distributed:
+            dist.barrier()
+        t_nd = timed(ndp, reps)
+        sizes = torch.tensor([tl, sl], dtype=torch.int64, device=dev)
+        if distributed:  # the only exchange the merged ParseND tape needs: per-shard (tape_len, strings_len)
+            gathered = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(gathered, sizes)
+            tmax = torch.tensor([t_nd], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            t_nd = float(tmax.item())
+        extra["ndjson"] = {"workload": f"configs[4]: parking-citations.json x{files_per_rank} per rank, ParseND, "
+                                       f"{world} shard(s) cut at record boundaries", "bytes_per_gpu": len(shard),
+                           "GBps": round(world * len(shard) / t_nd / 1e9, 2), "ms": round(t_nd * 1e3, 3),
+                           "tape_words_per_gpu": tl, "strings_bytes_per_gpu": sl}
+    except Exception as e:  # the headline number must still be reported
+        extra["extra_error"] = repr(e)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * n_bytes / (dt / args.steps) / 1e9
@@ -152,6 +202,7 @@ def main():
                          "algorithmic_bytes": algo_bytes,
                          "input_GBps": round(n_bytes / (k_ms * 1e-3) / 1e9, 1)},
         }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -54,6 +54,20 @@ const char *sjhip_last_error(const sjhip_ctx *ctx);
 /* run the context's work on an existing HIP stream (e.g. torch's current stream); NULL = own stream */
 int sjhip_ctx_set_stream(sjhip_ctx *ctx, void *hip_stream);
 
+/* ---- whole parse: replaces parseMessage (parse_json_amd64.go:52-127) ------------------------
+ * msg is a HOST buffer.  The library applies bytes.TrimSpace (parse_json_amd64.go:55) and reports
+ * the trimmed window so that the caller can alias pj.Message = msg[msg_off : msg_off+msg_len].
+ * On SJHIP_OK the tape/strings stay on the device until sjhip_fetch copies them into
+ * caller-owned memory of at least tape_len*8 / strings_len bytes. */
+int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len,
+                size_t *strings_len, size_t *msg_off, size_t *msg_len);
+int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
+
+/* Same parse on a message that is already resident in device memory (already trimmed). Used by
+ * bench.py (inputs in HBM before the timed region) and by the multi-GPU shard path. */
+int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
+                       size_t *strings_len);
+
 /* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------
  * pos_out receives ABSOLUTE uint32 byte positions (running sum of the reference's deltas).
  * *ok = the reference's return value (error_mask == 0 && indexTotal > 0 && end-of-doc checks). */

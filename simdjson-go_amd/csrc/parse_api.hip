@@ -1,0 +1,101 @@
+// parse_api.hip -- whole-parse entry points of the C ABI: sjhip_parse / sjhip_parse_device /
+// sjhip_fetch.  Mirrors parseMessage (parse_json_amd64.go:52-127): TrimSpace, stage 1, stage 2,
+// and the reference's error precedence (a stage-1 failure is reported even when stage 2 would
+// fail as well, :97-105 and :123-126).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/sjhip.h"
+#include "sj_ctx.h"
+#include "sj_device.h"
+#include "sj_host.h"
+
+using namespace sj;
+
+#define HIPCHK(call, what)                                        \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return ctx_hip_fail(ctx, e_, what); \
+    } while (0)
+
+static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte,
+                           int have_last, size_t *tape_len, size_t *strings_len) {
+    ctx->tape_len = ctx->strings_len = 0;
+    if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    // structural density is 0.02..0.22 per byte on real documents; start with len/3 and retry once
+    size_t pos_cap = len / 3 + 4096;
+    size_t n = 0;
+    int ok = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * sizeof(uint32_t));
+        if (rc) return rc;
+        rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
+                               have_last, &n, &ok);
+        if (rc) return rc;
+        if (n <= pos_cap) break;
+        pos_cap = n;
+    }
+    if (!ok) return SJHIP_ERR_STAGE1;
+    int rc = arena_reserve(ctx, ctx->d_s2, stage2_workspace_bytes(n));
+    if (rc) return rc;
+    const size_t tape_cap = 2 * n + 2;
+    const size_t strings_cap = len + 64;
+    rc = arena_reserve(ctx, ctx->d_tape, tape_cap * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = arena_reserve(ctx, ctx->d_strings, strings_cap);
+    if (rc) return rc;
+    HIPCHK(stage2_launch(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, (uint64_t *)ctx->d_tape.p,
+                         tape_cap, (uint8_t *)ctx->d_strings.p, strings_cap, ctx->stream),
+           "stage2 launch");
+    S2State *hs = (S2State *)(ctx->h_scratch + 256);
+    HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+    if (hs->err & 4u) {
+        ctx_set_error(ctx, "tape longer than 2^32 words");
+        return SJHIP_ERR_TOOBIG;
+    }
+    if (hs->err) return SJHIP_ERR_STAGE2;
+    ctx->tape_len = (size_t)hs->tape_len;
+    ctx->strings_len = (size_t)hs->strings_len;
+    if (tape_len) *tape_len = ctx->tape_len;
+    if (strings_len) *strings_len = ctx->strings_len;
+    return SJHIP_OK;
+}
+
+int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
+                       size_t *strings_len) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    return parse_on_device(ctx, d_msg, len, flags, 0, 0, tape_len, strings_len);
+}
+
+int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len, size_t *strings_len,
+                size_t *msg_off, size_t *msg_len) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    size_t off = 0, mlen = 0;
+    if (len) trim_space(msg, len, &off, &mlen);  // pj.Message = bytes.TrimSpace(msg), parse_json_amd64.go:55
+    if (msg_off) *msg_off = off;
+    if (msg_len) *msg_len = mlen;
+    if (tape_len) *tape_len = 0;
+    if (strings_len) *strings_len = 0;
+    ctx->tape_len = ctx->strings_len = 0;
+    if (mlen == 0) return SJHIP_ERR_STAGE1;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc = arena_reserve(ctx, ctx->d_msg, mlen + 128);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_msg.p, msg + off, mlen, hipMemcpyHostToDevice, ctx->stream), "H2D message");
+    return parse_on_device(ctx, ctx->d_msg.p, mlen, flags, msg[off + mlen - 1], 1, tape_len, strings_len);
+}
+
+int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->tape_len && tape_dst)
+        HIPCHK(hipMemcpyAsync(tape_dst, ctx->d_tape.p, ctx->tape_len * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream),
+               "D2H tape");
+    if (ctx->strings_len && strings_dst)
+        HIPCHK(hipMemcpyAsync(strings_dst, ctx->d_strings.p, ctx->strings_len, hipMemcpyDeviceToHost, ctx->stream),
+               "D2H strings");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "fetch sync");
+    return SJHIP_OK;
+}

@@ -17,6 +17,23 @@ struct Stage1State {
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
 
+// stage-2 totals and flags (zeroed before every launch)
+struct S2State {
+    uint32_t err;            // bit0: stage-2 failure, bit2: tape would exceed 2^32 words
+    uint32_t bignum_count;   // numbers queued for the big-integer tie-break
+    int32_t final_depth;
+    uint32_t records;        // record-separating newline runs (ND)
+    unsigned long long tape_len;
+    unsigned long long strings_len;
+    uint32_t pad[8];
+};
+static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
+
+size_t stage2_workspace_bytes(size_t n_tokens);
+hipError_t stage2_launch(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
+                         uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
+                         hipStream_t stream);
+
 size_t stage1_workspace_bytes(size_t len);
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,

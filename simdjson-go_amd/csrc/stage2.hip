@@ -1,0 +1,424 @@
+// stage2.hip -- stage 2 (tape build, string unescape, number parse) as follow-on kernels over the
+// structural-index array produced by stage 1.  Replaces unifiedMachine
+// (stage2_build_tape_amd64.go:160-446), parseString (:72-113), parse_string_amd64.s and
+// parseNumber (parse_number.go:65-135).  The per-token logic lives in sj_stage2.h / sj_number.h /
+// sj_bignum.h (host+device, replayed on the CPU by the test-suite); this file holds the kernels,
+// the device-wide scans and the launcher.  No host synchronisation happens between the kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sj_bignum.h"
+#include "sj_chunk.h"
+#include "sj_device.h"
+#include "sj_number.h"
+#include "sj_stage2.h"
+
+namespace sj {
+
+static constexpr int S2_BLOCK = 256;
+static constexpr int S2_ITEMS = 4;
+static constexpr int S2_TILE = S2_BLOCK * S2_ITEMS;
+static constexpr u32 DLEN_INVALID = 0xffffffffu;
+static constexpr u32 DLEN_COPY = 0x80000000u;
+
+// device view of all stage-2 arrays (carved out of one workspace by the launcher)
+struct S2Dev {
+    const u8 *msg;
+    u64 len;
+    const u32 *pos;
+    u32 n;
+    u32 ndjson, copy_strings;
+    u8 *kind;      // [n]
+    u32 *dlen;     // [n] strings: unescaped length | DLEN_COPY, or DLEN_INVALID
+    i32 *depth;    // [n]
+    u32 *tape_off; // [n]
+    u32 *str_off;  // [n]
+    u32 *last_br;  // [n]
+    u32 *match;    // [n] brackets: partner; record-separating newline: its ordinal
+    u8 *ctxb;      // [n]
+    u32 *nlb;      // [n] token indexes of record-separating newlines
+    u32 *bigq;     // [n] queue of number tokens that need the big-integer tie-break
+    // tile aggregates / exclusive prefixes
+    i32 *agg_d;
+    u32 *agg_w, *agg_s, *agg_lb, *agg_nb;
+    u32 tiles;
+    // min tree levels 1.. (level 0 is depth[])
+    i32 *lev[MinTree::MAXLEV];
+    u64 lev_size[MinTree::MAXLEV];
+    int nlev;
+    S2State *st;
+    u64 *tape;
+    u8 *strings;
+    u64 tape_cap, strings_cap;
+};
+
+struct Agg {
+    i32 d;
+    u32 w, s, lb, nb;
+};
+__device__ __forceinline__ Agg agg_combine(const Agg &a, const Agg &b) {
+    return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.lb > b.lb ? a.lb : b.lb, a.nb + b.nb};
+}
+__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
+    return Agg{__shfl_up(a.d, delta, 64), __shfl_up(a.w, delta, 64), __shfl_up(a.s, delta, 64), __shfl_up(a.lb, delta, 64),
+               __shfl_up(a.nb, delta, 64)};
+}
+
+__device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
+    const u8 k = p.kind[i];
+    const bool last = i + 1 == p.n;
+    const u8 nk = last ? (u8)K_BAD : p.kind[i + 1];
+    Agg a;
+    a.d = depth_delta(k);
+    a.w = tape_words(k, nk, last);
+    const u32 dl = p.dlen[i];
+    a.s = (k == K_STRING && dl != DLEN_INVALID && (dl & DLEN_COPY)) ? (dl & ~DLEN_COPY) : 0u;
+    a.lb = is_bracket(k) ? i + 1 : 0u;
+    a.nb = (k == K_NL && !last && nk != K_NL) ? 1u : 0u;
+    return a;
+}
+
+// ---- kernel 1: token kinds ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_token_kind(S2Dev p) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    p.kind[i] = token_kind(p.msg[p.pos[i]], p.ndjson != 0);
+}
+
+// ---- kernel 2: string lengths (parseStringSimdValidateOnly) --------------------------------------------
+__global__ __launch_bounds__(256) void k_string_measure(S2Dev p) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    u32 out = 0;
+    if (p.kind[i] == K_STRING) {
+        const MsgView mv{p.msg, p.len};
+        u32 sl, dl;
+        if (!string_walk(mv, p.pos[i], nullptr, &sl, &dl)) {
+            out = DLEN_INVALID;
+            atomicOr(&p.st->err, 1u);
+        } else {
+            out = dl | ((p.copy_strings || sl != dl) ? DLEN_COPY : 0u);
+        }
+    }
+    p.dlen[i] = out;
+}
+
+// ---- kernels 3-5: device-wide scan of (depth, tape words, string bytes, last bracket, newline runs) -----
+__device__ __forceinline__ Agg block_reduce(Agg v, Agg *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const Agg o = agg_shfl_up(v, s);
+        if (lane >= s) v = agg_combine(o, v);
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    Agg tot = lds[0];
+    for (int w = 1; w < S2_BLOCK / 64; w++) tot = agg_combine(tot, lds[w]);
+    return tot;
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void k_scan_reduce(S2Dev p) {
+    __shared__ Agg lds[S2_BLOCK / 64];
+    const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
+    Agg v{0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++)
+        if (base + k < p.n) v = agg_combine(v, token_agg(p, base + k));
+    const Agg tot = block_reduce(v, lds);
+    if (threadIdx.x == 0) {
+        p.agg_d[blockIdx.x] = tot.d;
+        p.agg_w[blockIdx.x] = tot.w;
+        p.agg_s[blockIdx.x] = tot.s;
+        p.agg_lb[blockIdx.x] = tot.lb;
+        p.agg_nb[blockIdx.x] = tot.nb;
+    }
+}
+
+// one block: exclusive scan over the tile aggregates (in place) + totals
+__global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
+    __shared__ Agg lds[16];
+    __shared__ Agg carry_s;
+    __shared__ unsigned long long words64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        carry_s = Agg{0, 0, 0, 0, 0};
+        words64 = 0;
+    }
+    __syncthreads();
+    for (u32 start = 0; start < p.tiles; start += 1024) {
+        const u32 t = start + threadIdx.x;
+        Agg incl{0, 0, 0, 0, 0};
+        if (t < p.tiles) incl = Agg{p.agg_d[t], p.agg_w[t], p.agg_s[t], p.agg_lb[t], p.agg_nb[t]};
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {  // inclusive scan inside the wave
+            const Agg o = agg_shfl_up(incl, s);
+            if (lane >= s) incl = agg_combine(o, incl);
+        }
+        if (lane == 63) lds[wave] = incl;
+        __syncthreads();
+        Agg before = carry_s;  // everything in front of this wave
+        for (int w = 0; w < wave; w++) before = agg_combine(before, lds[w]);
+        const Agg prev = agg_shfl_up(incl, 1);
+        const Agg excl = lane > 0 ? agg_combine(before, prev) : before;
+        if (t < p.tiles) {
+            p.agg_d[t] = excl.d;
+            p.agg_w[t] = excl.w;
+            p.agg_s[t] = excl.s;
+            p.agg_lb[t] = excl.lb;
+            p.agg_nb[t] = excl.nb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            const Agg total = agg_combine(before, incl);
+            words64 += (unsigned long long)(u32)(total.w - carry_s.w);  // chunk sum < 2^32
+            carry_s = total;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const Agg tot = carry_s;
+        p.st->final_depth = tot.d;
+        p.st->tape_len = words64 + 2ull;  // + opening root + closing root
+        p.st->strings_len = tot.s;
+        p.st->records = tot.nb;
+        if (words64 + 2ull > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
+        if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
+    }
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void k_scan_apply(S2Dev p) {
+    __shared__ Agg lds[S2_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
+    Agg item[S2_ITEMS];
+    Agg v{0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) {
+        item[k] = (base + k < p.n) ? token_agg(p, base + k) : Agg{0, 0, 0, 0, 0};
+        v = agg_combine(v, item[k]);
+    }
+    Agg incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const Agg o = agg_shfl_up(incl, s);
+        if (lane >= s) incl = agg_combine(o, incl);
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    Agg run{p.agg_d[blockIdx.x], p.agg_w[blockIdx.x], p.agg_s[blockIdx.x], p.agg_lb[blockIdx.x], p.agg_nb[blockIdx.x]};
+    for (int w = 0; w < wave; w++) run = agg_combine(run, lds[w]);
+    {
+        const Agg prev = agg_shfl_up(incl, 1);
+        if (lane > 0) run = agg_combine(run, prev);
+    }
+    // run = exclusive prefix for this thread's first token
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) {
+        const u32 i = base + k;
+        if (i >= p.n) break;
+        const Agg a = item[k];
+        p.tape_off[i] = run.w + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
+        p.str_off[i] = run.s;
+        if (a.nb) {
+            p.nlb[run.nb] = i;
+            p.match[i] = run.nb;
+        }
+        run = agg_combine(run, a);
+        p.depth[i] = run.d;
+        p.last_br[i] = run.lb;
+    }
+}
+
+// ---- kernel 6: one level of the 64-ary min tree (one wave per group) -------------------------------------
+__global__ __launch_bounds__(256) void k_min_level(const i32 *src, u64 n_src, i32 *dst, u64 n_dst) {
+    const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_dst) return;
+    const int lane = threadIdx.x & 63;
+    const u64 k = g * 64 + lane;
+    i32 v = k < n_src ? src[k] : 0x7fffffff;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i32 o = __shfl_xor(v, s, 64);
+        v = o < v ? o : v;
+    }
+    if (lane == 0) dst[g] = v;
+}
+
+__device__ __forceinline__ MinTree make_tree(const S2Dev &p) {
+    MinTree mt;
+    mt.lev[0] = p.depth;
+    mt.size[0] = p.n;
+    mt.nlev = p.nlev;
+    for (int l = 1; l < p.nlev; l++) {
+        mt.lev[l] = p.lev[l];
+        mt.size[l] = p.lev_size[l];
+    }
+    return mt;
+}
+__device__ __forceinline__ Tokens make_tokens(const S2Dev &p) {
+    return Tokens{p.pos, p.n, p.kind, p.depth, p.tape_off, p.str_off, p.last_br, p.match, p.ctxb};
+}
+
+// ---- kernel 7: bracket partners and resume contexts -------------------------------------------------------
+__global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    if (!is_close(p.kind[i])) return;
+    const MinTree mt = make_tree(p);
+    bracket_resolve(mt, p.kind, p.depth, i, p.match, p.ctxb);
+}
+
+// ---- kernel 8: grammar check + tape words of brackets, atoms, numbers and roots ----------------------------
+__global__ __launch_bounds__(256) void k_emit(S2Dev p) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const Tokens t = make_tokens(p);
+    const MsgView mv{p.msg, p.len};
+    const u64 tape_len = p.st->tape_len;
+    if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
+    bool bad = grammar_violation(t, i);
+    bad |= emit_simple(t, mv, i, p.tape);
+    const u8 k = p.kind[i];
+    if (k == K_NUM) {
+        u64 tag = 0, val = 0;
+        u32 numlen = 0;
+        const u32 at = p.pos[i];
+        const int st = parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
+        if (st == NUM_FAIL) {
+            bad = true;
+        } else {
+            const u32 o = p.tape_off[i];
+            p.tape[o] = tag;
+            p.tape[o + 1] = val;
+            if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = i;
+        }
+    } else if (k == K_NL) {
+        if (i + 1 < p.n && p.kind[i + 1] != K_NL)
+            emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, p.match[i] + 1, p.tape);
+    }
+    if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape);
+    if (bad) atomicOr(&p.st->err, 1u);
+}
+
+// ---- kernel 9: strings (tape words + unescaped copy into Strings.B) -----------------------------------------
+__global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    if (p.kind[i] != K_STRING) return;
+    const u32 dl = p.dlen[i];
+    if (dl == DLEN_INVALID) return;
+    if ((u64)p.str_off[i] + (dl & ~DLEN_COPY) > p.strings_cap) return;
+    const Tokens t = make_tokens(p);
+    const MsgView mv{p.msg, p.len};
+    emit_string(t, mv, i, (dl & DLEN_COPY) != 0, dl & ~DLEN_COPY, p.tape, p.strings);
+}
+
+// ---- kernel 10: exact tie-break for >19-digit mantissas whose neighbours disagree ------------------------------
+__global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
+    const u32 cnt = p.st->bignum_count;
+    Big X, Y;
+    for (u32 q = blockIdx.x * 64 + threadIdx.x; q < cnt; q += gridDim.x * 64) {
+        const u32 i = p.bigq[q];
+        const u32 at = p.pos[i];
+        u64 tag, val;
+        u32 numlen = 0;
+        (void)parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
+        const u32 o = p.tape_off[i];
+        const u64 cand = p.tape[o + 1];
+        const u64 sign = cand & 0x8000000000000000ull;
+        const u64 r = bignum_round(p.msg + at, numlen, cand & ~0x8000000000000000ull, X, Y);
+        if (r == 0x7ff0000000000000ull) atomicOr(&p.st->err, 1u);  // strconv.ErrRange
+        p.tape[o + 1] = r | sign;
+    }
+}
+
+// ---- launcher -----------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t stage2_workspace_bytes(size_t n) {
+    size_t b = sizeof(S2State) + 256;
+    b += align_up(n, 256) * 2;                      // kind, ctxb
+    b += align_up(n * 4, 256) * 9;                  // dlen depth tape_off str_off last_br match nlb bigq (+1 spare)
+    const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
+    b += align_up(tiles * 4, 256) * 5;
+    size_t lv = n;
+    for (int l = 1; l < MinTree::MAXLEV; l++) {
+        lv = (lv + 63) / 64;
+        b += align_up(lv * 4, 256);
+    }
+    return b + 4096;
+}
+
+hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
+                         size_t tape_cap, u8 *d_strings, size_t strings_cap, hipStream_t stream) {
+    S2Dev p;
+    char *w = reinterpret_cast<char *>(ws);
+    auto carve = [&](size_t bytes) {
+        char *r = w;
+        w += align_up(bytes, 256);
+        return r;
+    };
+    p.st = reinterpret_cast<S2State *>(carve(sizeof(S2State)));
+    p.msg = reinterpret_cast<const u8 *>(d_msg);
+    p.len = len;
+    p.pos = d_pos;
+    p.n = (u32)n;
+    p.ndjson = flags & 1u;
+    p.copy_strings = (flags >> 1) & 1u;
+    p.kind = reinterpret_cast<u8 *>(carve(n));
+    p.ctxb = reinterpret_cast<u8 *>(carve(n));
+    p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
+    p.depth = reinterpret_cast<i32 *>(carve(n * 4));
+    p.tape_off = reinterpret_cast<u32 *>(carve(n * 4));
+    p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
+    p.last_br = reinterpret_cast<u32 *>(carve(n * 4));
+    p.match = reinterpret_cast<u32 *>(carve(n * 4));
+    p.nlb = reinterpret_cast<u32 *>(carve(n * 4));
+    p.bigq = reinterpret_cast<u32 *>(carve(n * 4));
+    p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
+    p.agg_d = reinterpret_cast<i32 *>(carve((size_t)p.tiles * 4));
+    p.agg_w = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.agg_s = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.agg_lb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.agg_nb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.nlev = 1;
+    p.lev[0] = nullptr;
+    p.lev_size[0] = n;
+    {
+        u64 sz = n;
+        while (sz > 64 && p.nlev < MinTree::MAXLEV) {
+            sz = (sz + 63) / 64;
+            p.lev[p.nlev] = reinterpret_cast<i32 *>(carve(sz * 4));
+            p.lev_size[p.nlev] = sz;
+            p.nlev++;
+        }
+    }
+    p.tape = d_tape;
+    p.strings = d_strings;
+    p.tape_cap = tape_cap;
+    p.strings_cap = strings_cap;
+
+    hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(p.match, 0, n * 4, stream);
+    if (e != hipSuccess) return e;
+    const u32 gb = (u32)((n + 255) / 256);
+    hipLaunchKernelGGL(k_token_kind, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_string_measure, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(k_scan_apply, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    for (int l = 1; l < p.nlev; l++) {
+        const i32 *src = l == 1 ? p.depth : p.lev[l - 1];
+        const u64 ns = p.lev_size[l - 1], nd = p.lev_size[l];
+        hipLaunchKernelGGL(k_min_level, dim3((u32)((nd + 3) / 4)), dim3(256), 0, stream, src, ns, p.lev[l], nd);
+    }
+    hipLaunchKernelGGL(k_brackets, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace sj

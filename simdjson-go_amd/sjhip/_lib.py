@@ -21,6 +21,9 @@ SYMBOLS = {
     "sjhip_ctx_destroy": (None, [C.c_void_p]),
     "sjhip_last_error": (C.c_char_p, [C.c_void_p]),
     "sjhip_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sjhip_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
+    "sjhip_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sjhip_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
     "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,
                                       intp]),

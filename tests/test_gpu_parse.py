@@ -1,0 +1,229 @@
+"""GPU parity tests for the whole Parse()/ParseND() path (run with -m gpu on an MI355X):
+Tape and Strings.B produced by the HIP kernels, fetched through the C ABI, must be bit-identical
+to the oracle's; for rejected documents the error class (stage 1 / stage 2) must match."""
+import random
+
+import numpy as np
+import pytest
+
+import fixtures
+import golden_util as GU
+import oracle_lib as O
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sjhip
+    assert sjhip.supported(), "gfx950 device required"
+    c = sjhip.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_parse(ctx, data, nd, copy):
+    import sjhip
+    try:
+        pj = ctx.parse(data, ndjson=nd, copy_strings=copy)
+        return 0, pj
+    except sjhip.ParseError as e:
+        return e.code, None
+
+
+def check(ctx, data, nd=False, what=""):
+    for copy in (True, False):
+        ref = O.parse(data, ndjson=nd, copy_strings=copy)
+        rc, pj = gpu_parse(ctx, data, nd, copy)
+        assert rc == ref.rc, (what, nd, copy, rc, ref.rc, data[:80])
+        if rc == 0:
+            assert pj.Message == bytes(data[ref.msg_off:ref.msg_off + ref.msg_len]), what
+            assert len(pj.Tape) == len(ref.tape), (what, nd, copy, len(pj.Tape), len(ref.tape))
+            if not np.array_equal(pj.Tape, ref.tape):
+                d = np.nonzero(pj.Tape != ref.tape)[0]
+                raise AssertionError((what, nd, copy, "tape differs at", d[:5], [hex(int(x)) for x in pj.Tape[d[:3]]],
+                                      [hex(int(x)) for x in ref.tape[d[:3]]]))
+            assert np.array_equal(pj.Strings, ref.strings), (what, nd, copy, "strings differ")
+
+
+S2 = GU.load("stage2")
+CORP = GU.load("corpus")
+NUM = GU.load("numbers")
+
+
+def test_golden_tapes(ctx):  # stage2_build_tape_amd64_test.go:26-193, ndjson_test.go:36-248
+    import sjhip
+    for t in S2["tapes_nocopy"]:
+        pj = ctx.parse(bytes.fromhex(t["input_hex"]), copy_strings=False)
+        assert [int(x) for x in pj.Tape] == [int(x) for x in t["tape"]]
+    pj = ctx.parse(bytes.fromhex(S2["demo_ndjson_hex"]), ndjson=True, copy_strings=False)
+    assert [int(x) for x in pj.Tape] == [int(x) for x in S2["demo_ndjson_tape_nocopy"]]
+    for hx in S2["ndjson_empty_lines_hex"]:
+        ctx.parse(bytes.fromhex(hx), ndjson=True)
+
+
+@pytest.mark.parametrize("name", fixtures.ALL)
+def test_fixture_tapes_equal_oracle(ctx, name):
+    data = fixtures.load(name)
+    check(ctx, data, nd=(name == "parking-citations"), what=name)
+    if name not in ("parking-citations",):
+        check(ctx, data, nd=True, what=name + "/nd")
+
+
+def test_reference_corpora(ctx):  # simdjson_amd64_test.go fail / pass / ND tables
+    for key in ("fail_cases", "pass_cases"):
+        for c in CORP[key]:
+            check(ctx, bytes.fromhex(c["js_hex"]), False, c["name"])
+    for c in CORP["parse_nd"]:
+        check(ctx, bytes.fromhex(c["js_hex"]), True, c["name"])
+
+
+def test_string_table_through_parse(ctx):  # parse_string_test.go:19-235
+    for r in GU.load("strings"):
+        body = bytes.fromhex(r["str_hex"])
+        check(ctx, b'["' + body + b'"]', False, r["name"])
+        check(ctx, b'{"' + body + b'":"' + body + b'x"}', False, r["name"])
+
+
+def test_number_tables_through_parse(ctx):  # parse_json_amd64_test.go:222-538, parse_number_test.go
+    for r in NUM["atof"] + NUM["parse_int64"] + NUM["parse_number"]:
+        s = r["input"].encode()
+        check(ctx, b"[" + s + b"]", False, "num " + r["input"][:30])
+        check(ctx, b'{"a":' + s + b"}", False, "num " + r["input"][:30])
+    for s in NUM["valid"] + NUM["invalid"]:
+        check(ctx, b"[1," + s.encode() + b",2]", False, "numv " + s)
+
+
+def test_float_rounding_torture(ctx):
+    import struct
+    import decimal
+    decimal.getcontext().prec = 1200
+    rnd = random.Random(99)
+    docs = []
+    for i in range(3000):
+        bits = rnd.getrandbits(64) & 0x7FFFFFFFFFFFFFFF
+        if (bits >> 52) == 0x7FF:
+            continue
+        d = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        docs.append(repr(d))
+        docs.append("%.25e" % d)
+        nxt = struct.unpack("<d", struct.pack("<Q", bits + 1))[0]
+        if nxt != float("inf"):
+            mid = (decimal.Decimal(d) + decimal.Decimal(nxt)) / 2
+            s = format(mid, "e")
+            m, e = s.split("e")
+            docs += [s, m + "1e" + e, m + "00000000000000000001e" + e]
+    for i in range(0, len(docs), 500):
+        check(ctx, ("[" + ",".join(docs[i:i + 500]) + "]").encode(), False, "floats")
+
+
+def test_random_documents(ctx):
+    rnd = random.Random(5)
+    rng = np.random.default_rng(7)
+    alpha = np.frombuffer(b'{}[]:,"""  \n\\tfn0123-.e"a', dtype=np.uint8)
+    for trial in range(600):
+        body = bytes(alpha[rng.integers(0, alpha.size, int(rng.integers(1, 40)))])
+        check(ctx, body, bool(trial & 1), "soup")
+
+    def gen(depth=0):
+        r = rnd.random()
+        if depth > 6 or r < 0.3:
+            return rnd.choice(['1', '-2.5e3', 'true', 'false', 'null', '"s"', '"a\\nb"', '"\\u00e9"', '[]', '{}',
+                               '12345678901234567890', '0.1', '"\\ud83d\\ude00"'])
+        if r < 0.65:
+            return '[' + ','.join(gen(depth + 1) for _ in range(rnd.randint(0, 5))) + ']'
+        return '{' + ','.join('"k%d":%s' % (i, gen(depth + 1)) for i in range(rnd.randint(0, 5))) + '}'
+
+    for trial in range(300):
+        doc = gen()
+        if doc[0] not in '[{':
+            doc = '[' + doc + ']'
+        doc = doc.replace(',', ',' + rnd.choice(['', ' ', '\n ', '\t']))
+        check(ctx, doc.encode(), False, 'gen')
+        b = bytearray(doc.encode())
+        if len(b) > 2:
+            b[rnd.randrange(len(b))] = rnd.choice(b'{}[]:,"\\ 1tx')
+            check(ctx, bytes(b), False, 'mut')
+        lines = '\n'.join('{"a":%s}' % gen() for _ in range(rnd.randint(1, 5)))
+        check(ctx, lines.encode(), True, 'gennd')
+
+
+def test_deep_nesting_and_long_flat_containers(ctx):
+    check(ctx, b"[" * 5000 + b"]" * 5000, False, "deep")
+    check(ctx, b"[" * 5000 + b"]" * 4999, False, "deep-unbalanced")
+    check(ctx, b'{"a":' * 3000 + b"1" + b"}" * 3000, False, "deep-obj")
+    check(ctx, b"[" + b",".join(b"%d" % i for i in range(200000)) + b"]", False, "flat")
+    check(ctx, b"[" + b",".join(b"[%d,%d]" % (i, i) for i in range(100000)) + b"]", False, "pairs")
+    check(ctx, b"[" + b",".join(b'{"k":"v%d"}' % i for i in range(50000)) + b"]", False, "objs")
+    check(ctx, b"\n".join(b'{"k":[%d,{"z":null}]}' % i for i in range(50000)), True, "nd-many")
+
+
+def test_trim_space_variants(ctx):
+    for pre in (b"", b" \t\r\n", b"\x0b\x0c", "  ".encode(), b"\xc2\x85"):
+        for post in (b"", b"\n\n", "　".encode(), b" \xe2\x80\xa8"):
+            check(ctx, pre + b'{"a":[1,2,"x"]}' + post, False, "trim")
+            check(ctx, pre + b'{"a":1}\n{"b":2}' + post, True, "trim-nd")
+    check(ctx, b"   ", False, "blank")
+    check(ctx, b"", False, "empty")
+
+
+def test_multi_tile_documents(ctx):
+    check(ctx, workloads.c2_twitter_array(12), False, "twitter x12")
+    check(ctx, fixtures.load("parking-citations") * 12, True, "parking x12")
+    check(ctx, b"[" + b",".join([fixtures.load("canada").strip()] * 4) + b"]", False, "canada x4")
+
+
+def test_full_size_properties(ctx):
+    """BASELINE sizes: lengths are checked against the closed forms of SURVEY.md §8d and the tape
+    of every copy must be copy 0's tape rebased (a checksum of the structure, not of the data)."""
+    import torch
+    # C2: twitter x426 in one array
+    doc = workloads.c2_twitter_array(426)
+    dev = torch.empty(len(doc) + 256, dtype=torch.uint8, device="cuda:0")
+    dev[:len(doc)].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    tl, sl = ctx.parse_device(dev.data_ptr(), len(doc), ndjson=False, copy_strings=True)
+    one = O.parse(fixtures.load("twitter"))
+    assert tl == 426 * (len(one.tape) - 2) + 4
+    assert sl == 426 * len(one.strings)
+    tape, strings = ctx.fetch(tl, sl)
+    per = len(one.tape) - 2
+    body0 = tape[2:2 + per]
+    assert np.array_equal(strings[:len(one.strings)], one.strings)
+    k = 300
+    bodyk = tape[2 + k * per: 2 + (k + 1) * per]
+    tag0, tagk = body0 >> np.uint64(56), bodyk >> np.uint64(56)
+    assert np.array_equal(tag0, tagk)
+    del dev
+    # C5: parking-citations x1000, NDJSON
+    nd = workloads.c5_parking_nd(1000).rstrip(b"\n")
+    dev = torch.empty(len(nd) + 256, dtype=torch.uint8, device="cuda:0")
+    dev[:len(nd)].copy_(torch.frombuffer(bytearray(nd), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    tl, sl = ctx.parse_device(dev.data_ptr(), len(nd), ndjson=True, copy_strings=True)
+    assert tl == 80_000_000 and sl == 256_664_000
+    tape, strings = ctx.fetch(tl, sl)
+    ref = O.parse(fixtures.load("parking-citations"), ndjson=True)
+    assert np.array_equal(tape[:len(ref.tape) - 1], ref.tape[:-1])          # first file (its last root is re-chained)
+    assert np.array_equal(strings[:len(ref.strings)], ref.strings)
+    assert np.array_equal(strings[-len(ref.strings):], ref.strings)
+    tags = tape >> np.uint64(56)
+    assert int((tags == ord("r")).sum()) == 2 * 1_000_000
+    # Make == "HOND" (ndjson_test.go:250-267): 116 per file -> 116 000
+    sview = strings
+    idx = np.nonzero(tags == ord('"'))[0]
+    offs = (tape[idx] & np.uint64((1 << 55) - 1)).astype(np.int64)
+    lens = tape[idx + 1].astype(np.int64)
+
+    def eq4(o, word):
+        w = np.frombuffer(word, dtype=np.uint8)
+        o = np.minimum(o, len(sview) - 4)
+        return (sview[o] == w[0]) & (sview[o + 1] == w[1]) & (sview[o + 2] == w[2]) & (sview[o + 3] == w[3])
+
+    l4 = np.nonzero(lens == 4)[0]
+    l4 = l4[l4 + 1 < len(idx)]
+    keys = l4[eq4(offs[l4], b"Make")]
+    vals = keys + 1                      # the value string follows its key in tape order
+    hond = (lens[vals] == 4) & eq4(offs[vals], b"HOND")
+    assert int(hond.sum()) == S2["parking_citations_hond"] * 1000
