@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--copies", type=int, default=426, help="twitter.json copies in the array (426 = 256.56 MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage1-only", action="store_true", help="skip the full-parse / NDJSON extra legs")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +131,8 @@ def main():
     # ---- extra legs (not the headline value): full parse of the same document, and NDJSON ----
     extra = {}
     try:
+        if args.stage1_only:
+            raise StopIteration
         def timed(fn, reps):
             fn()
             torch.cuda.synchronize()
@@ -174,6 +177,8 @@ def main():
                                        f"{world} shard(s) cut at record boundaries", "bytes_per_gpu": len(shard),
                            "GBps": round(world * len(shard) / t_nd / 1e9, 2), "ms": round(t_nd * 1e3, 3),
                            "tape_words_per_gpu": tl, "strings_bytes_per_gpu": sl}
+    except StopIteration:
+        pass
     except Exception as e:  # the headline number must still be reported
         extra["extra_error"] = repr(e)
 

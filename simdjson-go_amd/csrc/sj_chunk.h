@@ -53,6 +53,14 @@ SJ_HD int ctz64(u64 x) {  // x != 0
 // ---- bit-plane transposition -----------------------------------------------------------
 // w[0..15] hold the chunk (little endian: byte j = (w[j>>2] >> 8*(j&3)) & 0xff).
 // plane[k] bit j = bit k of byte j.
+SJ_HD u32 alignbit(u32 hi, u32 lo, u32 sh) {  // ({hi,lo} >> sh)[31:0], sh < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (u32)((((u64)hi << 32) | lo) >> sh);
+#endif
+}
+
 template <int K>
 SJ_HD u64 plane_of(const u32 (&w)[16]) {
     const u32 m = 0x01010101u << K;
@@ -62,10 +70,12 @@ SJ_HD u64 plane_of(const u32 (&w)[16]) {
         u32 a = dot4(w[2 * i] & m, 0x08040201u, 0u);
         piece[i] = dot4(w[2 * i + 1] & m, 0x80402010u, a);  // (8 plane bits) << K
     }
-    // pieces are (bits << K) with bits < 256: pack four per dword, then drop the K shift.
-    u64 lo = (u64)piece[0] | ((u64)piece[1] << 8) | ((u64)piece[2] << 16) | ((u64)piece[3] << 24);
-    u64 hi = (u64)piece[4] | ((u64)piece[5] << 8) | ((u64)piece[6] << 16) | ((u64)piece[7] << 24);
-    return ((lo >> K) & 0xffffffffull) | ((hi >> K) << 32);
+    // pieces are (bits << K) with bits < 256: pack pairs (no overlap), then funnel-shift the K away
+    const u32 t01 = piece[0] | (piece[1] << 8), t23 = piece[2] | (piece[3] << 8);
+    const u32 t45 = piece[4] | (piece[5] << 8), t67 = piece[6] | (piece[7] << 8);
+    const u32 lo = alignbit(t23 >> 16, (t23 << 16) | t01, K);
+    const u32 hi = alignbit(t67 >> 16, (t67 << 16) | t45, K);
+    return ((u64)hi << 32) | lo;
 }
 
 struct Classes {
