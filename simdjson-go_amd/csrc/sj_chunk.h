@@ -87,9 +87,22 @@ struct Classes {
     u64 nl;      // '\n'                   (find_newline_delimiters_amd64.s:16-28)
 };
 
+// keeps the instruction scheduler from interleaving all eight planes (register pressure)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SJ_SCHED_FENCE)
+#define SJ_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SJ_FENCE() ((void)0)
+#endif
+
 SJ_HD Classes classify(const u32 (&w)[16]) {
-    const u64 b0 = plane_of<0>(w), b1 = plane_of<1>(w), b2 = plane_of<2>(w), b3 = plane_of<3>(w);
-    const u64 b4 = plane_of<4>(w), b5 = plane_of<5>(w), b6 = plane_of<6>(w), b7 = plane_of<7>(w);
+    const u64 b0 = plane_of<0>(w), b1 = plane_of<1>(w);
+    SJ_FENCE();
+    const u64 b2 = plane_of<2>(w), b3 = plane_of<3>(w);
+    SJ_FENCE();
+    const u64 b4 = plane_of<4>(w), b5 = plane_of<5>(w);
+    SJ_FENCE();
+    const u64 b6 = plane_of<6>(w), b7 = plane_of<7>(w);
+    SJ_FENCE();
     const u64 n0 = ~b0, n1 = ~b1, n2 = ~b2, n3 = ~b3, n4 = ~b4, n5 = ~b5, n6 = ~b6, n7 = ~b7;
     Classes c;
     const u64 hi_001 = n7 & n6 & b5;  // 0x20..0x3f

@@ -4,20 +4,25 @@
 // (find_structural_bits_amd64.s:49-155) and its Go driver findStructuralIndices
 // (stage1_find_marks_amd64.go:41-148).
 //
-// Shape: one 64-byte chunk per lane, BLOCK lanes per tile (BLOCK*64 contiguous bytes).  The
-// three cross-chunk dependencies of the reference loop are resolved like this:
+// Shape: one 64-byte chunk per lane and pass, BLOCK lanes, CH passes per tile
+// (BLOCK*CH*64 contiguous bytes).  The cross-chunk dependencies of the reference loop:
 //   * odd-backslash carry  -- constant per chunk unless the chunk is all backslashes, so the
-//                             predecessor's trailing-run parity is taken from the neighbour
-//                             lane (wave shuffle) or read back from memory (wave-first lane);
-//   * in-string parity     -- XOR scan: ballot inside the wave, LDS across waves, and a
-//                             decoupled look-back chain over per-tile descriptors across
-//                             tiles (so the input is fetched from HBM exactly once);
-//   * output offset        -- + scan of per-chunk structural counts, same three levels.
-// The pseudo-structural predecessor bit needs only the class of the previous byte (see
-// DESIGN.md "pseudo_pred without the quote state").
+//                             predecessor's trailing-run parity comes from the neighbour lane
+//                             (DPP wave shift); the first lane of a wave derives it from the 8
+//                             bytes in front of the wave's 4 KiB unit (one scalar load);
+//   * pseudo_pred carry    -- needs only the class of the previous byte, same route;
+//   * in-string parity and output offset -- every chunk is finalized under BOTH hypotheses
+//     about the in-string state at the start of its wave unit (lane-local, cheap next to the
+//     bit-plane transposition), so a tile can publish (parity, count|outside, count|inside)
+//     before it knows its own incoming state.  One decoupled look-back over 64-bit tile
+//     descriptors then resolves parity and offset together; the look-back window is BLOCK
+//     descriptors wide (every wave of the block reads 64 of them), so even with ~1000 tiles
+//     in flight it finishes in one or two memory round trips.
+// The input is fetched from HBM exactly once.
 // Output: ABSOLUTE uint32 byte positions (the running sum of the reference's deltas).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sj_chunk.h"
@@ -25,10 +30,14 @@
 
 namespace sj {
 
-// ---- decoupled look-back over one 64-bit descriptor per tile ---------------------------
-// descriptor = status(2) << 62 | value(62); the value IS the payload (single 8-byte granule,
-// relaxed agent-scope accesses: MI355X guide, Guideline 16 form R2).
-static constexpr u64 ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, VAL_MASK = (1ull << 62) - 1;
+// ---- tile descriptors ------------------------------------------------------------------
+// One naturally aligned 8-byte granule per tile, status and payload together, relaxed
+// agent-scope accesses (MI355X guide, Guideline 16 form R2):
+//   AGG    = 1<<62 | P<<61 | T1<<28 | T0     P: parity of unescaped quotes in the tile,
+//                                            T0/T1: structural count if the tile starts
+//                                            outside / inside a string (28 bits each)
+//   PREFIX = 2<<62 | G<<61 | COUNT           state and count at the END of the tile (48 bits)
+static constexpr u64 ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62;
 
 __device__ __forceinline__ u64 desc_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -36,53 +45,39 @@ __device__ __forceinline__ u64 desc_load(const u64 *p) {
 __device__ __forceinline__ void desc_store(u64 *p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ u64 pack_agg(u32 P, u32 T0, u32 T1) {
+    return ST_AGG | ((u64)(P & 1u) << 61) | ((u64)T1 << 28) | (u64)T0;
+}
+__device__ __forceinline__ u64 pack_prefix(u32 G, u64 count) { return ST_PREFIX | ((u64)(G & 1u) << 61) | count; }
 
-template <bool XOR>
-__device__ __forceinline__ u64 wave_reduce(u64 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        u64 o = __shfl_xor(v, s, 64);
-        v = XOR ? (v ^ o) : (v + o);
-    }
+// ---- wave primitives (DPP: no LDS traffic) -----------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ u32 dpp_or0(u32 src) {  // lanes without a source (or masked rows) read 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {  // inclusive + scan over the 64 lanes
+    v += dpp_or0<0x111>(v);       // row_shr:1
+    v += dpp_or0<0x112>(v);       // row_shr:2
+    v += dpp_or0<0x114>(v);       // row_shr:4
+    v += dpp_or0<0x118>(v);       // row_shr:8
+    v += dpp_or0<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_or0<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
-
-// Called by all 64 lanes of one wave.  Returns the exclusive prefix of `agg` over tiles < t.
-template <bool XOR>
-__device__ __forceinline__ u64 lookback(u64 *desc, u32 t, u64 agg, int lane) {
-    if (t == 0) {
-        if (lane == 0) desc_store(&desc[0], ST_PREFIX | (agg & VAL_MASK));
-        return 0;
-    }
-    if (lane == 0) desc_store(&desc[t], ST_AGG | (agg & VAL_MASK));
-    u64 acc = 0;
-    long long j = (long long)t - 1;
-    for (;;) {
-        const long long idx = j - lane;
-        const u64 d = idx >= 0 ? desc_load(&desc[idx]) : ST_PREFIX;  // identity before tile 0
-        const u32 status = (u32)(d >> 62);
-        const u64 invalid = __ballot(status == 0);
-        const u64 prefixes = __ballot(status == 2);
-        const int fp = prefixes ? ctz64(prefixes) : 64;
-        const u64 need = fp >= 63 ? ~0ull : ((2ull << fp) - 1);
-        if (invalid & need) {
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        u64 v = (lane <= fp) ? (d & VAL_MASK) : 0;
-        v = wave_reduce<XOR>(v);
-        acc = XOR ? (acc ^ v) : (acc + v);
-        if (fp < 64) break;
-        j -= 64;
-    }
-    if (lane == 0) desc_store(&desc[t], ST_PREFIX | ((XOR ? (acc ^ agg) : (acc + agg)) & VAL_MASK));
-    return acc;
+// value of the lane below; lane 0 receives `first`
+__device__ __forceinline__ u32 wave_shift_up(u32 v, u32 first) {
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 lane63(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u32 lanes_below_popc(u64 mask) {  // popcount of mask bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
 }
 
-// ---- memory peeks for the first lane of a wave -----------------------------------------
-// Parity of the backslash run that ends right before byte `p` (p > 0), i.e. the reference's
-// prev_iter_ends_odd_backslash at a chunk boundary.
-__device__ __noinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u64 p) {
+// ---- carries into the first chunk of a wave unit -------------------------------------------
+// Parity of the backslash run that ends right before byte `p` (p > lead), i.e. the reference's
+// prev_iter_ends_odd_backslash at a chunk boundary (find_odd_backslash_sequences_amd64.s:34-58).
+__device__ __forceinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u64 p) {
     u32 n = 0;
     while (p > lead && base[p - 1] == '\\') {
         n++;
@@ -91,9 +86,37 @@ __device__ __noinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u64 
     return n & 1u;
 }
 
-// pseudo_pred carry-in from the previous byte only: whitespace, one of {}[]:, or
-// an unescaped quote.
-__device__ __noinline__ u32 peek_pseudo_pred(const u8 *base, u64 lead, u64 p) {
+static constexpr u64 BS8 = 0x5c5c5c5c5c5c5c5cull, SP8 = 0x2020202020202020ull;
+
+// The 8 message bytes in front of offset `off` (off % 64 == 0, off >= 4096), blanks beyond the end.
+__device__ __forceinline__ u64 load_prev8(const u8 *base, u64 off, u64 end) {
+    if (off - 8 >= end) return SP8;
+    u64 v = *reinterpret_cast<const u64 *>(base + off - 8);  // inside the line of a valid byte
+    if (off > end) {
+        const u64 keep = (1ull << (8 * (end - (off - 8)))) - 1;
+        v = (v & keep) | (SP8 & ~keep);
+    }
+    return v;
+}
+// carry_in of the chunk at `off` from the 8 bytes before it
+__device__ __forceinline__ u32 carry_from_prev8(u64 prev8, const u8 *base, u64 lead, u64 off) {
+    const u64 x = prev8 ^ BS8;
+    if (x == 0) return peek_backslash_parity(base, lead, off);  // >= 8 backslashes: walk (rare)
+    return ((u32)__builtin_clzll(x) >> 3) & 1u;
+}
+// pseudo_pred carry from the previous byte only: whitespace, one of {}[]:, or an
+// unescaped quote.
+__device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base, u64 lead, u64 off) {
+    const u32 b = (u32)(prev8 >> 56);
+    if (b == ' ' || b == '\t' || b == '\n' || b == '\r') return 1;
+    if (b == '{' || b == '}' || b == '[' || b == ']' || b == ':' || b == ',') return 1;
+    if (b != '"') return 0;
+    const u64 x = (prev8 ^ BS8) << 8;
+    if (x == 0) return peek_backslash_parity(base, lead, off - 1) ^ 1u;
+    return ((((u32)__builtin_clzll(x | 0xffu) >> 3) & 1u)) ^ 1u;
+}
+// slow path for lanes > 0 (only taken when a wave holds a chunk made of 64 backslashes)
+__device__ __forceinline__ u32 peek_pseudo_pred(const u8 *base, u64 lead, u64 p) {
     if (p <= lead) return 1;  // stage1_find_marks_amd64.go:56: starts as 1
     const u8 b = base[p - 1];
     if (b == ' ' || b == '\t' || b == '\n' || b == '\r') return 1;
@@ -106,293 +129,200 @@ __device__ __noinline__ u32 peek_pseudo_pred(const u8 *base, u64 lead, u64 p) {
 // `base` is 64-byte aligned; the message occupies [lead, lead+len) of it.  Bytes outside are
 // replaced by 0x20, exactly like the reference's space-masked tail
 // (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as well, which
-// leaves the initial pseudo_pred (=1) semantics untouched.
-__device__ __noinline__ void load_chunk_edge(const u8 *base, u64 off, u64 lead, u64 end, u32 *w) {
-    for (int j = 0; j < 16; j++) {
-        u32 v = 0;
-        for (int b = 0; b < 4; b++) {
-            const u64 g = off + 4u * j + b;
-            const u32 byte = (g >= lead && g < end) ? base[g] : 0x20u;
-            v |= byte << (8 * b);
-        }
-        w[j] = v;
-    }
+// leaves the initial pseudo_pred (=1) semantics untouched.  A 64-byte line that holds at least
+// one message byte is readable as a whole (same page).
+// issue: 4 x global_load_dwordx4 of the 64-byte line (clamped to the first line for chunks that lie
+// completely outside the message, so that the address is always mapped)
+__device__ __forceinline__ void chunk_issue(const u8 *base, u64 off, u64 lead, u64 end, uint4 (&v)[4]) {
+    const bool any = off < end && off + 64 > lead;
+    const uint4 *p = reinterpret_cast<const uint4 *>(base + (any ? off : 0));
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = p[k];
 }
-
-__device__ __forceinline__ void load_chunk(const u8 *base, u64 off, u64 lead, u64 end, u32 (&w)[16]) {
+// consume: unpack, and blank the bytes outside the message (wave-uniform branch, edge waves only)
+__device__ __forceinline__ void chunk_finish(const uint4 (&v)[4], u64 off, u64 lead, u64 end, u32 (&w)[16]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        w[4 * k + 0] = v[k].x;
+        w[4 * k + 1] = v[k].y;
+        w[4 * k + 2] = v[k].z;
+        w[4 * k + 3] = v[k].w;
+    }
     const bool interior = off >= lead && off + 64 <= end;
-    if (__ballot(!interior) == 0) {  // wave-uniform fast path: 4 x global_load_dwordx4
-        const uint4 *p = reinterpret_cast<const uint4 *>(base + off);
+    if (__ballot(!interior) != 0) {
+        // bytes [lo, hi) of the chunk belong to the message
+        const long long lo = (long long)lead - (long long)off, hi = (long long)end - (long long)off;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint4 v = p[k];
-            w[4 * k + 0] = v.x;
-            w[4 * k + 1] = v.y;
-            w[4 * k + 2] = v.z;
-            w[4 * k + 3] = v.w;
+        for (int j = 0; j < 16; j++) {
+            const long long l = lo - 4 * j, h = hi - 4 * j;  // valid bytes of dword j: [l, h)
+            const u32 ml = l <= 0 ? 0u : (l >= 4 ? ~0u : ((1u << (8 * (int)l)) - 1u));  // bytes below l
+            const u32 mh = h <= 0 ? 0u : (h >= 4 ? ~0u : ((1u << (8 * (int)h)) - 1u));  // bytes below h
+            const u32 keep = mh & ~ml;
+            w[j] = (w[j] & keep) | (0x20202020u & ~keep);
         }
-    } else {
-        u32 tmp[16];
-        load_chunk_edge(base, off, lead, end, tmp);
-#pragma unroll
-        for (int j = 0; j < 16; j++) w[j] = tmp[j];
     }
 }
 
+// ---- the wide look-back -----------------------------------------------------------------
+// Summary of 64 descriptors (distances 64*w+1 .. 64*w+64 behind the tile), one per wave.
+struct WinSummary {
+    u32 flags;    // bit0: an INVALID descriptor among the needed ones, bit1: window holds a PREFIX
+    u32 P;        // composed effect of the aggregates nearer than the first PREFIX:
+    u32 T[2];     //   state g -> (g ^ P, count + T[g])
+    u32 Gfar;     // the PREFIX, if any
+    u32 pad;
+    u64 Cfar;
+};
+
+// Exclusive look-back for tile t > 0 (its AGG descriptor is already published): returns the
+// in-string state G and the structural count BASE in front of the tile.  All BLOCK threads call.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
-                                                       u32 ndjson, u32 *__restrict__ out_pos, u64 pos_cap,
-                                                       Stage1State *__restrict__ st, u64 *__restrict__ desc_par,
-                                                       u64 *__restrict__ desc_cnt, u32 num_tiles) {
+__device__ __forceinline__ void lookback_wide(u64 *desc, u32 t, int tid, WinSummary (*sum)[BLOCK / 64], u32 &G_out,
+                                              u64 &BASE_out) {
     constexpr int WAVES = BLOCK / 64;
-    __shared__ u32 s_tile;
-    __shared__ u32 s_wave_par[WAVES];
-    __shared__ u32 s_wave_cnt[WAVES];
-    __shared__ u64 s_excl_par;
-    __shared__ u64 s_excl_cnt;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // dynamic tile id: tiles are started in id order, so every predecessor in the look-back
-    // chain is resident or finished (forward progress without any dispatch-order assumption).
-    if (tid == 0) s_tile = atomicAdd(&st->tile_counter, 1u);
-    __syncthreads();
-    const u32 t = s_tile;
-
-    const u64 end = lead + len;
-    const u64 off = ((u64)t * BLOCK + tid) * 64;  // byte offset of this lane's chunk in `base`
-
-    u32 w[16];
-    load_chunk(base, off, lead, end, w);
-    const Classes c = classify(w);
-
-    // ---- backslash carry ---------------------------------------------------------------
-    // parity of the run of backslashes at the END of this chunk: if the chunk is not all
-    // backslashes this is the carry into the next chunk whatever our own carry-in is
-    // (an all-backslash chunk passes its carry-in through: 64 is even).
-    const bool all_bs = c.bs == ~0ull;
-    const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
-    u32 carry_in = __shfl_up(trail_odd, 1, 64);
-    const bool wave_has_all_bs = __ballot(all_bs) != 0;
-    if (off == 0) carry_in = 0;
-    else if (lane == 0 || wave_has_all_bs) carry_in = peek_backslash_parity(base, lead, off);
-    u32 carry_out;
-    const u64 odd_ends = odd_backslash_ends(c.bs, carry_in, carry_out);
-    const u64 quote_bits = c.quote & ~odd_ends;
-
-    // ---- in-string parity: wave (ballot) -> tile (LDS) -> global (look-back) --------------
-    const u32 par = (u32)popc64(quote_bits) & 1u;
-    const u64 par_ballot = __ballot(par != 0);
-    const u64 lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const u32 par_in_wave = (u32)popc64(par_ballot & lanes_below) & 1u;
-    if (lane == 0) s_wave_par[wave] = (u32)popc64(par_ballot) & 1u;
-    u64 quote_mask = prefix_xor(quote_bits);
-    __syncthreads();
-    u32 par_before_wave = 0, tile_par = 0;
-#pragma unroll
-    for (int i = 0; i < WAVES; i++) {
-        const u32 p = s_wave_par[i];
-        tile_par ^= p;
-        if (i < wave) par_before_wave ^= p;
-    }
-    if (wave == 0) {
-        const u64 ex = lookback<true>(desc_par, t, tile_par, lane);
-        if (lane == 0) s_excl_par = ex;
-    }
-    __syncthreads();
-    const u32 g_par = (u32)s_excl_par & 1u;
-    if ((g_par ^ par_before_wave ^ par_in_wave) & 1u) quote_mask = ~quote_mask;
-
-    // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80)
-    const bool err = (c.ctrl & quote_mask) != 0;
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-
-    // ---- pseudo-structural predecessor -------------------------------------------------
-    const u32 pp_out = (u32)(((c.structs | quote_bits | c.ws) >> 63) & 1u);
-    u32 pp_in = __shfl_up(pp_out, 1, 64);
-    if (lane == 0) pp_in = peek_pseudo_pred(base, lead, off);
-
-    u64 s = finalize(c.structs, c.ws, quote_mask, quote_bits, pp_in);
-    if (ndjson) s |= c.nl & ~quote_mask;
-
-    // ---- output offsets ----------------------------------------------------------------
-    const u32 n = (u32)popc64(s);
-    u32 incl = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_wave_cnt[wave] = incl;
-    __syncthreads();
-    u32 cnt_before_wave = 0, tile_cnt = 0;
-#pragma unroll
-    for (int i = 0; i < WAVES; i++) {
-        const u32 v = s_wave_cnt[i];
-        tile_cnt += v;
-        if (i < wave) cnt_before_wave += v;
-    }
-    if (wave == 0) {
-        const u64 ex = lookback<false>(desc_cnt, t, tile_cnt, lane);
-        if (lane == 0) s_excl_cnt = ex;
-    }
-    __syncthreads();
-    u64 o = s_excl_cnt + cnt_before_wave + (incl - n);
-
-    // ---- flatten (flatten_bits_amd64.s:26-60, absolute positions instead of deltas) -------
-    const u32 pos0 = (u32)(off - lead);
-    while (s) {
-        const int b = ctz64(s);
-        if (o < pos_cap) out_pos[o] = pos0 + (u32)b;
-        o++;
-        s &= s - 1;
-    }
-
-    if (t == num_tiles - 1 && tid == BLOCK - 1) {
-        st->total = s_excl_cnt + tile_cnt;
-        st->ends_in_quote = (g_par ^ tile_par) & 1u;
-    }
-}
-
-// =============================================================================================
-// v2: one combined look-back per tile.  Every chunk is finalized under BOTH hypotheses about the
-// in-string state at the start of its wave-unit (the work is lane-local and cheap next to the
-// transposition), so a tile can publish (parity, count|outside, count|inside) before it knows its
-// own incoming parity, and a single look-back chain resolves parity and output offset together.
-// A tile is BLOCK lanes x CH chunks (CH passes of BLOCK*64 contiguous bytes).
-// =============================================================================================
-// descriptor:  AGG    = 1<<62 | P<<61 | T1<<28 | T0          (T0/T1: 28 bits each)
-//              PREFIX = 2<<62 | G_end<<61 | COUNT_end        (48 bits)
-__device__ __forceinline__ u64 pack_agg(u32 P, u32 T0, u32 T1) {
-    return ST_AGG | ((u64)(P & 1u) << 61) | ((u64)T1 << 28) | (u64)T0;
-}
-__device__ __forceinline__ u64 pack_prefix(u32 G, u64 count) { return ST_PREFIX | ((u64)(G & 1u) << 61) | count; }
-
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
-
-// all 64 lanes of one wave; returns (G, BASE) = in-string parity and structural count before tile t
-__device__ __forceinline__ void lookback2(u64 *desc, u32 t, u32 P, u32 T0, u32 T1, int lane, u32 &G_out, u64 &BASE_out) {
-    if (t == 0) {
-        if (lane == 0) desc_store(&desc[0], pack_prefix(P, T0));
-        G_out = 0;
-        BASE_out = 0;
-        return;
-    }
-    if (lane == 0) desc_store(&desc[t], pack_agg(P, T0, T1));
-    // F = effect of the already-composed tiles (nearer to t): state(g) -> (g ^ Fp, + Ft[g])
+    const int lane = tid & 63, wave = tid >> 6;
+    // F = effect of the already-composed (nearer) tiles: state g -> (g ^ Fp, + Ft[g])
     u32 Fp = 0;
-    u64 Ft0 = 0, Ft1 = 0;
+    u64 Ft[2] = {0, 0};
     long long j = (long long)t - 1;
     u32 G = 0;
     u64 BASE = 0;
+    int buf = 0;
     for (;;) {
-        const long long idx = j - lane;
+        const long long idx = j - tid;
         const u64 d = idx >= 0 ? desc_load(&desc[idx]) : pack_prefix(0, 0);  // virtual prefix before tile 0
         const u32 status = (u32)(d >> 62);
         const u64 invalid = __ballot(status == 0);
         const u64 prefixes = __ballot(status == 2);
         const int fp = prefixes ? ctz64(prefixes) : 64;
-        const u64 need = fp >= 63 ? ~0ull : ((2ull << fp) - 1);
-        if (invalid & need) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const bool isagg = lane < fp;  // lanes nearer than the first prefix hold aggregates
+        const u64 need = fp >= 64 ? ~0ull : ((1ull << fp) - 1);
+        const bool isagg = lane < fp;
         const u32 p_l = isagg ? (u32)((d >> 61) & 1u) : 0u;
-        const u32 t0_l = (u32)(d & 0x0fffffffu), t1_l = (u32)((d >> 28) & 0x0fffffffu);
         const u64 pb = __ballot(p_l != 0);
         // parity contributed by the aggregates between this lane and the far end of the window
         const u64 above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
         const u32 par_above = (u32)popc64(pb & above) & 1u;
-        const u32 PW = (u32)popc64(pb) & 1u;
-        if (fp < 64) {
-            const u64 dp = __shfl(d, fp, 64);
-            const u32 Gfar = (u32)((dp >> 61) & 1u);
-            const u64 Cfar = dp & 0x0000ffffffffffffull;
-            const u32 gb = Gfar ^ par_above;
-            const u32 sum = wave_sum_u32(isagg ? (gb ? t1_l : t0_l) : 0u);
-            const u32 gw = Gfar ^ PW;  // state right before the already-composed part
-            G = gw ^ Fp;
-            BASE = Cfar + sum + (gw ? Ft1 : Ft0);
-            break;
+        const u32 t0_l = isagg ? (u32)(d & 0x0fffffffu) : 0u, t1_l = isagg ? (u32)((d >> 28) & 0x0fffffffu) : 0u;
+        // window as a function of the state g at its far end
+        const u32 s0 = lane63(wave_incl_scan(par_above ? t1_l : t0_l));
+        const u32 s1 = lane63(wave_incl_scan(par_above ? t0_l : t1_l));
+        if (lane == 0) {
+            WinSummary &S = sum[buf][wave];
+            S.flags = ((invalid & need) ? 1u : 0u) | (fp < 64 ? 2u : 0u);
+            S.P = (u32)popc64(pb) & 1u;
+            S.T[0] = s0;
+            S.T[1] = s1;
         }
-        // 64 aggregates, no prefix: compose the window as a function of the unknown far state
-        const u32 TW0 = wave_sum_u32(par_above ? t1_l : t0_l);
-        const u32 TW1 = wave_sum_u32(par_above ? t0_l : t1_l);
-        const u64 n0 = TW0 + (PW ? Ft1 : Ft0);
-        const u64 n1 = TW1 + (PW ? Ft0 : Ft1);
-        Ft0 = n0;
-        Ft1 = n1;
-        Fp ^= PW;
-        j -= 64;
+        if (fp < 64 && lane == fp) {
+            WinSummary &S = sum[buf][wave];
+            S.Gfar = (u32)((d >> 61) & 1u);
+            S.Cfar = d & 0x0000ffffffffffffull;
+        }
+        __syncthreads();
+        // every thread composes the wave windows, nearest first (uniform control flow)
+        bool retry = false, done = false;
+        u32 np = Fp;
+        u64 nt0 = Ft[0], nt1 = Ft[1];
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            if (retry || done) continue;
+            const WinSummary &S = sum[buf][w];
+            const u32 fl = uniform(S.flags);
+            if (fl & 1u) {
+                retry = true;
+                continue;
+            }
+            const u32 wp = uniform(S.P), w0 = uniform(S.T[0]), w1 = uniform(S.T[1]);
+            if (fl & 2u) {
+                const u32 g = uniform(S.Gfar);
+                const u64 c = S.Cfar;
+                const u32 gw = g ^ wp;  // state right in front of the already-composed part
+                G = gw ^ np;
+                BASE = c + (g ? w1 : w0) + (gw ? nt1 : nt0);
+                done = true;
+                continue;
+            }
+            // apply this window first, then the nearer part
+            const u64 a0 = (u64)w0 + (wp ? nt1 : nt0);
+            const u64 a1 = (u64)w1 + (wp ? nt0 : nt1);
+            nt0 = a0;
+            nt1 = a1;
+            np ^= wp;
+        }
+        buf ^= 1;
+        if (done) break;
+        if (retry) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;  // F unchanged: nothing of this round is consumed
+        }
+        Fp = np;
+        Ft[0] = nt0;
+        Ft[1] = nt1;
+        j -= BLOCK;
     }
-    if (lane == 0) desc_store(&desc[t], pack_prefix(G ^ P, BASE + (G ? T1 : T0)));
     G_out = G;
     BASE_out = BASE;
 }
 
+// ---- phase A: everything that does not need the state in front of the tile ----------------
+// One pass = one 64-byte chunk per lane.  The two candidate structural masks of every chunk go to
+// the wave's private LDS window m[pass][outside|inside][lane]; registers only carry the chunk
+// itself, so the kernel runs at high occupancy.  While pass k is being computed the loads of pass
+// k+1 are in flight (issued as soon as the chunk registers are dead).
+// s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
+//             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH>
-__global__ __launch_bounds__(BLOCK) void stage1_kernel_v2(const u8 *__restrict__ base, u64 lead, u64 len, u32 ndjson,
-                                                          u32 *__restrict__ out_pos, u64 pos_cap,
-                                                          Stage1State *__restrict__ st, u64 *__restrict__ desc,
-                                                          u32 num_tiles) {
+__device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 ndjson, u32 t, u32 t_next,
+                                        bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit) {
     constexpr int WAVES = BLOCK / 64;
-    constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
-    __shared__ u32 s_tile;
-    __shared__ u32 s_par[UNITS];
-    __shared__ u32 s_cnt[2][UNITS];
-    __shared__ u32 s_G;
-    __shared__ u64 s_BASE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(&st->tile_counter, 1u);
-    __syncthreads();
-    const u32 t = s_tile;
-    const u64 end = lead + len;
     const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
-
-    u64 sA[CH], sB[CH];  // final structural masks if the wave-unit starts outside / inside a string
-    u32 ex[CH];          // exclusive in-wave offsets: exA | exB << 16
-    u32 eflags = 0;      // bit 2k: control char in string under A, bit 2k+1: under B
-
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < CH; k++) {
-        const u64 off = tile_off + ((u64)k * BLOCK + tid) * 64;
+        const u64 unit_off = tile_off + ((u64)k * BLOCK + (u64)wave * 64) * 64;  // wave-uniform
+        const u64 off = unit_off + (u64)lane * 64;
         u32 w[16];
-        load_chunk(base, off, lead, end, w);
+        chunk_finish(pf, off, lead, end, w);
+
+        // carries into lane 0 from the 8 bytes in front of the unit (scalar path)
+        u32 carry0 = 0, pp0 = 1;
+        u64 prev8 = SP8;
+        if (unit_off != 0) prev8 = load_prev8(base, unit_off, end);
+
         const Classes c = classify(w);
 
+        // the chunk registers are dead now: put the next pass in flight
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads below the last use of w
+        if (k + 1 < CH)
+            chunk_issue(base, off + (u64)BLOCK * 64, lead, end, pf);
+        else if (has_next)
+            chunk_issue(base, (u64)t_next * (BLOCK * CH) * 64 + ((u64)wave * 64 + lane) * 64, lead, end, pf);
+
+        if (unit_off != 0) {
+            carry0 = carry_from_prev8(prev8, base, lead, unit_off);
+            pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
+        }
+
+        // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
+        // If that chunk is not all backslashes this does not depend on ITS carry-in.
         const bool all_bs = c.bs == ~0ull;
         const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
-        u32 carry_in = __shfl_up(trail_odd, 1, 64);
-        const bool wave_has_all_bs = __ballot(all_bs) != 0;
-        if (off == 0) carry_in = 0;
-        else if (lane == 0 || wave_has_all_bs) carry_in = peek_backslash_parity(base, lead, off);
-        u64 odd_ends = 0;
-        if (__ballot(c.bs != 0 || carry_in != 0) != 0) {  // wave-uniform: most waves see no backslash at all
+        u32 carry_in = wave_shift_up(trail_odd, carry0);
+        u64 quote_bits = c.quote;
+        if (__ballot(c.bs != 0 || carry_in != 0) != 0) {  // wave-uniform: many waves see no backslash at all
+            if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, off);
             u32 carry_out;
-            odd_ends = odd_backslash_ends(c.bs, carry_in, carry_out);
+            quote_bits &= ~odd_backslash_ends(c.bs, carry_in, carry_out);
         }
-        const u64 quote_bits = c.quote & ~odd_ends;
 
+        // ---- in-string mask relative to the start of the wave unit
         const u32 par = (u32)popc64(quote_bits) & 1u;
         const u64 par_ballot = __ballot(par != 0);
-        const u64 lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const bool in_wave = (popc64(par_ballot & lanes_below) & 1) != 0;
-        u64 qm = prefix_xor(quote_bits);  // relative to the start of this wave-unit
-        if (in_wave) qm = ~qm;
+        u64 qm = prefix_xor(quote_bits);
+        if (lanes_below_popc(par_ballot) & 1u) qm = ~qm;
 
+        // ---- pseudo-structural predecessor
         const u32 pp_out = (u32)(((c.structs | quote_bits | c.ws) >> 63) & 1u);
-        u32 pp_in = __shfl_up(pp_out, 1, 64);
-        if (lane == 0) pp_in = peek_pseudo_pred(base, lead, off);
+        const u32 pp_in = wave_shift_up(pp_out, pp0);
 
         u64 a = finalize(c.structs, c.ws, qm, quote_bits, pp_in);
         u64 b = finalize(c.structs, c.ws, ~qm, quote_bits, pp_in);
@@ -400,122 +330,260 @@ __global__ __launch_bounds__(BLOCK) void stage1_kernel_v2(const u8 *__restrict__
             a |= c.nl & ~qm;
             b |= c.nl & qm;
         }
-        sA[k] = a;
-        sB[k] = b;
-        if (c.ctrl & qm) eflags |= 1u << (2 * k);
-        if (c.ctrl & ~qm) eflags |= 2u << (2 * k);
+        m[(k * 2 + 0) * 64 + lane] = a;
+        m[(k * 2 + 1) * 64 + lane] = b;
+        // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80), per hypothesis
+        const u32 bad = (__ballot((c.ctrl & qm) != 0) != 0 ? 1u : 0u) | (__ballot((c.ctrl & ~qm) != 0) != 0 ? 2u : 0u);
 
-        // in-wave inclusive scans of both counts at once (16-bit fields: a wave holds <= 4096 bits)
-        const u32 n2 = (u32)popc64(a) | ((u32)popc64(b) << 16);
-        u32 incl = n2;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        ex[k] = incl - n2;
-        if (lane == 63) {
-            const int u = k * WAVES + wave;
-            s_par[u] = (u32)popc64(par_ballot) & 1u;
-            s_cnt[0][u] = incl & 0xffffu;
-            s_cnt[1][u] = incl >> 16;
-        }
-    }
-    __syncthreads();
-
-    // per-unit parity prefix (relative to the tile start) and the tile aggregate for both incoming states
-    u32 pre_mask = 0;  // bit u = parity of units < u
-    u32 P = 0, T0 = 0, T1 = 0;
-#pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-        pre_mask |= P << u;
-        T0 += s_cnt[P][u];
-        T1 += s_cnt[P ^ 1u][u];
-        P ^= s_par[u];
-    }
-    if (wave == 0) {
-        u32 G;
-        u64 BASE;
-        lookback2(desc, t, P, T0, T1, lane, G, BASE);
-        if (lane == 0) {
-            s_G = G;
-            s_BASE = BASE;
-        }
-    }
-    __syncthreads();
-    const u32 G = s_G;
-    u64 unit_base = s_BASE;
-
-    // ---- flatten (flatten_bits_amd64.s:26-60, absolute positions instead of deltas) -------
-    bool err = false;
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-#pragma unroll
-        for (int wv = 0; wv < WAVES; wv++) {
-            const int u = k * WAVES + wv;
-            const u32 h = G ^ ((pre_mask >> u) & 1u);
-            if (wv == wave) {
-                u64 s = h ? sB[k] : sA[k];
-                u64 o = unit_base + (h ? (ex[k] >> 16) : (ex[k] & 0xffffu));
-                err |= ((eflags >> (2 * k + h)) & 1u) != 0;
-                const u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + tid) * 64 - lead);
-                while (s) {
-                    const int bit = ctz64(s);
-                    if (o < pos_cap) out_pos[o] = pos0 + (u32)bit;
-                    o++;
-                    s &= s - 1;
-                }
-            }
-            unit_base += s_cnt[h][u];
-        }
-    }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-    if (t == num_tiles - 1 && tid == 0) {
-        st->total = unit_base;
-        st->ends_in_quote = (G ^ P) & 1u;
+        // unit totals of both counts at once (16-bit fields: a wave holds <= 4096 bits)
+        const u32 tot = lane63(wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16)));
+        if (lane == 0)
+            s_unit[k * WAVES + wave] =
+                (((u32)popc64(par_ballot) & 1u) << 31) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
     }
 }
 
+// tile aggregate for both incoming states; pre_mask bit u = parity of the units in front of unit u
+template <int UNITS>
+__device__ __forceinline__ void tile_aggregate(const u32 *s_unit, u32 &P, u32 &T0, u32 &T1, u32 &pre_mask) {
+    pre_mask = 0;
+    P = 0;
+    T0 = 0;
+    T1 = 0;
+#pragma unroll
+    for (int u = 0; u < UNITS; u++) {
+        const u32 v = uniform(s_unit[u]);
+        pre_mask |= P << u;
+        const u32 c0 = v & 0x1fffu, c1 = (v >> 13) & 0x1fffu;
+        T0 += P ? c1 : c0;
+        T1 += P ? c0 : c1;
+        P ^= v >> 31;
+    }
+}
+
+// ---- flatten (flatten_bits_amd64.s:26-60, absolute positions instead of deltas) ------------
+// Each wave expands its own units: lanes scatter their positions into the wave's LDS window (which
+// held the masks: they are read into registers first), then the wave copies the window out with
+// coalesced 256-byte stores.  A unit with more than CAP positions takes several rounds.
+template <int BLOCK, int CH>
+__device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
+                                             u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
+                                             u64 &tile_end) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int UNITS = WAVES * CH;
+    constexpr u32 CAP = CH * 256;  // u32 slots in the wave's window (CH * 2 * 64 u64)
+    static_assert(UNITS <= 64, "one unit per lane in the prefix");
+    // per-unit counts under the now known state, prefix over the units (lane u <-> unit u)
+    const u32 v = lane < UNITS ? s_unit[lane] : 0u;
+    const u32 hl = G ^ ((pre_mask >> (lane & 31)) & 1u);
+    const u32 cl = lane < UNITS ? (hl ? ((v >> 13) & 0x1fffu) : (v & 0x1fffu)) : 0u;
+    const u32 incl = wave_incl_scan(cl);
+    tile_end = BASE + lane63(incl);
+    const bool fits = tile_end <= pos_cap;  // uniform: no per-store capacity check needed
+
+    const bool err = lane < UNITS && ((v >> (26 + hl)) & 1u) != 0;  // any lane: the caller ballots
+
+    u64 sel[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
+        sel[k] = m[(k * 2 + (int)h) * 64 + lane];
+    }
+    u32 *stage = reinterpret_cast<u32 *>(m);
+    const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int u = k * WAVES + wave;
+        const u32 C = (u32)__builtin_amdgcn_readlane((int)cl, u);
+        const u64 g = BASE + ((u32)__builtin_amdgcn_readlane((int)incl, u) - C);
+        const u64 s = sel[k];
+        const u32 n = (u32)popc64(s);
+        const u32 loc = wave_incl_scan(n) - n;  // offset of this lane's first position inside the unit
+        u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
+        __builtin_amdgcn_wave_barrier();  // the window is free: all masks are in registers / already copied out
+        if (C <= CAP) {
+            u32 *p = stage + loc;
+            u32 lo = (u32)s, hi = (u32)(s >> 32);
+            while (lo) {
+                *p++ = pos0 + (u32)__builtin_ctz(lo);
+                lo &= lo - 1;
+            }
+            pos0 += 32;
+            while (hi) {
+                *p++ = pos0 + (u32)__builtin_ctz(hi);
+                hi &= hi - 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (u32 i = lane; i < C; i += 64)
+                if (fits || g + i < pos_cap) out_pos[g + i] = stage[i];
+        } else {
+            u64 r = s;
+            u32 l = loc;
+            for (u32 r0 = 0; r0 < C; r0 += CAP) {
+                const u32 lim = r0 + CAP;
+                while (r != 0 && l < lim) {
+                    stage[l - r0] = pos0 + (u32)ctz64(r);
+                    r &= r - 1;
+                    l++;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const u32 cnt = C - r0 < CAP ? C - r0 : CAP;
+                for (u32 i = lane; i < cnt; i += 64)
+                    if (fits || g + r0 + i < pos_cap) out_pos[g + r0 + i] = stage[i];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    return err;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------
+// Persistent blocks draw tiles from a ticket counter: tiles are started in id order, so every
+// predecessor in the look-back chain is resident or finished (forward progress without any
+// dispatch-order assumption), and no block ever waits for the dispatcher.
+template <int BLOCK, int CH, int WPE>
+__global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
+                                                                        u32 ndjson, u32 *__restrict__ out_pos,
+                                                                        u64 pos_cap, Stage1State *__restrict__ st,
+                                                                        u64 *__restrict__ desc, u32 num_tiles,
+                                                                        u64 *trace, u32 dbg) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
+    static_assert(UNITS <= 32, "pre_mask is a u32");
+    __shared__ u32 s_ticket[3];
+    __shared__ u32 s_unit[2][UNITS];
+    __shared__ WinSummary s_sum[2][WAVES];
+    __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
+#define TR(t_, i_)                                                                          \
+    do {                                                                                    \
+        if (trace && lane == 0) trace[((u64)(t_)*16 + wave) * 16 + (i_)] = wall_clock64(); \
+    } while (0)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (int)uniform((u32)tid >> 6);
+    const u64 end = lead + len;
+
+    if (tid == 0) {
+        s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
+        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
+        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
+    }
+    __syncthreads();
+    u32 t_cur = uniform(s_ticket[0]);
+    u32 t_nxt = uniform(s_ticket[1]);
+    if (t_cur >= num_tiles) return;
+
+    // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
+    // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.
+    uint4 pf[4];
+    chunk_issue(base, (u64)t_cur * (BLOCK * CH) * 64 + (u64)tid * 64, lead, end, pf);
+    TR(t_cur, 0);
+    phase_a<BLOCK, CH>(base, lead, end, ndjson, t_cur, t_nxt, t_nxt < num_tiles, lane, wave, pf, s_mask[0][wave], s_unit[0]);
+    TR(t_cur, 1);
+    __syncthreads();
+    u32 P0, T00, T01, pm0;
+    tile_aggregate<UNITS>(s_unit[0], P0, T00, T01, pm0);
+    if (tid == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
+
+    int cb = 0;
+    bool err = false;
+    for (;;) {
+        const u32 t_nn = uniform(s_ticket[2]);  // the tile after t_nxt
+        const bool has_next = t_nxt < num_tiles;
+        u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
+        if (has_next) {
+            TR(t_nxt, 0);
+            phase_a<BLOCK, CH>(base, lead, end, ndjson, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[cb ^ 1][wave],
+                               s_unit[cb ^ 1]);
+            TR(t_nxt, 1);
+            __syncthreads();
+            tile_aggregate<UNITS>(s_unit[cb ^ 1], P1, T10, T11, pm1);
+            if (tid == 0) {
+                desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+                s_ticket[2] = atomicAdd(&st->tile_counter, 1u);  // returns during look-back + flatten
+            }
+        }
+        TR(t_cur, 2);
+        u32 G = 0;
+        u64 BASE = 0;
+        if (t_cur != 0 && !(dbg & 1u)) {
+            lookback_wide<BLOCK>(desc, t_cur, tid, s_sum, G, BASE);
+            if (tid == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
+        }
+        TR(t_cur, 3);
+        u64 tile_end = 0;
+        if (!(dbg & 2u))
+            err |= flatten_tile<BLOCK, CH>(s_mask[cb][wave], s_unit[cb], pm0, G, BASE, t_cur, lead, lane, wave, out_pos,
+                                           pos_cap, tile_end);
+        if (t_cur == num_tiles - 1 && tid == 0) {
+            st->total = tile_end;
+            st->ends_in_quote = (G ^ P0) & 1u;
+        }
+        TR(t_cur, 4);
+        if (!has_next) break;
+        __syncthreads();  // s_unit[cb] and the ticket slot are recycled by the next round
+        P0 = P1;
+        T00 = T10;
+        T01 = T11;
+        pm0 = pm1;
+        t_cur = t_nxt;
+        t_nxt = t_nn;
+        cb ^= 1;
+    }
+    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+#undef TR
+}
+
 // ---- launcher --------------------------------------------------------------------------
-// Variant selection (A/B on hardware): SJHIP_S1_VARIANT = 0 (v1: 512 lanes, two look-backs),
-// 1..4 = v2 with (BLOCK, CH) = (256,1) (256,2) (256,4) (512,2).  Default: S1_DEFAULT_VARIANT.
-static constexpr int S1_DEFAULT_VARIANT = 3;
+// Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
+// allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
+static constexpr int S1_DEFAULT_VARIANT = 0;
 
 struct S1Variant {
-    int block, ch;
+    int block, ch, wpe;
 };
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {512, 2, 6}, {256, 2, 5}, {256, 2, 6},
+                                        {1024, 2, 4}, {256, 4, 4}, {512, 4, 4}};
 static S1Variant s1_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("SJHIP_S1_VARIANT");
         v = e ? atoi(e) : S1_DEFAULT_VARIANT;
-        if (v < 0 || v > 4) v = S1_DEFAULT_VARIANT;
+        if (v < 0 || v >= (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0])) v = S1_DEFAULT_VARIANT;
     }
-    switch (v) {
-    case 0: return {512, 0};
-    case 1: return {256, 1};
-    case 2: return {256, 2};
-    case 3: return {256, 4};
-    default: return {512, 2};
-    }
+    return S1_VARIANTS[v];
+}
+
+// persistent grid: as many blocks as fit on the device at once (more would only queue)
+template <typename K>
+static u32 grid_for(K kernel, int block, u32 tiles) {
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    static const int over = getenv("SJHIP_S1_BLOCKS_PER_CU") ? atoi(getenv("SJHIP_S1_BLOCKS_PER_CU")) : 0;
+    if (over > 0) per_cu = over;
+    const u64 cap = (u64)cus * (u64)per_cu;
+    return (u32)(tiles < cap ? tiles : cap);
 }
 
 static inline u32 stage1_tiles(size_t len, size_t lead) {
     const S1Variant v = s1_variant();
-    const u64 tile_bytes = (u64)v.block * (v.ch ? v.ch : 1) * 64;
+    const u64 tile_bytes = (u64)v.block * v.ch * 64;
     const u64 span = (u64)lead + len;
     return (u32)((span + tile_bytes - 1) / tile_bytes);
 }
 
 size_t stage1_workspace_bytes(size_t len) {
-    const size_t tiles = (len + 128) / (256 * 64) + 2;  // smallest tile of any variant
-    return sizeof(Stage1State) + 2 * tiles * sizeof(u64);
+    const size_t tiles = (len + 128) / (256 * 2 * 64) + 2;  // smallest tile of any variant
+    return sizeof(Stage1State) + tiles * sizeof(u64);
 }
 
 // zero the Stage1State and the tile descriptors (must precede every launch)
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream) {
     const u32 tiles = stage1_tiles(len, lead);
-    return hipMemsetAsync(ws, 0, sizeof(Stage1State) + 2 * (size_t)tiles * sizeof(u64), stream);
+    return hipMemsetAsync(ws, 0, sizeof(Stage1State) + (size_t)tiles * sizeof(u64), stream);
 }
 
 // d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
@@ -526,22 +594,43 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     const u64 lead = a & 63;
     const u32 tiles = stage1_tiles(len, lead);
     Stage1State *st = reinterpret_cast<Stage1State *>(ws);
-    u64 *desc_par = reinterpret_cast<u64 *>(st + 1);
-    u64 *desc_cnt = desc_par + tiles;
+    u64 *desc = reinterpret_cast<u64 *>(st + 1);
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-#define S1_V2(B, C)                                                                                              \
-    hipLaunchKernelGGL((stage1_kernel_v2<B, C>), dim3(tiles), dim3(B), 0, stream, base, lead, (u64)len, nd, d_pos, \
-                       (u64)pos_cap, st, desc_par, tiles)
-    if (v.ch == 0)
-        hipLaunchKernelGGL(stage1_kernel<512>, dim3(tiles), dim3(512), 0, stream, base, lead, (u64)len, nd, d_pos,
-                           (u64)pos_cap, st, desc_par, desc_cnt, tiles);
-    else if (v.block == 256 && v.ch == 1) S1_V2(256, 1);
-    else if (v.block == 256 && v.ch == 2) S1_V2(256, 2);
-    else if (v.block == 256 && v.ch == 4) S1_V2(256, 4);
-    else S1_V2(512, 2);
-#undef S1_V2
+    static const u32 dbg = getenv("SJHIP_S1_DBG") ? (u32)atoi(getenv("SJHIP_S1_DBG")) : 0u;
+    static const char *trace_path = getenv("SJHIP_S1_TRACE");
+    static u64 *trace = nullptr;
+    static size_t trace_cap = 0;
+    if (trace_path && trace_cap < (size_t)tiles * 2048) {
+        if (trace) (void)hipFree(trace);
+        trace_cap = (size_t)tiles * 2048;
+        (void)hipMalloc(&trace, trace_cap);
+    }
+    if (trace_path) (void)hipMemsetAsync(trace, 0, (size_t)tiles * 2048, stream);
+#define S1_LAUNCH(B, C, W)                                                                                      \
+    hipLaunchKernelGGL((stage1_kernel<B, C, W>), dim3(grid_for(stage1_kernel<B, C, W>, B, tiles)), dim3(B), 0, stream, \
+                       base, lead, (u64)len, nd, d_pos,                                                          \
+                       (u64)pos_cap, st, desc, tiles, trace, dbg)
+    if (v.block == 512 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(512, 2, 6);
+    else if (v.block == 256 && v.ch == 2 && v.wpe == 5) S1_LAUNCH(256, 2, 5);
+    else if (v.block == 256 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(256, 2, 6);
+    else if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
+    else if (v.block == 256 && v.ch == 4) S1_LAUNCH(256, 4, 4);
+    else if (v.block == 512 && v.ch == 4) S1_LAUNCH(512, 4, 4);
+    else S1_LAUNCH(512, 2, 4);
+#undef S1_LAUNCH
+    if (trace_path) {
+        (void)hipStreamSynchronize(stream);
+        u64 *h = (u64 *)malloc((size_t)tiles * 2048);
+        (void)hipMemcpy(h, trace, (size_t)tiles * 2048, hipMemcpyDeviceToHost);
+        FILE *f = fopen(trace_path, "wb");
+        if (f) {
+            fwrite(h, 2048, tiles, f);
+            fclose(f);
+        }
+        free(h);
+    }
     return hipGetLastError();
 }
 
