@@ -138,6 +138,10 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
     if (!have_last) last_byte = len ? *hlast : 0;
     ctx->s1 = *hs;
+    if (hs->error & 0x80000000u) {  // a bounded spin loop of the kernel ran out: internal error, never a verdict
+        ctx_set_error(ctx, "stage-1 kernel aborted (internal synchronisation timeout)");
+        return SJHIP_ERR_HIP;
+    }
     *n = (size_t)hs->total;
     *ok = stage1_verdict(*hs, len, last_byte);
     return SJHIP_OK;

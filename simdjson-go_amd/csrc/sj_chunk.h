@@ -78,6 +78,27 @@ SJ_HD u64 plane_of(const u32 (&w)[16]) {
     return ((u64)hi << 32) | lo;
 }
 
+// ---- three-input boolean functions (v_bitop3_b32 on gfx950) --------------------------------
+// TT is the truth table of f(a, b, c): bit (a*4 + b*2 + c) of TT is f's value.  Write TT as the same
+// expression over the constants TA, TB, TC, e.g. "a & ~b | c" -> (TA & ~TB | TC) & 0xff.
+static constexpr u32 TA = 0xF0, TB = 0xCC, TC = 0xAA;
+template <u32 TT>
+SJ_HD u32 bitop3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT & 0xff);
+#else
+    u32 r = 0;
+    for (int i = 0; i < 8; i++)
+        if ((TT >> i) & 1u) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
+#endif
+}
+template <u32 TT>
+SJ_HD u64 bitop3(u64 a, u64 b, u64 c) {
+    return ((u64)bitop3<TT>((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32)) << 32) |
+           bitop3<TT>((u32)a, (u32)b, (u32)c);
+}
+
 struct Classes {
     u64 bs;      // '\\'
     u64 quote;   // '"'
@@ -87,43 +108,37 @@ struct Classes {
     u64 nl;      // '\n'                   (find_newline_delimiters_amd64.s:16-28)
 };
 
-// keeps the instruction scheduler from interleaving all eight planes (register pressure)
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SJ_SCHED_FENCE)
-#define SJ_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SJ_FENCE() ((void)0)
-#endif
-
+// Every class is a conjunction of plane literals; the network below shares the common factors and
+// spends one v_bitop3 per three inputs (21 per 32-bit half, +2 for the newline class).
 SJ_HD Classes classify(const u32 (&w)[16]) {
-    const u64 b0 = plane_of<0>(w), b1 = plane_of<1>(w);
-    SJ_FENCE();
-    const u64 b2 = plane_of<2>(w), b3 = plane_of<3>(w);
-    SJ_FENCE();
-    const u64 b4 = plane_of<4>(w), b5 = plane_of<5>(w);
-    SJ_FENCE();
-    const u64 b6 = plane_of<6>(w), b7 = plane_of<7>(w);
-    SJ_FENCE();
-    const u64 n0 = ~b0, n1 = ~b1, n2 = ~b2, n3 = ~b3, n4 = ~b4, n5 = ~b5, n6 = ~b6, n7 = ~b7;
+    const u64 b0 = plane_of<0>(w), b1 = plane_of<1>(w), b2 = plane_of<2>(w), b3 = plane_of<3>(w);
+    const u64 b4 = plane_of<4>(w), b5 = plane_of<5>(w), b6 = plane_of<6>(w), b7 = plane_of<7>(w);
     Classes c;
-    const u64 hi_001 = n7 & n6 & b5;  // 0x20..0x3f
-    const u64 hi_000 = n7 & n6 & n5;  // 0x00..0x1f
-    const u64 hi_01x = n7 & b6;       // 0x40..0x7f
-    c.ctrl = hi_000;
-    // 0x22 = 0010 0010
-    c.quote = hi_001 & n4 & n3 & n2 & b1 & n0;
-    // 0x5c = 0101 1100
-    c.bs = hi_01x & n5 & b4 & b3 & b2 & n1 & n0;
-    // 0x5b 0x5d 0x7b 0x7d = 01x1 1011 / 01x1 1101
-    const u64 brackets = hi_01x & b4 & b3 & b0 & (b2 ^ b1);
-    // 0x2c = 0010 1100, 0x3a = 0011 1010
-    const u64 comma = hi_001 & n4 & b3 & b2 & n1 & n0;
-    const u64 colon = hi_001 & b4 & b3 & n2 & b1 & n0;
-    c.structs = brackets | comma | colon;
-    // 0x20 ; 0x09 0x0a 0x0d = 0000 1001 / 1010 / 1101
-    const u64 space = hi_001 & n4 & n3 & n2 & n1 & n0;
-    const u64 ctl_ws = hi_000 & n4 & b3 & ((n1 & b0) | (n2 & b1 & n0));
-    c.ws = space | ctl_ws;
-    c.nl = hi_000 & n4 & b3 & n2 & b1 & n0;
+    const u64 h001 = bitop3<(~TA & ~TB & TC)>(b7, b6, b5);   // 0x20..0x3f
+    const u64 h000 = bitop3<(~TA & ~TB & ~TC)>(b7, b6, b5);  // 0x00..0x1f
+    const u64 t1 = bitop3<(~TA & TB & TC)>(b7, b6, b4);      // 01x1 xxxx
+    const u64 m110 = bitop3<(TA & TB & ~TC)>(b3, b2, b1);    // xxxx 110x
+    const u64 m1100 = m110 & ~b0;                            // xxxx 1100
+    c.ctrl = h000;
+    c.bs = bitop3<(TA & ~TB & TC)>(t1, b5, m1100);             // 0x5c = 0101 1100
+    const u64 comma = bitop3<(TA & ~TB & TC)>(h001, b4, m1100);  // 0x2c = 0010 1100
+    const u64 y = bitop3<(TA & TB & TC)>(t1, b3, b0);          // 01x1 1xx1
+    const u64 brackets = bitop3<(TA & (TB ^ TC))>(y, b2, b1);  // 0x5b 0x5d 0x7b 0x7d
+    const u64 c1 = bitop3<(TA & TB & TC)>(h001, b4, b3);       // 0011 1xxx
+    const u64 c2 = bitop3<(TA & ~TB & TC)>(c1, b2, b1);        // 0011 101x
+    const u64 s1 = brackets | comma;
+    c.structs = bitop3<(TA | (TB & ~TC))>(s1, c2, b0);         // ... | 0x3a
+    const u64 q1 = bitop3<(TA & ~TB & ~TC)>(h001, b4, b3);     // 0010 0xxx
+    const u64 q2 = bitop3<(TA & ~TB & TC)>(q1, b2, b1);        // 0010 001x
+    c.quote = q2 & ~b0;                                        // 0x22
+    const u64 sp1 = bitop3<(TA & ~TB & ~TC)>(q1, b2, b1);      // 0010 000x
+    const u64 w1 = bitop3<(TA & ~TB & TC)>(h000, b4, b3);      // 0000 1xxx
+    // low three bits 001 (\t), 010 (\n), 101 (\r): minterms 1, 2, 5 of (b2, b1, b0)
+    const u64 g = bitop3<((1u << 1) | (1u << 2) | (1u << 5))>(b2, b1, b0);
+    const u64 sp = sp1 & ~b0;                                  // 0x20
+    c.ws = bitop3<(TA | (TB & TC))>(sp, w1, g);
+    const u64 h = bitop3<(1u << 2)>(b2, b1, b0);               // xxxx x010
+    c.nl = w1 & h;                                             // 0x0a
     return c;
 }
 
@@ -158,12 +173,12 @@ SJ_HD u64 prefix_xor(u64 x) {
 
 // finalize_structurals_amd64.s:19-36 (+ ND newline OR, find_structural_bits_amd64.s:91-96)
 SJ_HD u64 finalize(u64 structs, u64 ws, u64 quote_mask, u64 quote_bits, u32 pseudo_pred_in) {
-    u64 s = (structs & ~quote_mask) | quote_bits;
-    const u64 pseudo_pred = s | ws;
+    const u64 s0 = bitop3<((TA & ~TB) | TC)>(structs, quote_mask, quote_bits);  // (structs & ~qm) | quote_bits
+    const u64 pseudo_pred = s0 | ws;
     const u64 shifted = (pseudo_pred << 1) | (u64)pseudo_pred_in;
-    s |= shifted & ~ws & ~quote_mask;
-    s &= ~(quote_bits & ~quote_mask);
-    return s;
+    const u64 t = bitop3<(TA & ~TB & ~TC)>(shifted, ws, quote_mask);
+    // (s0 | t) & ~(quote_bits & ~quote_mask): drop the closing quotes
+    return bitop3<(TA & (~TB | TC))>(s0 | t, quote_bits, quote_mask);
 }
 
 }  // namespace sj

@@ -464,24 +464,27 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
 
-    if (tid == 0) {
-        s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
-        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
-        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
-    }
+    // At launch every block of the grid queues up on the ticket counter: the first ticket is drawn alone
+    // (one atomic per block), the next two while phase A of the first tile is already running.
+    if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
     u32 t_cur = uniform(s_ticket[0]);
-    u32 t_nxt = uniform(s_ticket[1]);
     if (t_cur >= num_tiles) return;
 
     // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
     // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.
     uint4 pf[4];
     chunk_issue(base, (u64)t_cur * (BLOCK * CH) * 64 + (u64)tid * 64, lead, end, pf);
+    if (tid == 0) {
+        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
+        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
+    }
     TR(t_cur, 0);
-    phase_a<BLOCK, CH>(base, lead, end, ndjson, t_cur, t_nxt, t_nxt < num_tiles, lane, wave, pf, s_mask[0][wave], s_unit[0]);
+    phase_a<BLOCK, CH>(base, lead, end, ndjson, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0]);
     TR(t_cur, 1);
     __syncthreads();
+    u32 t_nxt = uniform(s_ticket[1]);
+    if (t_nxt < num_tiles) chunk_issue(base, (u64)t_nxt * (BLOCK * CH) * 64 + (u64)tid * 64, lead, end, pf);
     u32 P0, T00, T01, pm0;
     tile_aggregate<UNITS>(s_unit[0], P0, T00, T01, pm0);
     if (tid == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # simdjson-go_amd/
-LIB_PATH = os.path.join(PKG_DIR, "libsjhip.so")
+LIB_PATH = os.environ.get("SJHIP_LIB") or os.path.join(PKG_DIR, "libsjhip.so")  # SJHIP_LIB: A/B builds
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
