@@ -169,11 +169,18 @@ extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flag
     }
     const u32 tlen = words + 1;  // + final root
     if (d != 0) bad = 1;
-    // min tree
+    // compact bracket view + min tree over it
+    std::vector<u32> br_tok;
+    std::vector<i32> br_depth;
+    for (size_t i = 0; i < n; i++)
+        if (is_bracket(kind[i])) {
+            br_tok.push_back((u32)i);
+            br_depth.push_back(depth[i]);
+        }
     MinTree mt;
     std::vector<std::vector<i32>> levels;
-    mt.lev[0] = depth.data();
-    mt.size[0] = n;
+    mt.lev[0] = br_depth.data();
+    mt.size[0] = br_depth.size();
     mt.nlev = 1;
     while (mt.size[mt.nlev - 1] > 64) {
         const u64 ps = mt.size[mt.nlev - 1], ns = (ps + 63) / 64;
@@ -187,8 +194,8 @@ extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flag
         mt.size[mt.nlev] = ns;
         mt.nlev++;
     }
-    for (size_t i = 0; i < n; i++)
-        if (is_close(kind[i])) bracket_resolve(mt, kind.data(), depth.data(), (u32)i, match.data(), ctxb.data());
+    for (size_t c = 0; c < br_tok.size(); c++)
+        if (is_close(kind[br_tok[c]])) bracket_resolve_compact(mt, br_tok.data(), kind.data(), (u32)c, match.data(), ctxb.data());
     Tokens t{pos.data(), (u32)n, kind.data(), depth.data(), toff.data(), soff.data(), lastbr.data(), match.data(), ctxb.data()};
     u64 *tape = (u64 *)malloc(sizeof(u64) * (tlen + 2));
     u8 *strs = (u8 *)malloc(sbytes + 64);

@@ -25,7 +25,8 @@ struct S2State {
     uint32_t records;        // record-separating newline runs (ND)
     unsigned long long tape_len;
     unsigned long long strings_len;
-    uint32_t pad[8];
+    uint32_t n_br;           // number of bracket tokens (size of the compact bracket view)
+    uint32_t pad[7];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 

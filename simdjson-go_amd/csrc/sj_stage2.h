@@ -120,12 +120,69 @@ SJ_HD u32 hex4(const MsgView &m, u64 p) {
     return (d0 << 12) | (d1 << 8) | (d2 << 4) | d3;  // sign-extended -1 poisons the high bits
 }
 
+// ---- unaligned 8-byte access and the exact zero-byte detector used by the plain-byte fast path ------
+SJ_HD u64 load_u64(const u8 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const u64 *>(p);
+#else
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+#endif
+}
+SJ_HD void store_u64(u8 *p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<u64 *>(p) = v;
+#else
+    __builtin_memcpy(p, &v, 8);
+#endif
+}
+// the low n (< 8) bytes of v
+SJ_HD void store_bytes(u8 *p, u64 v, u32 n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (n & 4u) {
+        *reinterpret_cast<u32 *>(p) = (u32)v;
+        p += 4;
+        v >>= 32;
+    }
+    if (n & 2u) {
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)v;
+        p += 2;
+        v >>= 16;
+    }
+    if (n & 1u) *p = (u8)v;
+#else
+    for (u32 i = 0; i < n; i++) p[i] = (u8)(v >> (8 * i));
+#endif
+}
+// 0x80 in every byte of x that is zero, 0 elsewhere (exact, no borrow artefacts)
+SJ_HD u64 zero_bytes(u64 x) {
+    const u64 k = 0x7f7f7f7f7f7f7f7full;
+    return ~(((x & k) + k) | x | k);
+}
+
 // Walks the string whose opening quote is at `q`.  If dst != nullptr the unescaped bytes are
 // written there.  Returns false if the reference's _parse_string_validate_only fails.
 SJ_HD bool string_walk(const MsgView &m, u64 q, u8 *dst, u32 *src_len, u32 *dst_len) {
     u64 pos = q + 1;
     u32 out = 0;
     for (;;) {
+        // plain bytes, eight at a time (unaligned 8-byte loads and stores are fine on gfx950 global memory)
+        while (pos + 8 <= m.len) {
+            const u64 x = load_u64(m.p + pos);
+            const u64 z = zero_bytes(x ^ 0x2222222222222222ull) | zero_bytes(x ^ 0x5c5c5c5c5c5c5c5cull);
+            if (z == 0) {
+                if (dst) store_u64(dst + out, x);
+                pos += 8;
+                out += 8;
+                continue;
+            }
+            const u32 nplain = (u32)ctz64(z) >> 3;  // bytes in front of the first quote / backslash
+            if (dst) store_bytes(dst + out, x, nplain);
+            pos += nplain;
+            out += nplain;
+            break;
+        }
         if (pos >= m.len) return false;  // unterminated: unreachable once stage 1 has accepted the document
         const u8 c = m.p[pos];
         if (c == '"') {
@@ -287,6 +344,29 @@ SJ_HD void bracket_resolve(const MinTree &mt, const u8 *kind, const i32 *depth, 
     if (d - 1 > 0) {
         const i64 p = psv(mt, j, d - 1) + 1;  // the enclosing container's open bracket
         ctx = kind[p] == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
+    }
+    ctxb[i] = ctx;
+}
+
+// The same on the compact bracket view (br_tok[c] = token index of the c-th bracket, the tree is built over
+// br_depth[c] = depth after it): non-bracket tokens never change the depth, so the previous-smaller-value
+// queries give the same brackets, over an array that is ~10x shorter.
+SJ_HD void bracket_resolve_compact(const MinTree &mt, const u32 *br_tok, const u8 *kind, u32 c, u32 *match, u8 *ctxb) {
+    const u32 i = br_tok[c];
+    const i32 d = mt.lev[0][c] + 1;  // depth before the close
+    if (d <= 0) {                    // closes nothing: the grammar check rejects it (context is ROOT)
+        match[i] = 0;
+        ctxb[i] = CTX_ROOT;
+        return;
+    }
+    const i64 jc = psv(mt, (i64)c, d) + 1;  // the open bracket that raised the depth to d
+    const u32 j = br_tok[jc];
+    match[i] = j;
+    match[j] = i;
+    u8 ctx = CTX_ROOT;
+    if (d - 1 > 0) {
+        const i64 pc = psv(mt, jc, d - 1) + 1;  // the enclosing container's open bracket
+        ctx = kind[br_tok[pc]] == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
     }
     ctxb[i] = ctx;
 }

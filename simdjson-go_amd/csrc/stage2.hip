@@ -38,11 +38,13 @@ struct S2Dev {
     u8 *ctxb;      // [n]
     u32 *nlb;      // [n] token indexes of record-separating newlines
     u32 *bigq;     // [n] queue of number tokens that need the big-integer tie-break
+    u32 *br_tok;   // [n] compact bracket view: token index of the c-th bracket
+    i32 *br_depth; // [n]                       depth after it (level 0 of the min tree)
     // tile aggregates / exclusive prefixes
     i32 *agg_d;
-    u32 *agg_w, *agg_s, *agg_lb, *agg_nb;
+    u32 *agg_w, *agg_s, *agg_lb, *agg_nb, *agg_bc;
     u32 tiles;
-    // min tree levels 1.. (level 0 is depth[])
+    // min tree levels 1.. (level 0 is br_depth[])
     i32 *lev[MinTree::MAXLEV];
     u64 lev_size[MinTree::MAXLEV];
     int nlev;
@@ -54,14 +56,14 @@ struct S2Dev {
 
 struct Agg {
     i32 d;
-    u32 w, s, lb, nb;
+    u32 w, s, lb, nb, bc;
 };
 __device__ __forceinline__ Agg agg_combine(const Agg &a, const Agg &b) {
-    return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.lb > b.lb ? a.lb : b.lb, a.nb + b.nb};
+    return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.lb > b.lb ? a.lb : b.lb, a.nb + b.nb, a.bc + b.bc};
 }
 __device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
     return Agg{__shfl_up(a.d, delta, 64), __shfl_up(a.w, delta, 64), __shfl_up(a.s, delta, 64), __shfl_up(a.lb, delta, 64),
-               __shfl_up(a.nb, delta, 64)};
+               __shfl_up(a.nb, delta, 64), __shfl_up(a.bc, delta, 64)};
 }
 
 __device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
@@ -75,6 +77,7 @@ __device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
     a.s = (k == K_STRING && dl != DLEN_INVALID && (dl & DLEN_COPY)) ? (dl & ~DLEN_COPY) : 0u;
     a.lb = is_bracket(k) ? i + 1 : 0u;
     a.nb = (k == K_NL && !last && nk != K_NL) ? 1u : 0u;
+    a.bc = is_bracket(k) ? 1u : 0u;
     return a;
 }
 
@@ -121,7 +124,7 @@ __device__ __forceinline__ Agg block_reduce(Agg v, Agg *lds) {
 __global__ __launch_bounds__(S2_BLOCK) void k_scan_reduce(S2Dev p) {
     __shared__ Agg lds[S2_BLOCK / 64];
     const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
-    Agg v{0, 0, 0, 0, 0};
+    Agg v{0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++)
         if (base + k < p.n) v = agg_combine(v, token_agg(p, base + k));
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_scan_reduce(S2Dev p) {
         p.agg_s[blockIdx.x] = tot.s;
         p.agg_lb[blockIdx.x] = tot.lb;
         p.agg_nb[blockIdx.x] = tot.nb;
+        p.agg_bc[blockIdx.x] = tot.bc;
     }
 }
 
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
     __shared__ unsigned long long words64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
-        carry_s = Agg{0, 0, 0, 0, 0};
+        carry_s = Agg{0, 0, 0, 0, 0, 0};
         words64 = 0;
     }
     __syncthreads();
     for (u32 start = 0; start < p.tiles; start += 1024) {
         const u32 t = start + threadIdx.x;
         Agg incl{0, 0, 0, 0, 0};
-        if (t < p.tiles) incl = Agg{p.agg_d[t], p.agg_w[t], p.agg_s[t], p.agg_lb[t], p.agg_nb[t]};
+        if (t < p.tiles) incl = Agg{p.agg_d[t], p.agg_w[t], p.agg_s[t], p.agg_lb[t], p.agg_nb[t], p.agg_bc[t]};
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {  // inclusive scan inside the wave
             const Agg o = agg_shfl_up(incl, s);
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
             p.agg_s[t] = excl.s;
             p.agg_lb[t] = excl.lb;
             p.agg_nb[t] = excl.nb;
+            p.agg_bc[t] = excl.bc;
         }
         __syncthreads();
         if (threadIdx.x == 1023) {
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
         p.st->tape_len = words64 + 2ull;  // + opening root + closing root
         p.st->strings_len = tot.s;
         p.st->records = tot.nb;
+        p.st->n_br = tot.bc;
         if (words64 + 2ull > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
         if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
     }
@@ -192,10 +198,10 @@ __global__ __launch_bounds__(S2_BLOCK) void k_scan_apply(S2Dev p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
     Agg item[S2_ITEMS];
-    Agg v{0, 0, 0, 0, 0};
+    Agg v{0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
-        item[k] = (base + k < p.n) ? token_agg(p, base + k) : Agg{0, 0, 0, 0, 0};
+        item[k] = (base + k < p.n) ? token_agg(p, base + k) : Agg{0, 0, 0, 0, 0, 0};
         v = agg_combine(v, item[k]);
     }
     Agg incl = v;
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_scan_apply(S2Dev p) {
     }
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
-    Agg run{p.agg_d[blockIdx.x], p.agg_w[blockIdx.x], p.agg_s[blockIdx.x], p.agg_lb[blockIdx.x], p.agg_nb[blockIdx.x]};
+    Agg run{p.agg_d[blockIdx.x], p.agg_w[blockIdx.x], p.agg_s[blockIdx.x], p.agg_lb[blockIdx.x], p.agg_nb[blockIdx.x],
+            p.agg_bc[blockIdx.x]};
     for (int w = 0; w < wave; w++) run = agg_combine(run, lds[w]);
     {
         const Agg prev = agg_shfl_up(incl, 1);
@@ -224,49 +231,61 @@ __global__ __launch_bounds__(S2_BLOCK) void k_scan_apply(S2Dev p) {
             p.nlb[run.nb] = i;
             p.match[i] = run.nb;
         }
+        const u32 c = run.bc;  // brackets in front of this token
         run = agg_combine(run, a);
         p.depth[i] = run.d;
         p.last_br[i] = run.lb;
+        if (a.bc) {
+            p.br_tok[c] = i;
+            p.br_depth[c] = run.d;
+        }
     }
 }
 
-// ---- kernel 6: one level of the 64-ary min tree (one wave per group) -------------------------------------
-__global__ __launch_bounds__(256) void k_min_level(const i32 *src, u64 n_src, i32 *dst, u64 n_dst) {
+// ---- kernel 6: one level of the 64-ary min tree over br_depth[] (one wave per group) -----------------------
+// The number of brackets is only known on the device: the launcher sizes grids and level arrays for the
+// worst case (every token a bracket) and the kernels derive the real level sizes from S2State::n_br.
+__device__ __forceinline__ MinTree make_tree(const S2Dev &p) {
+    MinTree mt;
+    mt.lev[0] = p.br_depth;
+    u64 sz = p.st->n_br;
+    mt.size[0] = sz;
+    mt.nlev = 1;
+    while (sz > 64 && mt.nlev < MinTree::MAXLEV) {
+        sz = (sz + 63) / 64;
+        mt.lev[mt.nlev] = p.lev[mt.nlev];
+        mt.size[mt.nlev] = sz;
+        mt.nlev++;
+    }
+    return mt;
+}
+__global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
+    const MinTree mt = make_tree(p);
+    if (l >= mt.nlev) return;
     const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_dst) return;
+    if (g >= mt.size[l]) return;
     const int lane = threadIdx.x & 63;
     const u64 k = g * 64 + lane;
-    i32 v = k < n_src ? src[k] : 0x7fffffff;
+    i32 v = k < mt.size[l - 1] ? mt.lev[l - 1][k] : 0x7fffffff;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         const i32 o = __shfl_xor(v, s, 64);
         v = o < v ? o : v;
     }
-    if (lane == 0) dst[g] = v;
+    if (lane == 0) p.lev[l][g] = v;
 }
 
-__device__ __forceinline__ MinTree make_tree(const S2Dev &p) {
-    MinTree mt;
-    mt.lev[0] = p.depth;
-    mt.size[0] = p.n;
-    mt.nlev = p.nlev;
-    for (int l = 1; l < p.nlev; l++) {
-        mt.lev[l] = p.lev[l];
-        mt.size[l] = p.lev_size[l];
-    }
-    return mt;
-}
 __device__ __forceinline__ Tokens make_tokens(const S2Dev &p) {
     return Tokens{p.pos, p.n, p.kind, p.depth, p.tape_off, p.str_off, p.last_br, p.match, p.ctxb};
 }
 
 // ---- kernel 7: bracket partners and resume contexts -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
-    if (!is_close(p.kind[i])) return;
+    const u32 c = blockIdx.x * 256 + threadIdx.x;  // compact bracket index
+    if (c >= p.st->n_br) return;
+    if (!is_close(p.kind[p.br_tok[c]])) return;
     const MinTree mt = make_tree(p);
-    bracket_resolve(mt, p.kind, p.depth, i, p.match, p.ctxb);
+    bracket_resolve_compact(mt, p.br_tok, p.kind, c, p.match, p.ctxb);
 }
 
 // ---- kernel 8: grammar check + tape words of brackets, atoms, numbers and roots ----------------------------
@@ -339,9 +358,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = sizeof(S2State) + 256;
     b += align_up(n, 256) * 2;                      // kind, ctxb
-    b += align_up(n * 4, 256) * 9;                  // dlen depth tape_off str_off last_br match nlb bigq (+1 spare)
+    b += align_up(n * 4, 256) * 11;                 // dlen depth tape_off str_off last_br match nlb bigq br_tok br_depth (+1)
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
-    b += align_up(tiles * 4, 256) * 5;
+    b += align_up(tiles * 4, 256) * 6;
     size_t lv = n;
     for (int l = 1; l < MinTree::MAXLEV; l++) {
         lv = (lv + 63) / 64;
@@ -376,12 +395,15 @@ hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.match = reinterpret_cast<u32 *>(carve(n * 4));
     p.nlb = reinterpret_cast<u32 *>(carve(n * 4));
     p.bigq = reinterpret_cast<u32 *>(carve(n * 4));
+    p.br_tok = reinterpret_cast<u32 *>(carve(n * 4));
+    p.br_depth = reinterpret_cast<i32 *>(carve(n * 4));
     p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
     p.agg_d = reinterpret_cast<i32 *>(carve((size_t)p.tiles * 4));
     p.agg_w = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
     p.agg_s = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
     p.agg_lb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
     p.agg_nb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.agg_bc = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
     p.nlev = 1;
     p.lev[0] = nullptr;
     p.lev_size[0] = n;
@@ -409,11 +431,8 @@ hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t
     hipLaunchKernelGGL(k_scan_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(k_scan_apply, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
-    for (int l = 1; l < p.nlev; l++) {
-        const i32 *src = l == 1 ? p.depth : p.lev[l - 1];
-        const u64 ns = p.lev_size[l - 1], nd = p.lev_size[l];
-        hipLaunchKernelGGL(k_min_level, dim3((u32)((nd + 3) / 4)), dim3(256), 0, stream, src, ns, p.lev[l], nd);
-    }
+    for (int l = 1; l < p.nlev; l++)  // worst-case grids; the kernels use the real bracket count
+        hipLaunchKernelGGL(k_min_level, dim3((u32)((p.lev_size[l] + 3) / 4)), dim3(256), 0, stream, p, l);
     hipLaunchKernelGGL(k_brackets, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
