@@ -68,6 +68,22 @@ int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
                        size_t *strings_len);
 
+/* ---- one NDJSON shard of a larger document: the multi-GPU ParseND path -------------------------------
+ * ParseND's records are independent (simdjson_amd64.go:82, and ParseNDStream parses 10 MiB blocks on their own,
+ * :156-192), so a document cut at record boundaries is parsed shard by shard, one shard per GPU.  The merged
+ * ParsedJson is the concatenation of the shard tapes / Strings.B, provided every index a shard's tape stores is
+ * rebased by where the shard starts in the merged Tape / Strings.B / Message.  Those three offsets are the
+ * exclusive prefix sums of the preceding shards' sizes -- the only data the shards exchange (8+8 bytes per rank).
+ *   begin : stage 1 + stage 2 up to the scan; returns this shard's tape_len / strings_len (message already on
+ *           the device, trimmed, starting at a record boundary)
+ *   ...   : all-gather the sizes (RCCL), compute the bases
+ *   finish: emits tape and Strings.B with the rebased indices; then sjhip_fetch as usual. */
+int sjhip_parse_shard_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
+                            size_t *strings_len);
+int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base);
+/* bytes.TrimSpace exactly as parseMessage applies it (parse_json_amd64.go:55); for hosts that are not Go */
+void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len);
+
 /* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------
  * pos_out receives ABSOLUTE uint32 byte positions (running sum of the reference's deltas).
  * *ok = the reference's return value (error_mask == 0 && indexTotal > 0 && end-of-doc checks). */

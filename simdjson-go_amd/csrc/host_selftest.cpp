@@ -120,8 +120,23 @@ extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, si
     trim_space(msg, len, off, out_len);
 }
 
+static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t tape_base, uint64_t strings_base,
+                          uint64_t msg_base, uint64_t **tape_out, size_t *tape_len, uint8_t **strings_out,
+                          size_t *strings_len, size_t *msg_off, size_t *msg_len);
 extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t **tape_out, size_t *tape_len,
                                  uint8_t **strings_out, size_t *strings_len, size_t *msg_off, size_t *msg_len) {
+    return selftest_parse(msg0, len0, flags, 0, 0, 0, tape_out, tape_len, strings_out, strings_len, msg_off, msg_len);
+}
+// one NDJSON shard of a larger document: the tape is emitted with rebased indices (sj_stage2.h, Tokens::*_base)
+extern "C" int sj_selftest_parse_shard(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t tape_base,
+                                       uint64_t strings_base, uint64_t msg_base, uint64_t **tape_out, size_t *tape_len,
+                                       uint8_t **strings_out, size_t *strings_len, size_t *msg_off, size_t *msg_len) {
+    return selftest_parse(msg0, len0, flags, tape_base, strings_base, msg_base, tape_out, tape_len, strings_out,
+                          strings_len, msg_off, msg_len);
+}
+static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t tape_base, uint64_t strings_base,
+                          uint64_t msg_base, uint64_t **tape_out, size_t *tape_len, uint8_t **strings_out,
+                          size_t *strings_len, size_t *msg_off, size_t *msg_len) {
     const bool ndjson = flags & 1, copy = flags & 2;
     size_t off, len;
     trim_space(msg0, len0, &off, &len);
@@ -197,6 +212,9 @@ extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flag
     for (size_t c = 0; c < br_tok.size(); c++)
         if (is_close(kind[br_tok[c]])) bracket_resolve_compact(mt, br_tok.data(), kind.data(), (u32)c, match.data(), ctxb.data());
     Tokens t{pos.data(), (u32)n, kind.data(), depth.data(), toff.data(), soff.data(), lastbr.data(), match.data(), ctxb.data()};
+    t.tape_base = tape_base;
+    t.strings_base = strings_base;
+    t.msg_base = msg_base;
     u64 *tape = (u64 *)malloc(sizeof(u64) * (tlen + 2));
     u8 *strs = (u8 *)malloc(sbytes + 64);
     for (size_t i = 0; i < n; i++) {
@@ -213,7 +231,7 @@ extern "C" int sj_selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flag
             }
         }
     }
-    for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape);
+    for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape, tape_base);
     if (bad) {
         free(tape);
         free(strs);

@@ -18,9 +18,12 @@ using namespace sj;
         if (e_ != hipSuccess) return ctx_hip_fail(ctx, e_, what); \
     } while (0)
 
-static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte,
-                           int have_last, size_t *tape_len, size_t *strings_len) {
+// Phase 1 (parse_begin): stage 1, then stage 2 up to the device-wide scan; reads back the sizes.
+// Phase 2 (parse_finish): the rest of stage 2 with the rebasing offsets, then the verdict.
+static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte, int have_last,
+                       size_t *tape_len, size_t *strings_len) {
     ctx->tape_len = ctx->strings_len = 0;
+    ctx->pending = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // structural density is 0.02..0.22 per byte on real documents; start with len/3 and retry once
@@ -39,15 +42,40 @@ static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32
     if (!ok) return SJHIP_ERR_STAGE1;
     int rc = arena_reserve(ctx, ctx->d_s2, stage2_workspace_bytes(n));
     if (rc) return rc;
-    const size_t tape_cap = 2 * n + 2;
-    const size_t strings_cap = len + 64;
-    rc = arena_reserve(ctx, ctx->d_tape, tape_cap * sizeof(uint64_t));
+    rc = arena_reserve(ctx, ctx->d_tape, (2 * n + 2) * sizeof(uint64_t));
     if (rc) return rc;
-    rc = arena_reserve(ctx, ctx->d_strings, strings_cap);
+    rc = arena_reserve(ctx, ctx->d_strings, len + 64);
     if (rc) return rc;
-    HIPCHK(stage2_launch(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, (uint64_t *)ctx->d_tape.p,
-                         tape_cap, (uint8_t *)ctx->d_strings.p, strings_cap, ctx->stream),
-           "stage2 launch");
+    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, ctx->stream),
+           "stage2 launch (measure)");
+    ctx->pending = 1;
+    ctx->p_msg = d_msg;
+    ctx->p_len = len;
+    ctx->p_n = n;
+    ctx->p_flags = flags;
+    if (tape_len || strings_len) {  // only the sharded path needs the sizes before phase 2
+        S2State *hs = (S2State *)(ctx->h_scratch + 256);
+        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
+        if (tape_len) *tape_len = (size_t)hs->tape_len;
+        if (strings_len) *strings_len = (size_t)hs->strings_len;
+    }
+    return SJHIP_OK;
+}
+
+static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, size_t *tape_len,
+                        size_t *strings_len) {
+    if (!ctx->pending) {
+        ctx_set_error(ctx, "no parse in progress");
+        return SJHIP_ERR_ARG;
+    }
+    ctx->pending = 0;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t n = ctx->p_n, len = ctx->p_len;
+    HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, n, ctx->p_flags, ctx->d_s2.p,
+                              (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
+                              strings_base, msg_base, ctx->stream),
+           "stage2 launch (emit)");
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
     HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
@@ -61,6 +89,25 @@ static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32
     if (tape_len) *tape_len = ctx->tape_len;
     if (strings_len) *strings_len = ctx->strings_len;
     return SJHIP_OK;
+}
+
+static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte,
+                           int have_last, size_t *tape_len, size_t *strings_len) {
+    int rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
+    if (rc) return rc;
+    return parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
+}
+
+int sjhip_parse_shard_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
+                            size_t *strings_len) {
+    if (!ctx || !tape_len || !strings_len) return SJHIP_ERR_ARG;
+    *tape_len = *strings_len = 0;
+    return parse_begin(ctx, d_msg, len, flags, 0, 0, tape_len, strings_len);
+}
+
+int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    return parse_finish(ctx, tape_base, strings_base, msg_base, nullptr, nullptr);
 }
 
 int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
@@ -85,6 +132,13 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->d_msg.p, msg + off, mlen, hipMemcpyHostToDevice, ctx->stream), "H2D message");
     return parse_on_device(ctx, ctx->d_msg.p, mlen, flags, msg[off + mlen - 1], 1, tape_len, strings_len);
+}
+
+void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
+    size_t o = 0, l = 0;
+    if (len) trim_space(msg, len, &o, &l);
+    if (off) *off = o;
+    if (out_len) *out_len = l;
 }
 
 int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {

@@ -23,6 +23,11 @@ struct sjhip_ctx {
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;
+    // a parse between its two phases (sjhip_parse_shard_begin / _finish)
+    int pending = 0;
+    const void *p_msg = nullptr;
+    size_t p_len = 0, p_n = 0;
+    uint32_t p_flags = 0;
     char err[256];
 };
 

@@ -35,6 +35,12 @@ hipError_t stage2_launch(const void *d_msg, size_t len, const uint32_t *d_pos, s
                          uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
                          hipStream_t stream);
 
+hipError_t stage2_launch_measure(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
+                                 hipStream_t stream);
+hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
+                              uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
+                              uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, hipStream_t stream);
+
 size_t stage1_workspace_bytes(size_t len);
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,

@@ -316,6 +316,9 @@ struct Tokens {
     const u32 *last_br;   // 1 + index of the last bracket token <= i (0: none)
     const u32 *match;     // brackets: index of the partner
     const u8 *ctxb;       // close brackets: context after the close
+    // NDJSON shards: where this shard's tape / Strings.B / Message window start inside the merged
+    // ParsedJson (all zero for an unsharded parse).  Every index the tape stores is rebased by these.
+    u64 tape_base = 0, strings_base = 0, msg_base = 0;
 };
 
 // context of the gap in front of token i
@@ -432,14 +435,14 @@ SJ_HD bool emit_simple(const Tokens &t, const MsgView &m, u32 i, u64 *tape) {
     case K_OPEN_OBJ:
     case K_OPEN_ARR: {  // payload: tape index just after the matching close (annotate_previousloc, :336)
         const u32 c = t.match[i];
-        const u32 after = (c < t.n) ? t.tape_off[c] + 1 : 0;
+        const u64 after = (c < t.n) ? t.tape_base + t.tape_off[c] + 1 : 0;
         tape[o] = ((u64)(k == K_OPEN_OBJ ? '{' : '[') << 56) | after;
         return false;
     }
     case K_CLOSE_OBJ:
     case K_CLOSE_ARR: {  // payload: tape index of the matching open (:335)
         const u32 op = t.match[i];
-        tape[o] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (op < t.n ? t.tape_off[op] : 0);
+        tape[o] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (op < t.n ? t.tape_base + t.tape_off[op] : 0);
         return false;
     }
     case K_TRUE:
@@ -458,11 +461,11 @@ SJ_HD void emit_string(const Tokens &t, const MsgView &m, u32 i, bool need_copy,
     const u32 o = t.tape_off[i];
     const u64 q = t.pos[i];
     if (!need_copy) {
-        tape[o] = ((u64)'"' << 56) | (q + 1);
+        tape[o] = ((u64)'"' << 56) | (t.msg_base + q + 1);
     } else {
         u32 sl, dl;
         string_walk(m, q, strings + t.str_off[i], &sl, &dl);
-        tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + t.str_off[i]);
+        tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + t.strings_base + t.str_off[i]);
     }
     tape[o + 1] = dst_len;
 }
@@ -470,17 +473,18 @@ SJ_HD void emit_string(const Tokens &t, const MsgView &m, u32 i, bool need_copy,
 // root words: tape[0], tape[tape_len-1] and the close/open pair written by every record-separating
 // newline run (startContinue, :196-221; succeed, :428-442).  nlb[r] = token index of the r-th such
 // newline; R = number of them.
-SJ_HD void emit_root(const u32 *nlb, u32 R, const u32 *tape_off, u32 tape_len, u32 r_plus1, u64 *tape) {
+SJ_HD void emit_root(const u32 *nlb, u32 R, const u32 *tape_off, u32 tape_len, u32 r_plus1, u64 *tape, u64 tape_base = 0) {
     const u64 ROOT = (u64)'r' << 56;
+    const u64 B = tape_base;
     if (r_plus1 == 0) {  // first and last word
-        tape[0] = ROOT | (R == 0 ? tape_len : tape_off[nlb[0]] + 1);
-        tape[tape_len - 1] = ROOT | (R == 0 ? 0u : tape_off[nlb[R - 1]] + 1);
+        tape[0] = ROOT | (B + (R == 0 ? tape_len : tape_off[nlb[0]] + 1));
+        tape[tape_len - 1] = ROOT | (B + (R == 0 ? 0u : tape_off[nlb[R - 1]] + 1));
         return;
     }
     const u32 r = r_plus1 - 1;
     const u32 o = tape_off[nlb[r]];
-    tape[o] = ROOT | (r == 0 ? 0u : tape_off[nlb[r - 1]] + 1);                 // close root of record r
-    tape[o + 1] = ROOT | (r + 1 == R ? tape_len : tape_off[nlb[r + 1]] + 1);  // open root of record r+1
+    tape[o] = ROOT | (B + (r == 0 ? 0u : tape_off[nlb[r - 1]] + 1));                 // close root of record r
+    tape[o + 1] = ROOT | (B + (r + 1 == R ? tape_len : tape_off[nlb[r + 1]] + 1));  // open root of record r+1
 }
 
 }  // namespace sj

@@ -52,6 +52,7 @@ struct S2Dev {
     u64 *tape;
     u8 *strings;
     u64 tape_cap, strings_cap;
+    u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
 };
 
 struct Agg {
@@ -81,19 +82,14 @@ __device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
     return a;
 }
 
-// ---- kernel 1: token kinds ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_token_kind(S2Dev p) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
-    p.kind[i] = token_kind(p.msg[p.pos[i]], p.ndjson != 0);
-}
-
-// ---- kernel 2: string lengths (parseStringSimdValidateOnly) --------------------------------------------
+// ---- kernel 1: token kinds + string lengths (parseStringSimdValidateOnly) ---------------------------------
 __global__ __launch_bounds__(256) void k_string_measure(S2Dev p) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
+    const u8 kind = token_kind(p.msg[p.pos[i]], p.ndjson != 0);
+    p.kind[i] = kind;
     u32 out = 0;
-    if (p.kind[i] == K_STRING) {
+    if (kind == K_STRING) {
         const MsgView mv{p.msg, p.len};
         u32 sl, dl;
         if (!string_walk(mv, p.pos[i], nullptr, &sl, &dl)) {
@@ -262,30 +258,33 @@ __device__ __forceinline__ MinTree make_tree(const S2Dev &p) {
 __global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
     const MinTree mt = make_tree(p);
     if (l >= mt.nlev) return;
-    const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= mt.size[l]) return;
     const int lane = threadIdx.x & 63;
-    const u64 k = g * 64 + lane;
-    i32 v = k < mt.size[l - 1] ? mt.lev[l - 1][k] : 0x7fffffff;
+    for (u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); g < mt.size[l]; g += (u64)gridDim.x * 4) {
+        const u64 k = g * 64 + lane;
+        i32 v = k < mt.size[l - 1] ? mt.lev[l - 1][k] : 0x7fffffff;
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const i32 o = __shfl_xor(v, s, 64);
-        v = o < v ? o : v;
+        for (int s = 32; s >= 1; s >>= 1) {
+            const i32 o = __shfl_xor(v, s, 64);
+            v = o < v ? o : v;
+        }
+        if (lane == 0) p.lev[l][g] = v;
     }
-    if (lane == 0) p.lev[l][g] = v;
 }
 
 __device__ __forceinline__ Tokens make_tokens(const S2Dev &p) {
-    return Tokens{p.pos, p.n, p.kind, p.depth, p.tape_off, p.str_off, p.last_br, p.match, p.ctxb};
+    Tokens t{p.pos, p.n, p.kind, p.depth, p.tape_off, p.str_off, p.last_br, p.match, p.ctxb};
+    t.tape_base = p.tape_base;
+    t.strings_base = p.strings_base;
+    t.msg_base = p.msg_base;
+    return t;
 }
 
 // ---- kernel 7: bracket partners and resume contexts -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
-    const u32 c = blockIdx.x * 256 + threadIdx.x;  // compact bracket index
-    if (c >= p.st->n_br) return;
-    if (!is_close(p.kind[p.br_tok[c]])) return;
+    const u32 n_br = p.st->n_br;
     const MinTree mt = make_tree(p);
-    bracket_resolve_compact(mt, p.br_tok, p.kind, c, p.match, p.ctxb);
+    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256)  // compact bracket index
+        if (is_close(p.kind[p.br_tok[c]])) bracket_resolve_compact(mt, p.br_tok, p.kind, c, p.match, p.ctxb);
 }
 
 // ---- kernel 8: grammar check + tape words of brackets, atoms, numbers and roots ----------------------------
@@ -314,9 +313,9 @@ __global__ __launch_bounds__(256) void k_emit(S2Dev p) {
         }
     } else if (k == K_NL) {
         if (i + 1 < p.n && p.kind[i + 1] != K_NL)
-            emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, p.match[i] + 1, p.tape);
+            emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, p.match[i] + 1, p.tape, p.tape_base);
     }
-    if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape);
+    if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape, p.tape_base);
     if (bad) atomicOr(&p.st->err, 1u);
 }
 
@@ -369,8 +368,9 @@ size_t stage2_workspace_bytes(size_t n) {
     return b + 4096;
 }
 
-hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
-                         size_t tape_cap, u8 *d_strings, size_t strings_cap, hipStream_t stream) {
+// carve the device view out of the workspace (deterministic: both phases rebuild the same view)
+static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
+                         size_t tape_cap, u8 *d_strings, size_t strings_cap) {
     S2Dev p;
     char *w = reinterpret_cast<char *>(ws);
     auto carve = [&](size_t bytes) {
@@ -420,24 +420,55 @@ hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.strings = d_strings;
     p.tape_cap = tape_cap;
     p.strings_cap = strings_cap;
+    p.tape_base = p.strings_base = p.msg_base = 0;
+    return p;
+}
 
+// Phase 1: token kinds, string lengths and the device-wide scan.  Afterwards S2State holds tape_len /
+// strings_len of this message (what an NDJSON shard exchanges with the other shards) and every token
+// knows its depth and its tape / Strings.B offsets.
+hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws,
+                                 hipStream_t stream) {
+    const S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, nullptr, 0, nullptr, 0);
     hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.match, 0, n * 4, stream);
     if (e != hipSuccess) return e;
     const u32 gb = (u32)((n + 255) / 256);
-    hipLaunchKernelGGL(k_token_kind, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_string_measure, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_scan_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(k_scan_apply, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
-    for (int l = 1; l < p.nlev; l++)  // worst-case grids; the kernels use the real bracket count
-        hipLaunchKernelGGL(k_min_level, dim3((u32)((p.lev_size[l] + 3) / 4)), dim3(256), 0, stream, p, l);
-    hipLaunchKernelGGL(k_brackets, dim3(gb), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// Phase 2: bracket matching, grammar check, tape and Strings.B.  The three bases rebase every index the
+// tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message, the exclusive
+// prefix sums over the preceding shards for an NDJSON shard.
+hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
+                              size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base, u64 strings_base,
+                              u64 msg_base, hipStream_t stream) {
+    S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap);
+    p.tape_base = tape_base;
+    p.strings_base = strings_base;
+    p.msg_base = msg_base;
+    const u32 gb = (u32)((n + 255) / 256);
+    for (int l = 1; l < p.nlev; l++) {  // grid-stride: the kernels use the real bracket count
+        const u64 want = (p.lev_size[l] + 3) / 4;
+        hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
+    }
+    hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
     return hipGetLastError();
+}
+
+hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
+                         size_t tape_cap, u8 *d_strings, size_t strings_cap, hipStream_t stream) {
+    hipError_t e = stage2_launch_measure(d_msg, len, d_pos, n, flags, ws, stream);
+    if (e != hipSuccess) return e;
+    return stage2_launch_emit(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, 0, 0, 0, stream);
 }
 
 }  // namespace sj

@@ -24,6 +24,9 @@ SYMBOLS = {
     "sjhip_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
     "sjhip_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sjhip_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
+    "sjhip_parse_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
+    "sjhip_parse_shard_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "sjhip_trim_space": (None, [C.c_void_p, C.c_size_t, szp, szp]),
     "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
     "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,
                                       intp]),

@@ -227,3 +227,30 @@ def test_full_size_properties(ctx):
     vals = keys + 1                      # the value string follows its key in tape order
     hond = (lens[vals] == 4) & eq4(offs[vals], b"HOND")
     assert int(hond.sum()) == S2["parking_citations_hond"] * 1000
+
+
+# ---- sharded ParseND (the multi-GPU path, here with the shards parsed one after the other on one GPU) ----
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("copy_strings", [True, False])
+def test_sharded_parse_nd_equals_oracle(ctx, world, copy_strings):
+    from sjhip import ndshard
+    park = fixtures.load("parking-citations")
+    lines = park.split(b"\n")
+    docs = [b"\n".join(lines[:200]) + b"\n", b"  \n" + b"\n\n".join(lines[:9]) + b"\n\n \n",
+            b'{"a":"x\\ny","b":[1,2.5e3,{"c":null}]}\n[1,2]\n{"k":"\\u00e9\\ud83d\\ude00"}']
+    trim, begin, finish = ndshard.device_callbacks(ctx, copy_strings)
+    for doc in docs:
+        # pass 1: every "rank" measures its shard (what the all_gather distributes)
+        sizes = []
+        for a, b in ndshard.record_cuts(doc, world):
+            off, ln = trim(doc[a:b])
+            sizes.append((0, 0) if ln == 0 else begin(doc[a + off:a + off + ln]))
+        # pass 2: every rank parses its shard with the gathered sizes
+        tapes, strs = [], []
+        for r in range(world):
+            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes, copy_strings)
+            tapes.append(t)
+            strs.append(s)
+        ref = O.parse(doc, ndjson=True, copy_strings=copy_strings)
+        assert np.array_equal(np.concatenate(tapes), ref.tape)
+        assert np.array_equal(np.concatenate(strs), ref.strings)
