@@ -22,7 +22,6 @@
 // Output: ABSOLUTE uint32 byte positions (the running sum of the reference's deltas).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "sj_chunk.h"
@@ -126,40 +125,38 @@ __device__ __forceinline__ u32 peek_pseudo_pred(const u8 *base, u64 lead, u64 p)
 }
 
 // ---- chunk load ------------------------------------------------------------------------
-// `base` is 64-byte aligned; the message occupies [lead, lead+len) of it.  Bytes outside are
-// replaced by 0x20, exactly like the reference's space-masked tail
-// (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as well, which
-// leaves the initial pseudo_pred (=1) semantics untouched.  A 64-byte line that holds at least
-// one message byte is readable as a whole (same page).
-// issue: 4 x global_load_dwordx4 of the 64-byte line (clamped to the first line for chunks that lie
-// completely outside the message, so that the address is always mapped)
-__device__ __forceinline__ void chunk_issue(const u8 *base, u64 off, u64 lead, u64 end, uint4 (&v)[4]) {
-    const bool any = off < end && off + 64 > lead;
-    const uint4 *p = reinterpret_cast<const uint4 *>(base + (any ? off : 0));
+// `base` is 64-byte aligned; the message occupies [lead, lead+len) of it.  A wave unit is 64
+// consecutive chunks (4 KiB, one per lane).  Interior units (every byte belongs to the message) take
+// the fast path: one scalar base + lane * 64.  The first and the last unit of a message take the
+// edge path: bytes outside the message are replaced by 0x20, exactly like the reference's
+// space-masked tail (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as
+// well, which leaves the initial pseudo_pred (=1) semantics untouched.  A 64-byte line that holds
+// at least one message byte is readable as a whole (same page); other lines are not touched.
+__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, u64 unit_off, bool interior, int lane, u64 lead,
+                                           u64 end, uint4 (&v)[4]) {
+    if (interior) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + unit_off) + lane * 4;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = p[k];
-}
-// consume: unpack, and blank the bytes outside the message (wave-uniform branch, edge waves only)
-__device__ __forceinline__ void chunk_finish(const uint4 (&v)[4], u64 off, u64 lead, u64 end, u32 (&w)[16]) {
+        for (int q = 0; q < 4; q++) v[q] = p[q];
+    } else {
+        const u64 off = unit_off + (u64)lane * 64;
+        const bool any = off < end && off + 64 > lead;
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + (any ? off : 0));
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        w[4 * k + 0] = v[k].x;
-        w[4 * k + 1] = v[k].y;
-        w[4 * k + 2] = v[k].z;
-        w[4 * k + 3] = v[k].w;
+        for (int q = 0; q < 4; q++) v[q] = p[q];
     }
-    const bool interior = off >= lead && off + 64 <= end;
-    if (__ballot(!interior) != 0) {
-        // bytes [lo, hi) of the chunk belong to the message
-        const long long lo = (long long)lead - (long long)off, hi = (long long)end - (long long)off;
+}
+// edge units only: blank the bytes of this lane's chunk that lie outside the message
+__device__ __forceinline__ void edge_blank(u32 (&w)[16], u64 off, u64 lead, u64 end) {
+    // bytes [lo, hi) of the chunk belong to the message
+    const long long lo = (long long)lead - (long long)off, hi = (long long)end - (long long)off;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const long long l = lo - 4 * j, h = hi - 4 * j;  // valid bytes of dword j: [l, h)
-            const u32 ml = l <= 0 ? 0u : (l >= 4 ? ~0u : ((1u << (8 * (int)l)) - 1u));  // bytes below l
-            const u32 mh = h <= 0 ? 0u : (h >= 4 ? ~0u : ((1u << (8 * (int)h)) - 1u));  // bytes below h
-            const u32 keep = mh & ~ml;
-            w[j] = (w[j] & keep) | (0x20202020u & ~keep);
-        }
+    for (int j = 0; j < 16; j++) {
+        const long long l = lo - 4 * j, h = hi - 4 * j;  // valid bytes of dword j: [l, h)
+        const u32 ml = l <= 0 ? 0u : (l >= 4 ? ~0u : ((1u << (8 * (int)l)) - 1u));  // bytes below l
+        const u32 mh = h <= 0 ? 0u : (h >= 4 ? ~0u : ((1u << (8 * (int)h)) - 1u));  // bytes below h
+        const u32 keep = mh & ~ml;
+        w[j] = (w[j] & keep) | (0x20202020u & ~keep);
     }
 }
 
@@ -271,70 +268,90 @@ __device__ __forceinline__ void lookback_wide(u64 *desc, u32 t, int tid, WinSumm
 // k+1 are in flight (issued as soon as the chunk registers are dead).
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
-template <int BLOCK, int CH>
-__device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 ndjson, u32 t, u32 t_next,
-                                        bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit) {
+template <int BLOCK, int CH, bool NDJSON>
+__device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 t, u32 t_next, bool has_next,
+                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit) {
     constexpr int WAVES = BLOCK / 64;
-    const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
-#pragma unroll 1
+    constexpr int UNITS = WAVES * CH;
+    // interior unit: all 4096 bytes belong to the message (wave-uniform -> scalar unit)
+    auto is_interior = [&](u64 unit) { return (unit != 0 || lead == 0) && (unit + 1) * 4096 <= end; };
+#pragma unroll
     for (int k = 0; k < CH; k++) {
-        const u64 unit_off = tile_off + ((u64)k * BLOCK + (u64)wave * 64) * 64;  // wave-uniform
-        const u64 off = unit_off + (u64)lane * 64;
+        const u64 unit = (u64)t * UNITS + (u64)(k * WAVES + wave);  // wave-uniform
+        const u64 unit_off = unit * 4096;
+        const bool interior = is_interior(unit);
         u32 w[16];
-        chunk_finish(pf, off, lead, end, w);
-
-        // carries into lane 0 from the 8 bytes in front of the unit (scalar path)
-        u32 carry0 = 0, pp0 = 1;
-        u64 prev8 = SP8;
-        if (unit_off != 0) prev8 = load_prev8(base, unit_off, end);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[4 * q + 0] = pf[q].x;
+            w[4 * q + 1] = pf[q].y;
+            w[4 * q + 2] = pf[q].z;
+            w[4 * q + 3] = pf[q].w;
+        }
+        u32 carry0 = 0, pp0 = 1;  // carries into lane 0 from the bytes in front of the unit
+        if (interior) {
+            if (unit != 0) {
+                const u64 prev8 = *reinterpret_cast<const u64 *>(base + unit_off - 8);  // scalar load
+                carry0 = carry_from_prev8(prev8, base, lead, unit_off);
+                pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
+            }
+        } else {
+            edge_blank(w, unit_off + (u64)lane * 64, lead, end);
+            if (unit != 0) {
+                const u64 prev8 = load_prev8(base, unit_off, end);
+                carry0 = carry_from_prev8(prev8, base, lead, unit_off);
+                pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
+            }
+        }
 
         const Classes c = classify(w);
 
-        // the chunk registers are dead now: put the next pass in flight
+        // the chunk registers are dead now: put the next pass in flight; it has the rest of this pass to arrive
         __builtin_amdgcn_sched_barrier(0);  // keep the loads below the last use of w
-        if (k + 1 < CH)
-            chunk_issue(base, off + (u64)BLOCK * 64, lead, end, pf);
-        else if (has_next)
-            chunk_issue(base, (u64)t_next * (BLOCK * CH) * 64 + ((u64)wave * 64 + lane) * 64, lead, end, pf);
-
-        if (unit_off != 0) {
-            carry0 = carry_from_prev8(prev8, base, lead, unit_off);
-            pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
+        if (k + 1 < CH) {
+            const u64 un = unit + WAVES;
+            unit_issue(base, un * 4096, is_interior(un), lane, lead, end, pf);
+        } else if (has_next) {
+            const u64 un = (u64)t_next * UNITS + (u64)wave;
+            unit_issue(base, un * 4096, is_interior(un), lane, lead, end, pf);
         }
 
         // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
-        const bool all_bs = c.bs == ~0ull;
-        const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
-        u32 carry_in = wave_shift_up(trail_odd, carry0);
         u64 quote_bits = c.quote;
-        if (__ballot(c.bs != 0 || carry_in != 0) != 0) {  // wave-uniform: many waves see no backslash at all
-            if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, off);
+        const u32 bs_any = (u32)c.bs | (u32)(c.bs >> 32);
+        if (__ballot(bs_any != 0) != 0 || carry0 != 0) {  // wave-uniform: many waves see no backslash at all
+            const bool all_bs = c.bs == ~0ull;
+            const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
+            u32 carry_in = wave_shift_up(trail_odd, carry0);
+            if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64);
             u32 carry_out;
             quote_bits &= ~odd_backslash_ends(c.bs, carry_in, carry_out);
         }
 
         // ---- in-string mask relative to the start of the wave unit
-        const u32 par = (u32)popc64(quote_bits) & 1u;
+        const u32 par =
+            ((u32)__builtin_popcount((u32)quote_bits) + (u32)__builtin_popcount((u32)(quote_bits >> 32))) & 1u;
         const u64 par_ballot = __ballot(par != 0);
         u64 qm = prefix_xor(quote_bits);
         if (lanes_below_popc(par_ballot) & 1u) qm = ~qm;
 
         // ---- pseudo-structural predecessor
-        const u32 pp_out = (u32)(((c.structs | quote_bits | c.ws) >> 63) & 1u);
+        const u32 pp_out = ((u32)(c.structs >> 32) | (u32)(quote_bits >> 32) | (u32)(c.ws >> 32)) >> 31;
         const u32 pp_in = wave_shift_up(pp_out, pp0);
 
         u64 a = finalize(c.structs, c.ws, qm, quote_bits, pp_in);
         u64 b = finalize(c.structs, c.ws, ~qm, quote_bits, pp_in);
-        if (ndjson) {
-            a |= c.nl & ~qm;
-            b |= c.nl & qm;
+        if (NDJSON) {
+            a = bitop3<(TA | (TB & ~TC))>(a, c.nl, qm);
+            b = bitop3<(TA | (TB & TC))>(b, c.nl, qm);
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
         // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80), per hypothesis
-        const u32 bad = (__ballot((c.ctrl & qm) != 0) != 0 ? 1u : 0u) | (__ballot((c.ctrl & ~qm) != 0) != 0 ? 2u : 0u);
-
+        const u64 in_a = c.ctrl & qm, in_b = c.ctrl & ~qm;
+        const u32 bad = (__ballot(((u32)in_a | (u32)(in_a >> 32)) != 0) != 0 ? 1u : 0u) |
+                        (__ballot(((u32)in_b | (u32)(in_b >> 32)) != 0) != 0 ? 2u : 0u);
         // unit totals of both counts at once (16-bit fields: a wave holds <= 4096 bits)
         const u32 tot = lane63(wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16)));
         if (lane == 0)
@@ -397,25 +414,24 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
         const u32 C = (u32)__builtin_amdgcn_readlane((int)cl, u);
         const u64 g = BASE + ((u32)__builtin_amdgcn_readlane((int)incl, u) - C);
         const u64 s = sel[k];
-        const u32 n = (u32)popc64(s);
+        const u32 lo0 = (u32)s, hi0 = (u32)(s >> 32);
+        const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
         const u32 loc = wave_incl_scan(n) - n;  // offset of this lane's first position inside the unit
         u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
         __builtin_amdgcn_wave_barrier();  // the window is free: all masks are in registers / already copied out
         if (C <= CAP) {
             u32 *p = stage + loc;
-            u32 lo = (u32)s, hi = (u32)(s >> 32);
-            while (lo) {
-                *p++ = pos0 + (u32)__builtin_ctz(lo);
-                lo &= lo - 1;
-            }
+            for (u32 lo = lo0; lo != 0; lo &= lo - 1) *p++ = pos0 + (u32)__builtin_ctz(lo);
             pos0 += 32;
-            while (hi) {
-                *p++ = pos0 + (u32)__builtin_ctz(hi);
-                hi &= hi - 1;
-            }
+            for (u32 hi = hi0; hi != 0; hi &= hi - 1) *p++ = pos0 + (u32)__builtin_ctz(hi);
             __builtin_amdgcn_wave_barrier();
-            for (u32 i = lane; i < C; i += 64)
-                if (fits || g + i < pos_cap) out_pos[g + i] = stage[i];
+            u32 *dst = out_pos + g;
+            if (fits) {
+                for (u32 i = lane; i < C; i += 64) dst[i] = stage[i];
+            } else {
+                for (u32 i = lane; i < C; i += 64)
+                    if (g + i < pos_cap) dst[i] = stage[i];
+            }
         } else {
             u64 r = s;
             u32 l = loc;
@@ -441,12 +457,11 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
 // Persistent blocks draw tiles from a ticket counter: tiles are started in id order, so every
 // predecessor in the look-back chain is resident or finished (forward progress without any
 // dispatch-order assumption), and no block ever waits for the dispatcher.
-template <int BLOCK, int CH, int WPE>
+template <int BLOCK, int CH, int WPE, bool NDJSON>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
-                                                                        u32 ndjson, u32 *__restrict__ out_pos,
+                                                                        u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
-                                                                        u64 *__restrict__ desc, u32 num_tiles,
-                                                                        u64 *trace, u32 dbg) {
+                                                                        u64 *__restrict__ desc, u32 num_tiles) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
@@ -454,10 +469,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_unit[2][UNITS];
     __shared__ WinSummary s_sum[2][WAVES];
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
-#define TR(t_, i_)                                                                          \
-    do {                                                                                    \
-        if (trace && lane == 0) trace[((u64)(t_)*16 + wave) * 16 + (i_)] = wall_clock64(); \
-    } while (0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -474,17 +485,21 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
     // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.
     uint4 pf[4];
-    chunk_issue(base, (u64)t_cur * (BLOCK * CH) * 64 + (u64)tid * 64, lead, end, pf);
+    {
+        const u64 un = (u64)t_cur * UNITS + (u64)wave;
+        unit_issue(base, un * 4096, (un != 0 || lead == 0) && (un + 1) * 4096 <= end, lane, lead, end, pf);
+    }
     if (tid == 0) {
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
-    TR(t_cur, 0);
-    phase_a<BLOCK, CH>(base, lead, end, ndjson, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0]);
-    TR(t_cur, 1);
+    phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0]);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
-    if (t_nxt < num_tiles) chunk_issue(base, (u64)t_nxt * (BLOCK * CH) * 64 + (u64)tid * 64, lead, end, pf);
+    if (t_nxt < num_tiles) {
+        const u64 un = (u64)t_nxt * UNITS + (u64)wave;
+        unit_issue(base, un * 4096, (un != 0 || lead == 0) && (un + 1) * 4096 <= end, lane, lead, end, pf);
+    }
     u32 P0, T00, T01, pm0;
     tile_aggregate<UNITS>(s_unit[0], P0, T00, T01, pm0);
     if (tid == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
@@ -496,10 +511,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const bool has_next = t_nxt < num_tiles;
         u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
         if (has_next) {
-            TR(t_nxt, 0);
-            phase_a<BLOCK, CH>(base, lead, end, ndjson, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[cb ^ 1][wave],
+            phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[cb ^ 1][wave],
                                s_unit[cb ^ 1]);
-            TR(t_nxt, 1);
             __syncthreads();
             tile_aggregate<UNITS>(s_unit[cb ^ 1], P1, T10, T11, pm1);
             if (tid == 0) {
@@ -507,23 +520,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                 s_ticket[2] = atomicAdd(&st->tile_counter, 1u);  // returns during look-back + flatten
             }
         }
-        TR(t_cur, 2);
         u32 G = 0;
         u64 BASE = 0;
-        if (t_cur != 0 && !(dbg & 1u)) {
+        if (t_cur != 0) {
             lookback_wide<BLOCK>(desc, t_cur, tid, s_sum, G, BASE);
             if (tid == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
         }
-        TR(t_cur, 3);
         u64 tile_end = 0;
-        if (!(dbg & 2u))
-            err |= flatten_tile<BLOCK, CH>(s_mask[cb][wave], s_unit[cb], pm0, G, BASE, t_cur, lead, lane, wave, out_pos,
+        err |= flatten_tile<BLOCK, CH>(s_mask[cb][wave], s_unit[cb], pm0, G, BASE, t_cur, lead, lane, wave, out_pos,
                                            pos_cap, tile_end);
         if (t_cur == num_tiles - 1 && tid == 0) {
             st->total = tile_end;
             st->ends_in_quote = (G ^ P0) & 1u;
         }
-        TR(t_cur, 4);
         if (!has_next) break;
         __syncthreads();  // s_unit[cb] and the ticket slot are recycled by the next round
         P0 = P1;
@@ -535,13 +544,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         cb ^= 1;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-#undef TR
 }
 
 // ---- launcher --------------------------------------------------------------------------
 // Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
 // allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
-static constexpr int S1_DEFAULT_VARIANT = 0;
+static constexpr int S1_DEFAULT_VARIANT = 6;
 
 struct S1Variant {
     int block, ch, wpe;
@@ -601,20 +609,16 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    static const u32 dbg = getenv("SJHIP_S1_DBG") ? (u32)atoi(getenv("SJHIP_S1_DBG")) : 0u;
-    static const char *trace_path = getenv("SJHIP_S1_TRACE");
-    static u64 *trace = nullptr;
-    static size_t trace_cap = 0;
-    if (trace_path && trace_cap < (size_t)tiles * 2048) {
-        if (trace) (void)hipFree(trace);
-        trace_cap = (size_t)tiles * 2048;
-        (void)hipMalloc(&trace, trace_cap);
-    }
-    if (trace_path) (void)hipMemsetAsync(trace, 0, (size_t)tiles * 2048, stream);
-#define S1_LAUNCH(B, C, W)                                                                                      \
-    hipLaunchKernelGGL((stage1_kernel<B, C, W>), dim3(grid_for(stage1_kernel<B, C, W>, B, tiles)), dim3(B), 0, stream, \
-                       base, lead, (u64)len, nd, d_pos,                                                          \
-                       (u64)pos_cap, st, desc, tiles, trace, dbg)
+#define S1_LAUNCH2(B, C, W, ND)                                                                                   \
+    hipLaunchKernelGGL((stage1_kernel<B, C, W, ND>), dim3(grid_for(stage1_kernel<B, C, W, ND>, B, tiles)), dim3(B), 0, \
+                       stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles)
+#define S1_LAUNCH(B, C, W)            \
+    do {                              \
+        if (nd)                       \
+            S1_LAUNCH2(B, C, W, true);  \
+        else                          \
+            S1_LAUNCH2(B, C, W, false); \
+    } while (0)
     if (v.block == 512 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(512, 2, 6);
     else if (v.block == 256 && v.ch == 2 && v.wpe == 5) S1_LAUNCH(256, 2, 5);
     else if (v.block == 256 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(256, 2, 6);
@@ -622,18 +626,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     else if (v.block == 256 && v.ch == 4) S1_LAUNCH(256, 4, 4);
     else if (v.block == 512 && v.ch == 4) S1_LAUNCH(512, 4, 4);
     else S1_LAUNCH(512, 2, 4);
+#undef S1_LAUNCH2
 #undef S1_LAUNCH
-    if (trace_path) {
-        (void)hipStreamSynchronize(stream);
-        u64 *h = (u64 *)malloc((size_t)tiles * 2048);
-        (void)hipMemcpy(h, trace, (size_t)tiles * 2048, hipMemcpyDeviceToHost);
-        FILE *f = fopen(trace_path, "wb");
-        if (f) {
-            fwrite(h, 2048, tiles, f);
-            fclose(f);
-        }
-        free(h);
-    }
     return hipGetLastError();
 }
 

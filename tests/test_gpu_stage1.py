@@ -144,8 +144,8 @@ def test_small_and_edge_inputs(ctx):
 
 
 def test_backslash_runs_across_boundaries(ctx):
-    # runs of backslashes straddling chunk (64), wave (4096) and tile (32768) boundaries
-    for boundary in (64, 4096, 32768):
+    # runs of backslashes straddling chunk (64), wave-unit (4096), pass (32768) and tile (65536, 131072) boundaries
+    for boundary in (64, 4096, 32768, 65536, 131072):
         for k in list(range(0, 9)) + [63, 64, 65, 127, 128, 129, 200]:
             for shift in (-3, -1, 0, 1):
                 pre = boundary - 2 - k // 2 + shift
@@ -175,6 +175,19 @@ def test_random_structural_soup(ctx):
             else:
                 # the reference stops handing over index buffers at the first failure; the prefix must agree
                 assert np.array_equal(pos[: len(pos_ref)], pos_ref) or len(pos_ref) == 0
+
+
+def test_quotes_and_escapes_across_tile_boundaries(ctx):
+    # strings that open in one tile and close in a later one; escaped quotes right at the boundaries
+    for tile in (32768, 65536, 131072):
+        for delta in (-2, -1, 0, 1, 2):
+            n = tile + delta
+            for body in (b"x" * n, b"x" * (n - 2) + b'\\"' + b"y" * 70000, b"x" * (n - 1) + b"\\\\" + b"z" * 5):
+                data = b'{"k":"' + body + b'","n":[1,2,{"a":null}]}'
+                for nd in (False, True):
+                    ok_ref, pos_ref = O.stage1(data, nd)
+                    ok, pos = ctx.stage1(data, nd)
+                    assert ok == ok_ref and np.array_equal(pos, pos_ref), (tile, delta, len(body), nd)
 
 
 def test_multi_tile_twitter_replicated(ctx):
