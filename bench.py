@@ -50,6 +50,17 @@ def cpu_baseline(copies=426, passes=5):
                       f"{dt:.1f} s, 1 thread"}
 
 
+def pmc_traffic(copies):
+    """HBM bytes per stage-1 launch from the committed rocprofv3 PMC passes ((2*FETCH_SIZE + WRITE_SIZE) KiB,
+    MI355X_MICROARCH.md HBM section); only valid for the workload it was measured on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "stage1_pmc.json")) as f:
+            d = json.load(f)
+        return int(d["hbm_bytes_per_launch"]) if copies == 426 else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,10 +232,13 @@ def main():
                                    f"one document replica per GPU", "bytes_per_gpu": n_bytes,
                        "structurals": s_expect, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "stage1_kernel<512>", "kernel_ms": round(k_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.copies),
+                         "kernel": "sj::stage1_kernel", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": algo_bytes,
-                         "input_GBps": round(n_bytes / (k_ms * 1e-3) / 1e9, 1)},
+                         "input_GBps": round(n_bytes / (k_ms * 1e-3) / 1e9, 1),
+                         "note": "achieved = (N + 4*S) bytes / hipEvent kernel time; traffic = HBM bytes per launch "
+                                 "from the committed rocprofv3 PMC passes (profiles/stage1_pmc.json); the kernel is "
+                                 "bound by instruction issue, not by HBM (DESIGN.md section 4.1)"},
         }
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
