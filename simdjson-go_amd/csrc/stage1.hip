@@ -160,105 +160,80 @@ __device__ __forceinline__ void edge_blank(u32 (&w)[16], u64 off, u64 lead, u64 
     }
 }
 
-// ---- the wide look-back -----------------------------------------------------------------
-// Summary of 64 descriptors (distances 64*w+1 .. 64*w+64 behind the tile), one per wave.
-struct WinSummary {
-    u32 flags;    // bit0: an INVALID descriptor among the needed ones, bit1: window holds a PREFIX
-    u32 P;        // composed effect of the aggregates nearer than the first PREFIX:
-    u32 T[2];     //   state g -> (g ^ P, count + T[g])
-    u32 Gfar;     // the PREFIX, if any
-    u32 pad;
-    u64 Cfar;
+// ---- the look-back (wave 0 of a block) -------------------------------------------------------
+// Resumable look-back: one call = one window of 256 descriptors (4 per lane, nearest first).
+struct LookBack {
+    long long j;  // nearest descriptor not yet consumed
+    u32 Fp;       // effect of the already-composed (nearer) tiles: state g -> (g ^ Fp, + Ft[g])
+    u64 Ft0, Ft1;
 };
 
-// Exclusive look-back for tile t > 0 (its AGG descriptor is already published): returns the
-// in-string state G and the structural count BASE in front of the tile.  All BLOCK threads call.
-template <int BLOCK>
-__device__ __forceinline__ void lookback_wide(u64 *desc, u32 t, int tid, WinSummary (*sum)[BLOCK / 64], u32 &G_out,
-                                              u64 &BASE_out) {
-    constexpr int WAVES = BLOCK / 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    // F = effect of the already-composed (nearer) tiles: state g -> (g ^ Fp, + Ft[g])
-    u32 Fp = 0;
-    u64 Ft[2] = {0, 0};
-    long long j = (long long)t - 1;
-    u32 G = 0;
-    u64 BASE = 0;
-    int buf = 0;
-    for (;;) {
-        const long long idx = j - tid;
-        const u64 d = idx >= 0 ? desc_load(&desc[idx]) : pack_prefix(0, 0);  // virtual prefix before tile 0
-        const u32 status = (u32)(d >> 62);
-        const u64 invalid = __ballot(status == 0);
-        const u64 prefixes = __ballot(status == 2);
-        const int fp = prefixes ? ctz64(prefixes) : 64;
-        const u64 need = fp >= 64 ? ~0ull : ((1ull << fp) - 1);
-        const bool isagg = lane < fp;
-        const u32 p_l = isagg ? (u32)((d >> 61) & 1u) : 0u;
-        const u64 pb = __ballot(p_l != 0);
-        // parity contributed by the aggregates between this lane and the far end of the window
-        const u64 above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
-        const u32 par_above = (u32)popc64(pb & above) & 1u;
-        const u32 t0_l = isagg ? (u32)(d & 0x0fffffffu) : 0u, t1_l = isagg ? (u32)((d >> 28) & 0x0fffffffu) : 0u;
-        // window as a function of the state g at its far end
-        const u32 s0 = lane63(wave_incl_scan(par_above ? t1_l : t0_l));
-        const u32 s1 = lane63(wave_incl_scan(par_above ? t0_l : t1_l));
-        if (lane == 0) {
-            WinSummary &S = sum[buf][wave];
-            S.flags = ((invalid & need) ? 1u : 0u) | (fp < 64 ? 2u : 0u);
-            S.P = (u32)popc64(pb) & 1u;
-            S.T[0] = s0;
-            S.T[1] = s1;
-        }
-        if (fp < 64 && lane == fp) {
-            WinSummary &S = sum[buf][wave];
-            S.Gfar = (u32)((d >> 61) & 1u);
-            S.Cfar = d & 0x0000ffffffffffffull;
-        }
-        __syncthreads();
-        // every thread composes the wave windows, nearest first (uniform control flow)
-        bool retry = false, done = false;
-        u32 np = Fp;
-        u64 nt0 = Ft[0], nt1 = Ft[1];
+__device__ __forceinline__ void lookback_load(const u64 *desc, long long j, int lane, u64 (&d)[4]) {
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            if (retry || done) continue;
-            const WinSummary &S = sum[buf][w];
-            const u32 fl = uniform(S.flags);
-            if (fl & 1u) {
-                retry = true;
-                continue;
-            }
-            const u32 wp = uniform(S.P), w0 = uniform(S.T[0]), w1 = uniform(S.T[1]);
-            if (fl & 2u) {
-                const u32 g = uniform(S.Gfar);
-                const u64 c = S.Cfar;
-                const u32 gw = g ^ wp;  // state right in front of the already-composed part
-                G = gw ^ np;
-                BASE = c + (g ? w1 : w0) + (gw ? nt1 : nt0);
-                done = true;
-                continue;
-            }
-            // apply this window first, then the nearer part
-            const u64 a0 = (u64)w0 + (wp ? nt1 : nt0);
-            const u64 a1 = (u64)w1 + (wp ? nt0 : nt1);
-            nt0 = a0;
-            nt1 = a1;
-            np ^= wp;
-        }
-        buf ^= 1;
-        if (done) break;
-        if (retry) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;  // F unchanged: nothing of this round is consumed
-        }
-        Fp = np;
-        Ft[0] = nt0;
-        Ft[1] = nt1;
-        j -= BLOCK;
+    for (int q = 0; q < 4; q++) {
+        const long long idx = j - 4 * lane - q;
+        d[q] = idx >= 0 ? desc_load(&desc[idx]) : pack_prefix(0, 0);  // virtual prefix before tile 0
     }
-    G_out = G;
-    BASE_out = BASE;
+}
+// Evaluates the window d loaded at lb.j.  0: needed descriptors still invalid (reload the same window),
+// 1: resolved (G, BASE valid), 2: 256 aggregates folded into lb, look further back (load at the new lb.j)
+__device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, int lane, u32 &G, u64 &BASE) {
+    // this lane's four descriptors, nearest first, as one function of the state at their far end
+    u32 lp = 0, lt0 = 0, lt1 = 0, lG = 0;
+    u64 lC = 0;
+    bool linv = false, lpre = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const u32 status = (u32)(d[q] >> 62);
+        if (!linv && !lpre) {
+            if (status == 0) {
+                linv = true;
+            } else if (status == 2) {
+                lpre = true;
+                lG = (u32)((d[q] >> 61) & 1u);
+                lC = d[q] & 0x0000ffffffffffffull;
+            } else {
+                const u32 P = (u32)((d[q] >> 61) & 1u);
+                const u32 T0 = (u32)(d[q] & 0x0fffffffu), T1 = (u32)((d[q] >> 28) & 0x0fffffffu);
+                const u32 a0 = T0 + (P ? lt1 : lt0), a1 = T1 + (P ? lt0 : lt1);  // this one first, then the nearer part
+                lt0 = a0;
+                lt1 = a1;
+                lp ^= P;
+            }
+        }
+    }
+    const u64 inv_b = __ballot(linv), pre_b = __ballot(lpre);
+    const int fp = pre_b ? ctz64(pre_b) : 64;  // first lane that holds a PREFIX
+    const u64 below_fp = fp >= 64 ? ~0ull : ((1ull << fp) - 1);
+    if (inv_b & below_fp) return 0;  // (the prefix lane itself met its prefix before any invalid one)
+    if (lane > fp) {
+        lp = 0;
+        lt0 = 0;
+        lt1 = 0;
+    }
+    const u64 pb = __ballot(lp != 0);
+    const u64 above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+    const u32 par_above = (u32)popc64(pb & above) & 1u;  // parity between this lane and the far end
+    const u32 s0 = lane63(wave_incl_scan(par_above ? lt1 : lt0));
+    const u32 s1 = lane63(wave_incl_scan(par_above ? lt0 : lt1));
+    const u32 WP = (u32)popc64(pb) & 1u;
+    if (fp < 64) {
+        const u32 g = (u32)__builtin_amdgcn_readlane((int)lG, fp);
+        const u64 c = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lC >> 32), fp) << 32) |
+                      (u32)__builtin_amdgcn_readlane((int)(u32)lC, fp);
+        const u32 gw = g ^ WP;  // state right in front of the already-composed part
+        G = gw ^ lb.Fp;
+        BASE = c + (g ? s1 : s0) + (gw ? lb.Ft1 : lb.Ft0);
+        return 1;
+    }
+    // 256 aggregates and no prefix: fold the window into F and look further back
+    const u64 a0 = (u64)s0 + (WP ? lb.Ft1 : lb.Ft0);
+    const u64 a1 = (u64)s1 + (WP ? lb.Ft0 : lb.Ft1);
+    lb.Ft0 = a0;
+    lb.Ft1 = a1;
+    lb.Fp ^= WP;
+    lb.j -= 256;
+    return 2;
 }
 
 // ---- phase A: everything that does not need the state in front of the tile ----------------
@@ -360,22 +335,18 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
     }
 }
 
-// tile aggregate for both incoming states; pre_mask bit u = parity of the units in front of unit u
+// tile aggregate for both incoming states, one unit per lane (called by one wave);
+// pre_mask bit u = parity of the units in front of unit u
 template <int UNITS>
-__device__ __forceinline__ void tile_aggregate(const u32 *s_unit, u32 &P, u32 &T0, u32 &T1, u32 &pre_mask) {
-    pre_mask = 0;
-    P = 0;
-    T0 = 0;
-    T1 = 0;
-#pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-        const u32 v = uniform(s_unit[u]);
-        pre_mask |= P << u;
-        const u32 c0 = v & 0x1fffu, c1 = (v >> 13) & 0x1fffu;
-        T0 += P ? c1 : c0;
-        T1 += P ? c0 : c1;
-        P ^= v >> 31;
-    }
+__device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 &P, u32 &T0, u32 &T1, u32 &pre_mask) {
+    const u32 v = lane < UNITS ? s_unit[lane] : 0u;
+    const u64 pbm = __ballot((v >> 31) != 0);
+    const u32 pre = lanes_below_popc(pbm) & 1u;  // parity of the units in front of this one
+    const u32 c0 = v & 0x1fffu, c1 = (v >> 13) & 0x1fffu;
+    T0 = lane63(wave_incl_scan(pre ? c1 : c0));
+    T1 = lane63(wave_incl_scan(pre ? c0 : c1));
+    P = (u32)popc64(pbm) & 1u;
+    pre_mask = (u32)__ballot(pre != 0);
 }
 
 // ---- flatten (flatten_bits_amd64.s:26-60, absolute positions instead of deltas) ------------
@@ -466,14 +437,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
     __shared__ u32 s_ticket[3];
-    __shared__ u32 s_unit[2][UNITS];
-    __shared__ WinSummary s_sum[2][WAVES];
+    __shared__ u32 s_unit[3][UNITS];
+    __shared__ u32 s_res[4];  // look-back result of the current tile: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
+    auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
 
     // At launch every block of the grid queues up on the ticket counter: the first ticket is drawn alone
     // (one atomic per block), the next two while phase A of the first tile is already running.
@@ -483,11 +455,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     if (t_cur >= num_tiles) return;
 
     // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
-    // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.
+    // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.  Per tile
+    // there are two block barriers; what is serial per tile (aggregate, ticket, look-back) is done by
+    // wave 0 between them while the other waves wait (their issue slots go to the other blocks of the CU).
     uint4 pf[4];
     {
         const u64 un = (u64)t_cur * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, (un != 0 || lead == 0) && (un + 1) * 4096 <= end, lane, lead, end, pf);
+        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
     if (tid == 0) {
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
@@ -498,50 +472,80 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
         const u64 un = (u64)t_nxt * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, (un != 0 || lead == 0) && (un + 1) * 4096 <= end, lane, lead, end, pf);
+        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
-    u32 P0, T00, T01, pm0;
-    tile_aggregate<UNITS>(s_unit[0], P0, T00, T01, pm0);
-    if (tid == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
+    u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // of the current tile; meaningful in wave 0 only
+    if (wave == 0) {
+        tile_aggregate<UNITS>(s_unit[0], lane, P0, T00, T01, pm0);
+        if (lane == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
+    }
 
-    int cb = 0;
+    int ms = 0, us = 0;  // mask / unit slots of t_cur
     bool err = false;
     for (;;) {
         const u32 t_nn = uniform(s_ticket[2]);  // the tile after t_nxt
         const bool has_next = t_nxt < num_tiles;
+        const int us_n = us == 2 ? 0 : us + 1;
+        u32 tk = 0;  // the ticket after t_nn: drawn now, it returns while phase A runs
+        if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
+        if (has_next)
+            phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
+                                       s_unit[us_n]);
+        // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
+        // waits for the other waves (the predecessors published their aggregates about a phase ago)
+        LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
+        u64 win[4] = {0, 0, 0, 0};
+        if (wave == 0 && t_cur != 0) lookback_load(desc, lb.j, lane, win);
+        __syncthreads();
         u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
-        if (has_next) {
-            phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[cb ^ 1][wave],
-                               s_unit[cb ^ 1]);
-            __syncthreads();
-            tile_aggregate<UNITS>(s_unit[cb ^ 1], P1, T10, T11, pm1);
-            if (tid == 0) {
-                desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
-                s_ticket[2] = atomicAdd(&st->tile_counter, 1u);  // returns during look-back + flatten
+        if (wave == 0) {
+            if (has_next) {
+                tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
+                if (lane == 0) {
+                    desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+                    s_ticket[2] = tk;
+                }
+            }
+            u32 G = 0;
+            u64 BASE = 0;
+            if (t_cur != 0) {
+                u32 spins = 0;
+                for (;;) {
+                    const int r = lookback_eval(win, lb, lane, G, BASE);
+                    if (r == 1) break;
+                    if (r == 0) __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                        break;
+                    }
+                    lookback_load(desc, lb.j, lane, win);
+                }
+                if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
+            }
+            if (lane == 0) {
+                s_res[0] = G;
+                s_res[1] = pm0;
+                s_res[2] = (u32)BASE;
+                s_res[3] = (u32)(BASE >> 32);
+                if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
             }
         }
-        u32 G = 0;
-        u64 BASE = 0;
-        if (t_cur != 0) {
-            lookback_wide<BLOCK>(desc, t_cur, tid, s_sum, G, BASE);
-            if (tid == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
-        }
+        __syncthreads();
+        const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
+        const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH>(s_mask[cb][wave], s_unit[cb], pm0, G, BASE, t_cur, lead, lane, wave, out_pos,
-                                           pos_cap, tile_end);
-        if (t_cur == num_tiles - 1 && tid == 0) {
-            st->total = tile_end;
-            st->ends_in_quote = (G ^ P0) & 1u;
-        }
+        err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
+                                       tile_end);
+        if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
-        __syncthreads();  // s_unit[cb] and the ticket slot are recycled by the next round
         P0 = P1;
         T00 = T10;
         T01 = T11;
         pm0 = pm1;
         t_cur = t_nxt;
         t_nxt = t_nn;
-        cb ^= 1;
+        ms ^= 1;
+        us = us_n;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 // ---- launcher --------------------------------------------------------------------------
 // Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
 // allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
-static constexpr int S1_DEFAULT_VARIANT = 6;
+static constexpr int S1_DEFAULT_VARIANT = 4;
 
 struct S1Variant {
     int block, ch, wpe;
