@@ -79,7 +79,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2};
+                      &ctx->d_s2,  &ctx->d_aux};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
@@ -120,7 +120,7 @@ static int stage1_verdict(const Stage1State &st, size_t len, uint8_t last_byte) 
 }
 
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                          uint8_t last_byte, int have_last, size_t *n, int *ok) {
+                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -128,7 +128,8 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream), "stage1 launch");
+    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux),
+           "stage1 launch");
     Stage1State *hs = (Stage1State *)ctx->h_scratch;
     HIPCHK(hipMemcpyAsync(hs, ctx->d_ws.p, sizeof(Stage1State), hipMemcpyDeviceToHost, ctx->stream), "D2H state");
     uint8_t *hlast = ctx->h_scratch + 128;

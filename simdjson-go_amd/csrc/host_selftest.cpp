@@ -30,6 +30,10 @@ static u32 peek_pseudo_pred(const u8 *msg, u64 p) {
     return 0;
 }
 
+// optional per-chunk outputs (what the stage-1 kernel leaves for the string kernels; absolute in-string mask,
+// i.e. unit state 0)
+static uint64_t *g_qm = nullptr, *g_q = nullptr, *g_st = nullptr;
+
 extern "C" int sj_selftest_stage1(const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t cap,
                                   size_t *n_out, uint32_t *error, uint32_t *ends_in_quote) {
     u32 par = 0;
@@ -43,12 +47,20 @@ extern "C" int sj_selftest_stage1(const uint8_t *msg, size_t len, int ndjson, ui
         memcpy(w, chunk, 64);
         const Classes c = classify(w);
         const u32 carry_in = off == 0 ? 0 : peek_backslash_parity(msg, off);
-        u32 carry_out;
-        const u64 odd_ends = odd_backslash_ends(c.bs, carry_in, carry_out);
-        const u64 quote_bits = c.quote & ~odd_ends;
+        const u64 escaped = escaped_mask(c.bs, carry_in);
+        const u64 quote_bits = c.quote & ~escaped;  // what the kernel runs
+        {
+            u32 carry_out;  // the reference's formulation must agree at the quotes
+            if ((c.quote & ~odd_backslash_ends(c.bs, carry_in, carry_out)) != quote_bits) err |= 0x100;
+        }
         u64 quote_mask = prefix_xor(quote_bits);
         if (par) quote_mask = ~quote_mask;
         par ^= (u32)popc64(quote_bits) & 1u;
+        if (g_qm) {
+            g_qm[off >> 6] = quote_mask;
+            g_q[off >> 6] = quote_bits;
+            g_st[off >> 6] = c.bs & ~escaped;
+        }
         if (c.ctrl & quote_mask) err = 1;
         const u32 pp_in = peek_pseudo_pred(msg, off);
         u64 s = finalize(c.structs, c.ws, quote_mask, quote_bits, pp_in);
@@ -115,6 +127,7 @@ extern "C" int sj_selftest_parse_number(const uint8_t *buf, size_t len, uint64_t
 
 #include "sj_host.h"
 #include "sj_stage2.h"
+#include "sj_strings.h"
 
 extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
     trim_space(msg, len, off, out_len);
@@ -150,7 +163,16 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     std::vector<u32> pos(len + 64);
     size_t n = 0;
     u32 err = 0, inq = 0;
+    const size_t units = (len + 4095) / 4096 + 1, chunks = units * 64;
+    std::vector<u64> v_qm(chunks, 0), v_q(chunks, 0), v_st(chunks, 0), v_em(chunks, 0), v_um(chunks, 0);
+    std::vector<u8> v_h(units, 0);
+    std::vector<uint16_t> v_pre(chunks, 0);
+    std::vector<u32> v_ucnt(units, 0);
+    g_qm = v_qm.data();
+    g_q = v_q.data();
+    g_st = v_st.data();
     sj_selftest_stage1(msg, len, ndjson, pos.data(), pos.size(), &n, &err, &inq);
+    g_qm = g_q = g_st = nullptr;
     if (len == 0 || err || inq || n == 0 || !(msg[len - 1] == '}' || msg[len - 1] == ']')) return 1;
     const MsgView mv{msg, len};
     // stage 2
@@ -160,7 +182,31 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     std::vector<u8> needcopy(n, 0);
     u32 bad = 0;
     for (size_t i = 0; i < n; i++) kind[i] = token_kind(msg[pos[i]], ndjson);
-    for (size_t i = 0; i < n; i++)
+    // byte-parallel string path (copy mode): the "kernels" k_str_masks / k_str_scan of stage2.hip as loops
+    const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data()};
+    const size_t used_units = (len + 4095) / 4096;
+    u64 masks_total = 0;
+    if (copy) {
+        for (size_t c = 0; c < used_units * 64; c++)
+            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c])) bad = 1;
+        for (size_t u = 0; u < used_units; u++) {
+            u32 run = 0;
+            for (size_t c = u * 64; c < u * 64 + 64; c++) {
+                v_pre[c] = (uint16_t)run;
+                run += (u32)popc64(v_em[c]);
+            }
+            v_ucnt[u] = (u32)masks_total;
+            masks_total += run;
+        }
+        for (size_t i = 0; i < n; i++)
+            if (kind[i] == K_STRING) {
+                const u64 a0 = (u64)pos[i] + 1, a1 = i + 1 < n ? pos[i + 1] : len;
+                dlen[i] = (u32)(emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a1) -
+                                emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a0));
+                needcopy[i] = 1;
+            }
+    }
+    for (size_t i = 0; i < n && !copy; i++)
         if (kind[i] == K_STRING) {
             u32 sl, dl;
             if (!string_walk(mv, pos[i], nullptr, &sl, &dl)) bad = 1;
@@ -220,7 +266,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     for (size_t i = 0; i < n; i++) {
         if (grammar_violation(t, (u32)i)) bad = 1;
         if (emit_simple(t, mv, (u32)i, tape)) bad = 1;
-        if (kind[i] == K_STRING && !bad) emit_string(t, mv, (u32)i, needcopy[i], dlen[i], tape, strs);
+        if (kind[i] == K_STRING && !bad) emit_string(t, mv, (u32)i, needcopy[i], dlen[i], tape, copy ? nullptr : strs);
         if (kind[i] == K_NUM) {
             u64 tag, val;
             int ub;
@@ -231,6 +277,9 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             }
         }
     }
+    if (copy && !bad)  // k_str_emit
+        for (size_t c = 0; c < used_units * 64; c++)
+            str_chunk_emit(sv, c, v_em[c], v_um[c], c ? v_um[c - 1] : 0ull, strs + v_ucnt[c >> 6] + v_pre[c]);
     for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape, tape_base);
     if (bad) {
         free(tape);

@@ -30,11 +30,18 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     size_t pos_cap = len / 3 + 4096;
     size_t n = 0;
     int ok = 0;
+    // every string copied (the reference's default): stage 1 leaves its string masks for the byte-parallel unescape
+    void *aux = nullptr;
+    if (flags & SJHIP_FLAG_COPY_STRINGS) {
+        int rc = arena_reserve(ctx, ctx->d_aux, str_aux_bytes(len + 64));
+        if (rc) return rc;
+        aux = ctx->d_aux.p;
+    }
     for (int attempt = 0; attempt < 2; attempt++) {
         int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * sizeof(uint32_t));
         if (rc) return rc;
         rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                               have_last, &n, &ok);
+                               have_last, &n, &ok, aux);
         if (rc) return rc;
         if (n <= pos_cap) break;
         pos_cap = n;
@@ -46,8 +53,9 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_strings, len + 64);
     if (rc) return rc;
-    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, ctx->stream),
+    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, ctx->stream, aux),
            "stage2 launch (measure)");
+    ctx->p_aux = aux;
     ctx->pending = 1;
     ctx->p_msg = d_msg;
     ctx->p_len = len;
@@ -74,7 +82,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     const size_t n = ctx->p_n, len = ctx->p_len;
     HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, n, ctx->p_flags, ctx->d_s2.p,
                               (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
-                              strings_base, msg_base, ctx->stream),
+                              strings_base, msg_base, ctx->stream, ctx->p_aux),
            "stage2 launch (emit)");
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
     HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");

@@ -160,6 +160,22 @@ SJ_HD u64 odd_backslash_ends(u64 bs, u32 carry_in, u32 &carry_out) {
     return ((even_carries & ~bs) & odd_bits) | ((odd_carries & ~bs) & even_bits);
 }
 
+// The same information in the form the kernels use: the mask of ESCAPED characters -- every character that
+// directly follows an unescaped backslash (a "starter"): the second, fourth, ... backslash of a run and
+// the character after an odd-length run.  At quote positions it equals odd_backslash_ends, so
+// quote & ~escaped_mask == quote & ~odd_backslash_ends; bs & ~escaped_mask are the starters.
+// carry_in = 1 iff the first character of the chunk is escaped (previous chunk ended in an odd run).
+SJ_HD u64 escaped_mask(u64 bs, u32 carry_in) {
+    const u64 even_bits = 0x5555555555555555ull;
+    const u64 prev = carry_in;
+    const u64 b = bs & ~prev;                    // an escaped backslash does not escape
+    const u64 follows = (b << 1) | prev;         // characters that follow a backslash
+    const u64 odd_starts = b & ~even_bits & ~follows;  // runs that begin on an odd bit
+    const u64 seq_even = odd_starts + b;         // carry ripples through each such run
+    const u64 invert = seq_even << 1;
+    return (even_bits ^ invert) & follows;
+}
+
 // prefix XOR (the reference's VPCLMULQDQ by all-ones, find_quote_mask_and_bits_amd64.s:62-66)
 SJ_HD u64 prefix_xor(u64 x) {
     x ^= x << 1;

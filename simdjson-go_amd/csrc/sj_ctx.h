@@ -19,7 +19,7 @@ struct sjhip_ctx {
     hipStream_t own_stream = nullptr;  // created with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
-    sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2;
+    sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_aux;
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;
@@ -28,6 +28,7 @@ struct sjhip_ctx {
     const void *p_msg = nullptr;
     size_t p_len = 0, p_n = 0;
     uint32_t p_flags = 0;
+    void *p_aux = nullptr;
     char err[256];
 };
 
@@ -36,5 +37,5 @@ void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                      uint8_t last_byte, int have_last, size_t *n, int *ok);
+                      uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr);
 }  // namespace sj

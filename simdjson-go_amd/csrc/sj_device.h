@@ -26,7 +26,9 @@ struct S2State {
     unsigned long long tape_len;
     unsigned long long strings_len;
     uint32_t n_br;           // number of bracket tokens (size of the compact bracket view)
-    uint32_t pad[7];
+    uint32_t pad0;
+    unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
+    uint32_t pad[4];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 
@@ -36,16 +38,49 @@ hipError_t stage2_launch(const void *d_msg, size_t len, const uint32_t *d_pos, s
                          hipStream_t stream);
 
 hipError_t stage2_launch_measure(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
-                                 hipStream_t stream);
+                                 hipStream_t stream, void *str_aux = nullptr);
 hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
                               uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
-                              uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, hipStream_t stream);
+                              uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, hipStream_t stream,
+                              void *str_aux = nullptr);
 
 size_t stage1_workspace_bytes(size_t len);
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
+// String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / q / st / unit_h, the string
+// kernels of stage 2 add em / um / chunk_pre / unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
+// base of the message); everything is sized in whole 4 KiB units.
+struct StrAux {
+    size_t units, chunks, bytes;
+    uint64_t *qm, *q, *st, *em, *um;
+    uint16_t *chunk_pre;
+    uint32_t *unit_cnt;
+    uint8_t *unit_h;
+};
+inline StrAux str_aux_layout(void *buf, size_t span) {
+    StrAux a;
+    a.units = (span + 4095) / 4096 + 1;
+    a.chunks = a.units * 64;
+    char *w = reinterpret_cast<char *>(buf);
+    auto carve = [&](size_t n) {
+        char *r = w;
+        w += (n + 255) / 256 * 256;
+        return r;
+    };
+    a.qm = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
+    a.q = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
+    a.st = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
+    a.em = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
+    a.um = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
+    a.chunk_pre = reinterpret_cast<uint16_t *>(carve(a.chunks * 2));
+    a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
+    a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
+    a.bytes = (size_t)(w - reinterpret_cast<char *>(buf));
+    return a;
+}
+inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).bytes + 256; }
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
-                                  void *ws, hipStream_t stream);
+                                  void *ws, hipStream_t stream, void *aux_buf = nullptr);
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream);
+                         hipStream_t stream, void *aux_buf = nullptr);
 
 }  // namespace sj

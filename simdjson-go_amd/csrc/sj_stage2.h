@@ -463,8 +463,10 @@ SJ_HD void emit_string(const Tokens &t, const MsgView &m, u32 i, bool need_copy,
     if (!need_copy) {
         tape[o] = ((u64)'"' << 56) | (t.msg_base + q + 1);
     } else {
-        u32 sl, dl;
-        string_walk(m, q, strings + t.str_off[i], &sl, &dl);
+        if (strings) {  // nullptr: Strings.B is written by the byte-parallel path (sj_strings.h)
+            u32 sl, dl;
+            string_walk(m, q, strings + t.str_off[i], &sl, &dl);
+        }
         tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + t.strings_base + t.str_off[i]);
     }
     tape[o + 1] = dst_len;

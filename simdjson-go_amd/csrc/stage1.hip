@@ -29,6 +29,13 @@
 
 namespace sj {
 
+// optional extra outputs for the whole parse (all null for stage 1 alone): per 64-byte chunk the in-string mask
+// relative to the unit start, the unescaped quotes and the escape starters; per 4 KiB unit the resolved state
+struct S1Aux {
+    u64 *qm, *q, *st;
+    u8 *unit_h;
+};
+
 // ---- tile descriptors ------------------------------------------------------------------
 // One naturally aligned 8-byte granule per tile, status and payload together, relaxed
 // agent-scope accesses (MI355X guide, Guideline 16 form R2):
@@ -245,7 +252,7 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 t, u32 t_next, bool has_next,
-                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit) {
+                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit, const S1Aux &aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // interior unit: all 4096 bytes belong to the message (wave-uniform -> scalar unit)
@@ -294,14 +301,16 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
         u64 quote_bits = c.quote;
+        u64 starters = 0;  // backslashes that begin an escape sequence
         const u32 bs_any = (u32)c.bs | (u32)(c.bs >> 32);
         if (__ballot(bs_any != 0) != 0 || carry0 != 0) {  // wave-uniform: many waves see no backslash at all
             const bool all_bs = c.bs == ~0ull;
             const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
             u32 carry_in = wave_shift_up(trail_odd, carry0);
             if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64);
-            u32 carry_out;
-            quote_bits &= ~odd_backslash_ends(c.bs, carry_in, carry_out);
+            const u64 escaped = escaped_mask(c.bs, carry_in);
+            quote_bits &= ~escaped;
+            starters = c.bs & ~escaped;
         }
 
         // ---- in-string mask relative to the start of the wave unit
@@ -323,6 +332,12 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
+        if (aux.qm && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+            const u64 ci = unit * 64 + (u64)lane;
+            aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
+            aux.q[ci] = quote_bits;
+            aux.st[ci] = starters;
+        }
         // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80), per hypothesis
         const u64 in_a = c.ctrl & qm, in_b = c.ctrl & ~qm;
         const u32 bad = (__ballot(((u32)in_a | (u32)(in_a >> 32)) != 0) != 0 ? 1u : 0u) |
@@ -356,7 +371,7 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 template <int BLOCK, int CH>
 __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
-                                             u64 &tile_end) {
+                                             u64 &tile_end, u8 *unit_h, u64 len_) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     constexpr u32 CAP = CH * 256;  // u32 slots in the wave's window (CH * 2 * 64 u64)
@@ -376,6 +391,8 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
     for (int k = 0; k < CH; k++) {
         const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
         sel[k] = m[(k * 2 + (int)h) * 64 + lane];
+        if (unit_h && lane == 0 && ((u64)t * UNITS + (u64)(k * WAVES + wave)) * 4096 < lead + len_)
+            unit_h[(u64)t * UNITS + (u64)(k * WAVES + wave)] = (u8)h;
     }
     u32 *stage = reinterpret_cast<u32 *>(m);
     const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
@@ -432,7 +449,7 @@ template <int BLOCK, int CH, int WPE, bool NDJSON>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
-                                                                        u64 *__restrict__ desc, u32 num_tiles) {
+                                                                        u64 *__restrict__ desc, u32 num_tiles, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
-    phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0]);
+    phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0], aux);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
         if (has_next)
             phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                       s_unit[us_n]);
+                                       s_unit[us_n], aux);
         // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
         // waits for the other waves (the predecessors published their aggregates about a phase ago)
         LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end);
+                                       tile_end, aux.unit_h, len);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
         P0 = P1;
@@ -603,7 +620,7 @@ hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream)
 
 // d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, void *aux_buf) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -613,9 +630,17 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr};
+    if (aux_buf) {
+        const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
+        aux.qm = a.qm;
+        aux.q = a.q;
+        aux.st = a.st;
+        aux.unit_h = a.unit_h;
+    }
 #define S1_LAUNCH2(B, C, W, ND)                                                                                   \
     hipLaunchKernelGGL((stage1_kernel<B, C, W, ND>), dim3(grid_for(stage1_kernel<B, C, W, ND>, B, tiles)), dim3(B), 0, \
-                       stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles)
+                       stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles, aux)
 #define S1_LAUNCH(B, C, W)            \
     do {                              \
         if (nd)                       \
@@ -636,10 +661,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 }
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream) {
+                         hipStream_t stream, void *aux_buf) {
     hipError_t e = stage1_prepare(len, reinterpret_cast<uintptr_t>(d_msg) & 63, ws, stream);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf);
 }
 
 }  // namespace sj

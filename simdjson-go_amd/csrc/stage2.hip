@@ -12,6 +12,7 @@
 #include "sj_device.h"
 #include "sj_number.h"
 #include "sj_stage2.h"
+#include "sj_strings.h"
 
 namespace sj {
 
@@ -53,6 +54,12 @@ struct S2Dev {
     u8 *strings;
     u64 tape_cap, strings_cap;
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
+    // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
+    StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
+    u64 *em, *um;         // [chunks] emit mask, 'u' mask
+    uint16_t *chunk_pre;  // [chunks] emitted bytes of the unit in front of the chunk
+    u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
+    u64 units;
 };
 
 struct Agg {
@@ -82,6 +89,74 @@ __device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
     return a;
 }
 
+// ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
+__global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (c >= p.units * 64) return;  // whole waves
+    u64 em, um;
+    if (!str_chunk_masks(p.sv, c, &em, &um)) atomicOr(&p.st->err, 1u);
+    p.em[c] = em;
+    p.um[c] = um;
+    const u32 n = (u32)popc64(em);
+    u32 incl = n;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const u32 o = __shfl_up(incl, s, 64);
+        if (lane >= s) incl += o;
+    }
+    p.chunk_pre[c] = (uint16_t)(incl - n);
+    if (lane == 63) p.unit_cnt[c >> 6] = incl;
+}
+
+// one block: exclusive scan of the unit counts (in place) + Strings.B length
+__global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
+    __shared__ u64 lds[1024];
+    const u64 per = (p.units + 1023) / 1024;
+    const u64 lo = (u64)threadIdx.x * per, hi = lo + per < p.units ? lo + per : p.units;
+    u64 sum = 0;
+    for (u64 u = lo; u < hi; u++) sum += p.unit_cnt[u];
+    lds[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele over the 1024 partial sums
+        const u64 v = threadIdx.x >= (unsigned)s ? lds[threadIdx.x - s] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u64 run = threadIdx.x ? lds[threadIdx.x - 1] : 0;
+    for (u64 u = lo; u < hi; u++) {
+        const u32 cnt = p.unit_cnt[u];
+        p.unit_cnt[u] = (u32)run;
+        run += cnt;
+    }
+    if (threadIdx.x == 1023) p.st->strings_len_masks = lds[1023];
+}
+
+__global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
+    __shared__ u8 stage[4][4096 + 16];
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (c >= p.units * 64) return;
+    const u64 unit = c >> 6;
+    const u64 em = p.em[c];
+    const u32 pre = p.chunk_pre[c];
+    const u32 n = (u32)popc64(em);
+    const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
+    if (total == 0) return;  // wave-uniform
+    str_chunk_emit(p.sv, c, em, p.um[c], c ? p.um[c - 1] : 0ull, &stage[wave][pre]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
+    if (g + total > p.strings_cap) return;
+    u8 *dst = p.strings + g;
+    const u32 words = total >> 2;
+    for (u32 i = lane; i < words; i += 64)  // unaligned 4-byte global stores are fine on gfx950
+        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&stage[wave][4 * i]);
+    const u32 tail = words * 4 + lane;
+    if (tail < total) dst[tail] = stage[wave][tail];
+}
+
 // ---- kernel 1: token kinds + string lengths (parseStringSimdValidateOnly) ---------------------------------
 __global__ __launch_bounds__(256) void k_string_measure(S2Dev p) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -89,7 +164,12 @@ __global__ __launch_bounds__(256) void k_string_measure(S2Dev p) {
     const u8 kind = token_kind(p.msg[p.pos[i]], p.ndjson != 0);
     p.kind[i] = kind;
     u32 out = 0;
-    if (kind == K_STRING) {
+    if (kind == K_STRING && p.sv.qm) {  // every string is copied: offset and length come from the emit masks
+        const u64 a0 = (u64)p.pos[i] + p.sv.lead + 1;
+        const u64 a1 = (i + 1 < p.n ? (u64)p.pos[i + 1] : p.len) + p.sv.lead;
+        out = (u32)(emitted_before(p.unit_cnt, p.chunk_pre, p.em, a1) - emitted_before(p.unit_cnt, p.chunk_pre, p.em, a0)) |
+              DLEN_COPY;
+    } else if (kind == K_STRING) {
         const MsgView mv{p.msg, p.len};
         u32 sl, dl;
         if (!string_walk(mv, p.pos[i], nullptr, &sl, &dl)) {
@@ -329,7 +409,7 @@ __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
     if ((u64)p.str_off[i] + (dl & ~DLEN_COPY) > p.strings_cap) return;
     const Tokens t = make_tokens(p);
     const MsgView mv{p.msg, p.len};
-    emit_string(t, mv, i, (dl & DLEN_COPY) != 0, dl & ~DLEN_COPY, p.tape, p.strings);
+    emit_string(t, mv, i, (dl & DLEN_COPY) != 0, dl & ~DLEN_COPY, p.tape, p.sv.qm ? nullptr : p.strings);
 }
 
 // ---- kernel 10: exact tie-break for >19-digit mantissas whose neighbours disagree ------------------------------
@@ -370,7 +450,7 @@ size_t stage2_workspace_bytes(size_t n) {
 
 // carve the device view out of the workspace (deterministic: both phases rebuild the same view)
 static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
-                         size_t tape_cap, u8 *d_strings, size_t strings_cap) {
+                         size_t tape_cap, u8 *d_strings, size_t strings_cap, void *str_aux) {
     S2Dev p;
     char *w = reinterpret_cast<char *>(ws);
     auto carve = [&](size_t bytes) {
@@ -421,6 +501,29 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.tape_cap = tape_cap;
     p.strings_cap = strings_cap;
     p.tape_base = p.strings_base = p.msg_base = 0;
+    // byte-parallel strings: only when every string is copied and stage 1 left its masks
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_msg);
+    p.sv.base = reinterpret_cast<const u8 *>(addr & ~(uintptr_t)63);
+    p.sv.lead = addr & 63;
+    p.sv.end = p.sv.lead + len;
+    p.sv.qm = p.sv.q = p.sv.st = nullptr;
+    p.sv.unit_h = nullptr;
+    p.em = p.um = nullptr;
+    p.chunk_pre = nullptr;
+    p.unit_cnt = nullptr;
+    p.units = 0;
+    if (str_aux && p.copy_strings) {
+        const StrAux a = str_aux_layout(str_aux, (size_t)p.sv.end);
+        p.sv.qm = a.qm;
+        p.sv.q = a.q;
+        p.sv.st = a.st;
+        p.sv.unit_h = a.unit_h;
+        p.em = a.em;
+        p.um = a.um;
+        p.chunk_pre = a.chunk_pre;
+        p.unit_cnt = a.unit_cnt;
+        p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
+    }
     return p;
 }
 
@@ -428,13 +531,17 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
 // strings_len of this message (what an NDJSON shard exchanges with the other shards) and every token
 // knows its depth and its tape / Strings.B offsets.
 hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws,
-                                 hipStream_t stream) {
-    const S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, nullptr, 0, nullptr, 0);
+                                 hipStream_t stream, void *str_aux) {
+    const S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
     hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.match, 0, n * 4, stream);
     if (e != hipSuccess) return e;
     const u32 gb = (u32)((n + 255) / 256);
+    if (p.sv.qm) {
+        hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(k_str_scan, dim3(1), dim3(1024), 0, stream, p);
+    }
     hipLaunchKernelGGL(k_string_measure, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_scan_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
@@ -447,8 +554,8 @@ hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos
 // prefix sums over the preceding shards for an NDJSON shard.
 hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
                               size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base, u64 strings_base,
-                              u64 msg_base, hipStream_t stream) {
-    S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap);
+                              u64 msg_base, hipStream_t stream, void *str_aux) {
+    S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, str_aux);
     p.tape_base = tape_base;
     p.strings_base = strings_base;
     p.msg_base = msg_base;
@@ -460,15 +567,17 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
     hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
                          size_t tape_cap, u8 *d_strings, size_t strings_cap, hipStream_t stream) {
-    hipError_t e = stage2_launch_measure(d_msg, len, d_pos, n, flags, ws, stream);
+    hipError_t e = stage2_launch_measure(d_msg, len, d_pos, n, flags, ws, stream, nullptr);
     if (e != hipSuccess) return e;
-    return stage2_launch_emit(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, 0, 0, 0, stream);
+    return stage2_launch_emit(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, 0, 0, 0, stream,
+                              nullptr);
 }
 
 }  // namespace sj
