@@ -279,7 +279,8 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     }
     if (copy && !bad)  // k_str_emit
         for (size_t c = 0; c < used_units * 64; c++)
-            str_chunk_emit(sv, c, v_em[c], v_um[c], c ? v_um[c - 1] : 0ull, strs + v_ucnt[c >> 6] + v_pre[c]);
+            str_chunk_emit(sv, c, v_em[c], v_um[c], c ? v_um[c - 1] : 0ull, strs + v_ucnt[c >> 6] + v_pre[c],
+                           [&](u32 p) { return sv.at(c * 64 + p); });
     for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape, tape_base);
     if (bad) {
         free(tape);

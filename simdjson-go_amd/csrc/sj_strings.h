@@ -174,8 +174,10 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out) {
 }
 
 // Pass 2, one chunk: writes the popc(em) bytes of chunk c to dst (ascending positions).
-// em / um are the masks of pass 1 (um of the previous chunk for escapes that reach into this one).
-SJ_HD void str_chunk_emit(const StrView &m, u64 c, u64 em, u64 um, u64 um_prev, u8 *dst) {
+// em / um are the masks of pass 1 (um of the previous chunk for escapes that reach into this one);
+// byte_at(p) returns byte p of the chunk (the kernel serves it from LDS, the host replay from memory).
+template <typename ByteAt>
+SJ_HD void str_chunk_emit(const StrView &m, u64 c, u64 em, u64 um, u64 um_prev, u8 *dst, ByteAt byte_at) {
     const u64 e = m.esc(c);
     // positions 1..4 behind a 'u' (hex digit slots): handled by the unicode path
     const u64 uh = (um << 1) | (um << 2) | (um << 3) | (um << 4) | (um_prev >> 63) | (um_prev >> 62) | (um_prev >> 61) |
@@ -199,9 +201,9 @@ SJ_HD void str_chunk_emit(const StrView &m, u64 c, u64 em, u64 um, u64 um_prev, 
             }
             v = unicode_escape(m, au).b[j];
         } else if (e & bit) {
-            v = escape_value(m.at(a));
+            v = escape_value(byte_at(p));
         } else {
-            v = m.at(a);
+            v = byte_at(p);
         }
         dst[o++] = v;
     }

@@ -109,32 +109,61 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
+// one block of 1024 threads: exclusive scan of u32 data[n] in place (n padded to a multiple of 4 by the caller's
+// allocation), 4096 elements per round with 16-byte coalesced accesses; returns the total (valid in every thread)
+__device__ u64 block_exclusive_scan_u32(u32 *data, u64 n) {
+    __shared__ u32 s_wave[16];
+    __shared__ u64 s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 start = 0; start < n; start += 4096) {
+        const u64 i = start + (u64)threadIdx.x * 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i + 3 < n) {
+            v = *reinterpret_cast<const uint4 *>(data + i);
+        } else {
+            if (i < n) v.x = data[i];
+            if (i + 1 < n) v.y = data[i + 1];
+            if (i + 2 < n) v.z = data[i + 2];
+        }
+        const u32 t = v.x + v.y + v.z + v.w;
+        u32 incl = t;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const u32 o = __shfl_up(incl, s, 64);
+            if (lane >= s) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        u32 before = 0;
+        for (int w = 0; w < wave; w++) before += s_wave[w];
+        const u64 carry = s_carry;
+        const u32 ex = (u32)carry + before + incl - t;  // positions are < 2^32
+        const uint4 o = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        if (i + 3 < n) {
+            *reinterpret_cast<uint4 *>(data + i) = o;
+        } else {
+            if (i < n) data[i] = o.x;
+            if (i + 1 < n) data[i + 1] = o.y;
+            if (i + 2 < n) data[i + 2] = o.z;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + before + incl;
+        __syncthreads();
+    }
+    return s_carry;
+}
+
 // one block: exclusive scan of the unit counts (in place) + Strings.B length
 __global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
-    __shared__ u64 lds[1024];
-    const u64 per = (p.units + 1023) / 1024;
-    const u64 lo = (u64)threadIdx.x * per, hi = lo + per < p.units ? lo + per : p.units;
-    u64 sum = 0;
-    for (u64 u = lo; u < hi; u++) sum += p.unit_cnt[u];
-    lds[threadIdx.x] = sum;
-    __syncthreads();
-    for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele over the 1024 partial sums
-        const u64 v = threadIdx.x >= (unsigned)s ? lds[threadIdx.x - s] : 0;
-        __syncthreads();
-        lds[threadIdx.x] += v;
-        __syncthreads();
-    }
-    u64 run = threadIdx.x ? lds[threadIdx.x - 1] : 0;
-    for (u64 u = lo; u < hi; u++) {
-        const u32 cnt = p.unit_cnt[u];
-        p.unit_cnt[u] = (u32)run;
-        run += cnt;
-    }
-    if (threadIdx.x == 1023) p.st->strings_len_masks = lds[1023];
+    const u64 total = block_exclusive_scan_u32(p.unit_cnt, p.units);
+    if (threadIdx.x == 0) p.st->strings_len_masks = total;
 }
 
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
-    __shared__ u8 stage[4][4096 + 16];
+    __shared__ u32 s_in[4][16][64];       // the wave's 64 chunks, dword-major (bank = lane)
+    __shared__ u8 s_out[4][4096 + 16];    // the unit's unescaped bytes
     const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (c >= p.units * 64) return;
@@ -144,17 +173,30 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const u32 n = (u32)popc64(em);
     const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
     if (total == 0) return;  // wave-uniform
-    str_chunk_emit(p.sv, c, em, p.um[c], c ? p.um[c - 1] : 0ull, &stage[wave][pre]);
-    __builtin_amdgcn_wave_barrier();
+    if (em != 0) {  // the chunk holds message bytes: its 64-byte line is readable
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + c * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = src[q];
+            s_in[wave][4 * q + 0][lane] = v.x;
+            s_in[wave][4 * q + 1][lane] = v.y;
+            s_in[wave][4 * q + 2][lane] = v.z;
+            s_in[wave][4 * q + 3][lane] = v.w;
+        }
+        const u8 *in8 = reinterpret_cast<const u8 *>(&s_in[wave][0][0]);
+        str_chunk_emit(p.sv, c, em, p.um[c], c ? p.um[c - 1] : 0ull, &s_out[wave][pre],
+                       [&](u32 q) { return in8[((q >> 2) * 64 + lane) * 4 + (q & 3)]; });
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
     if (g + total > p.strings_cap) return;
     u8 *dst = p.strings + g;
     const u32 words = total >> 2;
     for (u32 i = lane; i < words; i += 64)  // unaligned 4-byte global stores are fine on gfx950
-        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&stage[wave][4 * i]);
+        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&s_out[wave][4 * i]);
     const u32 tail = words * 4 + lane;
-    if (tail < total) dst[tail] = stage[wave][tail];
+    if (tail < total) dst[tail] = s_out[wave][tail];
 }
 
 // ---- kernel 1: token kinds + string lengths (parseStringSimdValidateOnly) ---------------------------------
@@ -391,6 +433,9 @@ __global__ __launch_bounds__(256) void k_emit(S2Dev p) {
             p.tape[o + 1] = val;
             if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = i;
         }
+    } else if (k == K_STRING && p.sv.qm) {  // copy mode: the bytes are written by k_str_emit, only the tape words here
+        const u32 dl = p.dlen[i];
+        if (dl != DLEN_INVALID) emit_string(t, mv, i, true, dl & ~DLEN_COPY, p.tape, nullptr);
     } else if (k == K_NL) {
         if (i + 1 < p.n && p.kind[i + 1] != K_NL)
             emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, p.match[i] + 1, p.tape, p.tape_base);
@@ -566,7 +611,7 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
     }
     hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
+    if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
     return hipGetLastError();
