@@ -374,27 +374,25 @@ SJ_HD void bracket_resolve_compact(const MinTree &mt, const u32 *br_tok, const u
     ctxb[i] = ctx;
 }
 
+// ---- grammar on values (the kernel preloads them; the pointer forms below feed the same functions) ----------
 // a string token is an object key iff it sits in an object right after '{' or ','
-SJ_HD bool string_is_key(const Tokens &t, u32 j, u8 ctx) {
-    return ctx == CTX_OBJ && j > 0 && (t.kind[j - 1] == K_OPEN_OBJ || t.kind[j - 1] == K_COMMA);
+SJ_HD bool string_is_key_v(u8 ctx, bool has_prev, u8 prev_kind) {
+    return ctx == CTX_OBJ && has_prev && (prev_kind == K_OPEN_OBJ || prev_kind == K_COMMA);
 }
-// does token j end a value of the container whose context is ctx?
-SJ_HD bool ends_value(const Tokens &t, u32 j, u8 ctx) {
-    const u8 k = t.kind[j];
+// does a token of kind k (whose predecessor has kind prev_kind, if any) end a value of the container with context ctx?
+SJ_HD bool ends_value_v(u8 k, u8 ctx, bool has_prev, u8 prev_kind) {
     if (k == K_CLOSE_OBJ || k == K_CLOSE_ARR || k == K_NUM || k == K_TRUE || k == K_FALSE || k == K_NULL) return true;
-    if (k == K_STRING) return !string_is_key(t, j, ctx);
+    if (k == K_STRING) return !string_is_key_v(ctx, has_prev, prev_kind);
     return false;
 }
-
-// Grammar check of token i (true = violation).  Mirrors the transitions of unifiedMachine:
+// Grammar check of token i (true = violation): k = its kind, pk / ppk = kinds of tokens i-1 / i-2 (if they
+// exist), G = context of the gap in front of it.  Mirrors the transitions of unifiedMachine:
 // continueRoot/startContinue (:176-221), object_begin/object_key_state/objectContinue (:225-325),
 // arrayBegin/mainArraySwitch/arrayContinue (:346-426).
-SJ_HD bool grammar_violation(const Tokens &t, u32 i) {
-    const u8 k = t.kind[i];
+SJ_HD bool grammar_violation_v(u32 i, u8 k, u8 pk, u8 ppk, u8 G) {
     if (k == K_BAD) return true;
     if (i == 0) return !is_open(k);
-    const u8 G = gap_ctx(t, i);
-    const u8 pk = t.kind[i - 1];
+    const bool has_pp = i > 1;
     switch (k) {
     case K_OPEN_OBJ:
     case K_OPEN_ARR:
@@ -412,18 +410,31 @@ SJ_HD bool grammar_violation(const Tokens &t, u32 i) {
         if (G == CTX_ARR) return !(pk == K_OPEN_ARR || pk == K_COMMA);
         return true;
     case K_COLON:
-        return !(G == CTX_OBJ && pk == K_STRING && string_is_key(t, i - 1, G));
+        return !(G == CTX_OBJ && pk == K_STRING && string_is_key_v(G, has_pp, ppk));
     case K_COMMA:
-        return !(G != CTX_ROOT && ends_value(t, i - 1, G));
+        return !(G != CTX_ROOT && ends_value_v(pk, G, has_pp, ppk));
     case K_CLOSE_OBJ:
-        return !(G == CTX_OBJ && (pk == K_OPEN_OBJ || ends_value(t, i - 1, G)));
+        return !(G == CTX_OBJ && (pk == K_OPEN_OBJ || ends_value_v(pk, G, has_pp, ppk)));
     case K_CLOSE_ARR:
-        return !(G == CTX_ARR && (pk == K_OPEN_ARR || ends_value(t, i - 1, G)));
+        return !(G == CTX_ARR && (pk == K_OPEN_ARR || ends_value_v(pk, G, has_pp, ppk)));
     case K_NL:
         return !(G == CTX_ROOT && (is_close(pk) || pk == K_NL));
     default:
         return true;
     }
+}
+// context from the last bracket in front of a token: b = its index + 1 (0: none), bk / bc = its kind / resume context
+SJ_HD u8 gap_ctx_v(u32 b, u8 bk, u8 bc) {
+    if (b == 0) return CTX_ROOT;
+    if (bk == K_OPEN_OBJ) return CTX_OBJ;
+    if (bk == K_OPEN_ARR) return CTX_ARR;
+    return bc;
+}
+
+SJ_HD bool string_is_key(const Tokens &t, u32 j, u8 ctx) { return string_is_key_v(ctx, j > 0, j > 0 ? t.kind[j - 1] : (u8)K_BAD); }
+SJ_HD bool grammar_violation(const Tokens &t, u32 i) {
+    return grammar_violation_v(i, t.kind[i], i > 0 ? t.kind[i - 1] : (u8)K_BAD, i > 1 ? t.kind[i - 2] : (u8)K_BAD,
+                               gap_ctx(t, i));
 }
 
 // ---- tape emission ---------------------------------------------------------------------------------

@@ -410,37 +410,89 @@ __global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
 }
 
 // ---- kernel 8: grammar check + tape words of brackets, atoms, numbers and roots ----------------------------
-__global__ __launch_bounds__(256) void k_emit(S2Dev p) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+// Numbers are the expensive tokens (a byte loop and a 128-bit multiply) and only ~10 % of all tokens: every
+// block first handles everything else and queues its number tokens in LDS, then parses them with the lanes
+// packed densely, so that a wave of commas does not pay for the one number among them.
+static constexpr int EMIT_BLOCK = 1024;
+__global__ __launch_bounds__(EMIT_BLOCK) void k_emit(S2Dev p) {
+    __shared__ u32 s_num[EMIT_BLOCK];
+    __shared__ u32 s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const u32 i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
     const Tokens t = make_tokens(p);
     const MsgView mv{p.msg, p.len};
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    bool bad = grammar_violation(t, i);
-    bad |= emit_simple(t, mv, i, p.tape);
-    const u8 k = p.kind[i];
-    if (k == K_NUM) {
+    bool bad = false;
+    if (i < p.n) {
+        // round 1: everything that only depends on i, issued together (one memory round trip)
+        const u8 k = p.kind[i];
+        const u8 pk = i > 0 ? p.kind[i - 1] : (u8)K_BAD, ppk = i > 1 ? p.kind[i - 2] : (u8)K_BAD;
+        const u8 nk = i + 1 < p.n ? p.kind[i + 1] : (u8)K_BAD;
+        const u32 lb = i > 0 ? p.last_br[i - 1] : 0u;
+        const u32 o = p.tape_off[i], m = p.match[i], dl = p.dlen[i], so = p.str_off[i];
+        // round 2: the last bracket in front (context) and the partner of a bracket
+        const u8 bk = lb ? p.kind[lb - 1] : (u8)K_BAD, bc = lb ? p.ctxb[lb - 1] : (u8)CTX_ROOT;
+        const bool br = is_bracket(k) && m < p.n;
+        const u32 mo = br ? p.tape_off[m] : 0u;
+        bad = grammar_violation_v(i, k, pk, ppk, gap_ctx_v(lb, bk, bc));
+        switch (k) {
+        case K_OPEN_OBJ:
+        case K_OPEN_ARR:  // payload: tape index just after the matching close (annotate_previousloc, :336)
+            p.tape[o] = ((u64)(k == K_OPEN_OBJ ? '{' : '[') << 56) | (br ? p.tape_base + mo + 1 : 0ull);
+            break;
+        case K_CLOSE_OBJ:
+        case K_CLOSE_ARR:  // payload: tape index of the matching open (:335)
+            p.tape[o] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (br ? p.tape_base + mo : 0ull);
+            break;
+        case K_TRUE:
+        case K_FALSE:
+        case K_NULL:
+            p.tape[o] = (u64)(k == K_TRUE ? 't' : (k == K_FALSE ? 'f' : 'n')) << 56;
+            bad |= !atom_valid(mv, p.pos[i], k);
+            break;
+        case K_NUM: {  // wave-aggregated append: one LDS atomic per wave
+            const u64 act = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            const int leader = (int)__builtin_ctzll(act);
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&s_cnt, (u32)__builtin_popcountll(act));
+            base = (u32)__shfl((int)base, leader, 64);
+            s_num[base + (u32)__builtin_popcountll(act & ((1ull << lane) - 1))] = i;
+            break;
+        }
+        case K_STRING:
+            if (p.sv.qm && dl != DLEN_INVALID) {  // copy mode: the bytes are written by k_str_emit, only the tape words here
+                p.tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + p.strings_base + so);
+                p.tape[o + 1] = dl & ~DLEN_COPY;
+            }
+            break;
+        case K_NL:
+            if (i + 1 < p.n && nk != K_NL)
+                emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, m + 1, p.tape, p.tape_base);
+            break;
+        default: break;
+        }
+        if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape, p.tape_base);
+    }
+    __syncthreads();
+    const u32 cnt = s_cnt;
+    for (u32 j = threadIdx.x; j < cnt; j += EMIT_BLOCK) {
+        const u32 q = s_num[j];
         u64 tag = 0, val = 0;
         u32 numlen = 0;
-        const u32 at = p.pos[i];
+        const u32 at = p.pos[q];
         const int st = parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
         if (st == NUM_FAIL) {
             bad = true;
         } else {
-            const u32 o = p.tape_off[i];
+            const u32 o = p.tape_off[q];
             p.tape[o] = tag;
             p.tape[o + 1] = val;
-            if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = i;
+            if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = q;
         }
-    } else if (k == K_STRING && p.sv.qm) {  // copy mode: the bytes are written by k_str_emit, only the tape words here
-        const u32 dl = p.dlen[i];
-        if (dl != DLEN_INVALID) emit_string(t, mv, i, true, dl & ~DLEN_COPY, p.tape, nullptr);
-    } else if (k == K_NL) {
-        if (i + 1 < p.n && p.kind[i + 1] != K_NL)
-            emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, p.match[i] + 1, p.tape, p.tape_base);
     }
-    if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape, p.tape_base);
     if (bad) atomicOr(&p.st->err, 1u);
 }
 
@@ -610,7 +662,7 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
         hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
     }
     hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_emit, dim3(gb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_emit, dim3((u32)((n + EMIT_BLOCK - 1) / EMIT_BLOCK)), dim3(EMIT_BLOCK), 0, stream, p);
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
