@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
 static constexpr int EMIT_BLOCK = 1024;
 __global__ __launch_bounds__(EMIT_BLOCK) void k_emit(S2Dev p) {
     __shared__ u32 s_num[EMIT_BLOCK];
+    __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
     __shared__ u32 s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -477,20 +478,37 @@ __global__ __launch_bounds__(EMIT_BLOCK) void k_emit(S2Dev p) {
         if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape, p.tape_base);
     }
     __syncthreads();
+    // the queued numbers, 256 at a time: the first 32 bytes of each go to LDS (two unaligned 16-byte loads instead
+    // of one dependent byte load per digit); longer numbers fall back to the message itself
     const u32 cnt = s_cnt;
-    for (u32 j = threadIdx.x; j < cnt; j += EMIT_BLOCK) {
-        const u32 q = s_num[j];
-        u64 tag = 0, val = 0;
-        u32 numlen = 0;
-        const u32 at = p.pos[q];
-        const int st = parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
-        if (st == NUM_FAIL) {
-            bad = true;
-        } else {
-            const u32 o = p.tape_off[q];
-            p.tape[o] = tag;
-            p.tape[o + 1] = val;
-            if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = q;
+    for (u32 j0 = 0; j0 < cnt; j0 += 256) {
+        const u32 j = j0 + threadIdx.x;
+        if (threadIdx.x < 256 && j < cnt) {
+            const u32 q = s_num[j];
+            const u32 at = p.pos[q];
+            const u64 rest = p.len - at;
+            u32 *w = s_nb[threadIdx.x];
+            if (rest >= 32) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(p.msg + at), b = *reinterpret_cast<const uint4 *>(p.msg + at + 16);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+            } else {
+                u8 *wb = reinterpret_cast<u8 *>(w);
+                for (u32 k = 0; k < (u32)rest; k++) wb[k] = p.msg[at + k];
+            }
+            u64 tag = 0, val = 0;
+            u32 numlen = 0;
+            const u32 avail = rest < 32 ? (u32)rest : 32u;
+            int st = parse_number(reinterpret_cast<const u8 *>(w), avail, &tag, &val, &numlen);
+            if (numlen == 32 && rest > 32) st = parse_number(p.msg + at, (u32)rest, &tag, &val, &numlen);
+            if (st == NUM_FAIL) {
+                bad = true;
+            } else {
+                const u32 o = p.tape_off[q];
+                p.tape[o] = tag;
+                p.tape[o + 1] = val;
+                if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = q;
+            }
         }
     }
     if (bad) atomicOr(&p.st->err, 1u);
