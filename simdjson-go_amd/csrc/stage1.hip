@@ -250,14 +250,18 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 // k+1 are in flight (issued as soon as the chunk registers are dead).
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
-template <int BLOCK, int CH, bool NDJSON>
+template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 t, u32 t_next, bool has_next,
                                         int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit, const S1Aux &aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // interior unit: all 4096 bytes belong to the message (wave-uniform -> scalar unit)
     auto is_interior = [&](u64 unit) { return (unit != 0 || lead == 0) && (unit + 1) * 4096 <= end; };
+#if defined(SJ_S1_ROLL)
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int k = 0; k < CH; k++) {
         const u64 unit = (u64)t * UNITS + (u64)(k * WAVES + wave);  // wave-uniform
         const u64 unit_off = unit * 4096;
@@ -310,7 +314,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64);
             const u64 escaped = escaped_mask(c.bs, carry_in);
             quote_bits &= ~escaped;
-            starters = c.bs & ~escaped;
+            if (AUX) starters = c.bs & ~escaped;
         }
 
         // ---- in-string mask relative to the start of the wave unit
@@ -332,7 +336,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
-        if (aux.qm && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+        if (AUX && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.q[ci] = quote_bits;
@@ -445,7 +449,7 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
 // Persistent blocks draw tiles from a ticket counter: tiles are started in id order, so every
 // predecessor in the look-back chain is resident or finished (forward progress without any
 // dispatch-order assumption), and no block ever waits for the dispatcher.
-template <int BLOCK, int CH, int WPE, bool NDJSON>
+template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
-    phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0], aux);
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0], aux);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         u32 tk = 0;  // the ticket after t_nn: drawn now, it returns while phase A runs
         if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
         if (has_next)
-            phase_a<BLOCK, CH, NDJSON>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
                                        s_unit[us_n], aux);
         // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
         // waits for the other waves (the predecessors published their aggregates about a phase ago)
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end, aux.unit_h, len);
+                                       tile_end, AUX ? aux.unit_h : nullptr, len);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
         P0 = P1;
@@ -638,9 +642,16 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.st = a.st;
         aux.unit_h = a.unit_h;
     }
-#define S1_LAUNCH2(B, C, W, ND)                                                                                   \
-    hipLaunchKernelGGL((stage1_kernel<B, C, W, ND>), dim3(grid_for(stage1_kernel<B, C, W, ND>, B, tiles)), dim3(B), 0, \
-                       stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles, aux)
+#define S1_LAUNCH3(B, C, W, ND, AX)                                                                                  \
+    hipLaunchKernelGGL((stage1_kernel<B, C, W, ND, AX>), dim3(grid_for(stage1_kernel<B, C, W, ND, AX>, B, tiles)), dim3(B), \
+                       0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles, aux)
+#define S1_LAUNCH2(B, C, W, ND)           \
+    do {                                  \
+        if (aux_buf)                      \
+            S1_LAUNCH3(B, C, W, ND, true);  \
+        else                              \
+            S1_LAUNCH3(B, C, W, ND, false); \
+    } while (0)
 #define S1_LAUNCH(B, C, W)            \
     do {                              \
         if (nd)                       \
@@ -656,6 +667,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     else if (v.block == 512 && v.ch == 4) S1_LAUNCH(512, 4, 4);
     else S1_LAUNCH(512, 2, 4);
 #undef S1_LAUNCH2
+#undef S1_LAUNCH3
 #undef S1_LAUNCH
     return hipGetLastError();
 }
