@@ -175,14 +175,11 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     g_qm = g_q = g_st = nullptr;
     if (len == 0 || err || inq || n == 0 || !(msg[len - 1] == '}' || msg[len - 1] == ']')) return 1;
     const MsgView mv{msg, len};
-    // stage 2
-    std::vector<u8> kind(n), ctxb(n, 0);
-    std::vector<i32> depth(n);
-    std::vector<u32> toff(n), soff(n), lastbr(n), match(n, 0), dlen(n, 0), nlb;
-    std::vector<u8> needcopy(n, 0);
+    // stage 2: the kernels of stage2.hip as loops, in launch order
+    static constexpr GrammarLut GLUT = make_grammar_lut();
+    static constexpr KindLut KLUT = make_kind_lut();
     u32 bad = 0;
-    for (size_t i = 0; i < n; i++) kind[i] = token_kind(msg[pos[i]], ndjson);
-    // byte-parallel string path (copy mode): the "kernels" k_str_masks / k_str_scan of stage2.hip as loops
+    // k_str_masks / k_str_scan (every string copied)
     const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data()};
     const size_t used_units = (len + 4095) / 4096;
     u64 masks_total = 0;
@@ -198,46 +195,92 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             v_ucnt[u] = (u32)masks_total;
             masks_total += run;
         }
-        for (size_t i = 0; i < n; i++)
-            if (kind[i] == K_STRING) {
-                const u64 a0 = (u64)pos[i] + 1, a1 = i + 1 < n ? pos[i + 1] : len;
-                dlen[i] = (u32)(emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a1) -
-                                emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a0));
-                needcopy[i] = 1;
-            }
     }
-    for (size_t i = 0; i < n && !copy; i++)
-        if (kind[i] == K_STRING) {
-            u32 sl, dl;
-            if (!string_walk(mv, pos[i], nullptr, &sl, &dl)) bad = 1;
-            else {
-                dlen[i] = dl;
-                needcopy[i] = copy || sl != dl;
-            }
-        }
-    i32 d = 0;
-    u32 words = 1, sbytes = 0, lb = 0;
+    // k_s2_reduce: kinds, string lengths (selective copy), elements
+    std::vector<u8> kind(n);
+    std::vector<u32> dlen(n, 0), copied(n, 0);
+    std::vector<u8> needcopy(n, 0), strbad(n, 0);
     for (size_t i = 0; i < n; i++) {
-        d += depth_delta(kind[i]);
-        depth[i] = d;
-        toff[i] = words;
-        words += tape_words(kind[i], i + 1 < n ? kind[i + 1] : (u8)K_BAD, i + 1 == n);
-        soff[i] = sbytes;
-        if (kind[i] == K_STRING && needcopy[i]) sbytes += dlen[i];
-        if (is_bracket(kind[i])) lb = (u32)i + 1;
-        lastbr[i] = lb;
-        if (kind[i] == K_NL && i + 1 < n && kind[i + 1] != K_NL) nlb.push_back((u32)i);
-    }
-    const u32 tlen = words + 1;  // + final root
-    if (d != 0) bad = 1;
-    // compact bracket view + min tree over it
-    std::vector<u32> br_tok;
-    std::vector<i32> br_depth;
-    for (size_t i = 0; i < n; i++)
-        if (is_bracket(kind[i])) {
-            br_tok.push_back((u32)i);
-            br_depth.push_back(depth[i]);
+        u8 k = KLUT.v[msg[pos[i]]];
+        if (k == K_NL && !ndjson) k = K_BAD;
+        kind[i] = k;
+        if (k != token_kind(msg[pos[i]], ndjson)) return 99;  // the table must agree with the switch
+        if (!copy && k == K_STRING) {
+            u32 sl, dl;
+            if (!string_walk(mv, pos[i], nullptr, &sl, &dl)) {
+                bad = 1;
+                strbad[i] = 1;
+            } else {
+                dlen[i] = dl;
+                needcopy[i] = sl != dl;
+                copied[i] = needcopy[i] ? dl : 0u;
+            }
         }
+    }
+    auto kind_at = [&](size_t i, long d) -> u8 {
+        const long j = (long)i + d;
+        return (j < 0 || j >= (long)n) ? (u8)K_BAD : kind[(size_t)j];
+    };
+    // k_s2_scan_tiles + k_s2_emit: the scan as a sequential sum
+    std::vector<i32> br_depth;
+    std::vector<u32> br_off, nl_off;
+    std::vector<u8> br_info;
+    std::vector<u32> toff(n), soff(n, 0);
+    Agg run = agg_identity();
+    u64 words = 0, sbytes = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Agg e = token_element(GLUT.v, (u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), copied[i]);
+        // the table must agree with the rule it was generated from
+        for (u8 G = 0; G < 3; G++)
+            if (context_allowed(e.am & AM_ALL, G) == grammar_violation_v((u32)i, kind[i], kind_at(i, -1), kind_at(i, -2), G)) return 98;
+        toff[i] = run.w + 1u;
+        soff[i] = run.s;
+        if ((e.am & AM_ALL) == 0) bad = 1;
+        if (is_bracket(kind[i])) {
+            br_depth.push_back(run.d + e.d);
+            br_off.push_back(toff[i]);
+            br_info.push_back((u8)(kind[i] | (gap_mask(run, e) << 4)));
+        }
+        if (e.nb) nl_off.push_back(toff[i]);
+        words += e.w;
+        sbytes += e.s;
+        run = agg_combine(run, e);
+    }
+    if (copy) sbytes = masks_total;
+    const u32 tlen = (u32)words + 2;  // + opening and closing root
+    if (run.d != 0) bad = 1;
+    const u32 tail_mask = is_bracket(kind[n - 1]) ? AM_ALL : (run.am & AM_ALL);
+    u64 *tape = (u64 *)calloc(tlen + 2, sizeof(u64));
+    u8 *strs = (u8 *)malloc(sbytes + 64);
+    for (size_t i = 0; i < n; i++) {
+        const u8 k = kind[i];
+        if (k == K_TRUE || k == K_FALSE || k == K_NULL) {
+            tape[toff[i]] = atom_word(k);
+            if (!atom_valid(mv, pos[i], k)) bad = 1;
+        } else if (k == K_STRING && copy) {
+            const u64 a0 = (u64)pos[i] + 1, a1 = i + 1 < n ? pos[i + 1] : len;
+            const u64 so = emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a0);
+            const u64 se = emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a1);
+            tape[toff[i]] = string_word(true, strings_base + so, 0);
+            tape[toff[i] + 1] = se - so;
+        } else if (k == K_STRING && !strbad[i]) {
+            tape[toff[i]] = string_word(needcopy[i], strings_base + soff[i], msg_base + pos[i] + 1);
+            tape[toff[i] + 1] = dlen[i];
+            if (needcopy[i]) {  // k_emit_strings
+                u32 sl, dl;
+                string_walk(mv, pos[i], strs + soff[i], &sl, &dl);
+            }
+        } else if (k == K_NUM) {
+            u64 tag, val;
+            int ub;
+            if (!sj_selftest_parse_number(msg + pos[i], len - pos[i], &tag, &val, &ub)) bad = 1;
+            else {
+                tape[toff[i]] = tag;
+                tape[toff[i] + 1] = val;
+            }
+        }
+    }
+    // k_min_level + k_brackets: min tree over the compact bracket view, partners, contexts, gap check
     MinTree mt;
     std::vector<std::vector<i32>> levels;
     mt.lev[0] = br_depth.data();
@@ -255,33 +298,19 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         mt.size[mt.nlev] = ns;
         mt.nlev++;
     }
-    for (size_t c = 0; c < br_tok.size(); c++)
-        if (is_close(kind[br_tok[c]])) bracket_resolve_compact(mt, br_tok.data(), kind.data(), (u32)c, match.data(), ctxb.data());
-    Tokens t{pos.data(), (u32)n, kind.data(), depth.data(), toff.data(), soff.data(), lastbr.data(), match.data(), ctxb.data()};
-    t.tape_base = tape_base;
-    t.strings_base = strings_base;
-    t.msg_base = msg_base;
-    u64 *tape = (u64 *)malloc(sizeof(u64) * (tlen + 2));
-    u8 *strs = (u8 *)malloc(sbytes + 64);
-    for (size_t i = 0; i < n; i++) {
-        if (grammar_violation(t, (u32)i)) bad = 1;
-        if (emit_simple(t, mv, (u32)i, tape)) bad = 1;
-        if (kind[i] == K_STRING && !bad) emit_string(t, mv, (u32)i, needcopy[i], dlen[i], tape, copy ? nullptr : strs);
-        if (kind[i] == K_NUM) {
-            u64 tag, val;
-            int ub;
-            if (!sj_selftest_parse_number(msg + pos[i], len - pos[i], &tag, &val, &ub)) bad = 1;
-            else {
-                tape[toff[i]] = tag;
-                tape[toff[i] + 1] = val;
-            }
-        }
+    const u32 n_br = (u32)br_off.size();
+    for (u32 c = 0; c < n_br; c++) {
+        const u8 ctx = bracket_resolve(mt, br_off.data(), br_info.data(), c, tape_base, tape);
+        const u32 next = c + 1 < n_br ? (u32)(br_info[c + 1] >> 4) : tail_mask;
+        if (!context_allowed(next, ctx)) bad = 1;
+        if (c == 0 && !context_allowed((u32)(br_info[0] >> 4), CTX_ROOT)) bad = 1;
     }
+    if (n_br == 0) bad = 1;  // unreachable: token 0 must be an open bracket
     if (copy && !bad)  // k_str_emit
         for (size_t c = 0; c < used_units * 64; c++)
             str_chunk_emit(sv, c, v_em[c], v_um[c], c ? v_um[c - 1] : 0ull, strs + v_ucnt[c >> 6] + v_pre[c],
                            [&](u32 p) { return sv.at(c * 64 + p); });
-    for (u32 r = 0; r <= nlb.size(); r++) emit_root(nlb.data(), (u32)nlb.size(), toff.data(), tlen, r, tape, tape_base);
+    for (u32 r = 0; r <= nl_off.size(); r++) emit_root(nl_off.data(), (u32)nl_off.size(), tlen, r, tape, tape_base);  // k_roots
     if (bad) {
         free(tape);
         free(strs);

@@ -15,8 +15,10 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define SJ_HD __host__ __device__ __forceinline__
+#define SJ_HDC __host__ __device__ __forceinline__ constexpr
 #else
 #define SJ_HD inline
+#define SJ_HDC inline constexpr
 #endif
 
 namespace sj {

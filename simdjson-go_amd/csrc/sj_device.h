@@ -26,7 +26,7 @@ struct S2State {
     unsigned long long tape_len;
     unsigned long long strings_len;
     uint32_t n_br;           // number of bracket tokens (size of the compact bracket view)
-    uint32_t pad0;
+    uint32_t tail_mask;      // allowed contexts of the gap behind the last bracket (sj_stage2.h)
     unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
     uint32_t pad[4];
 };

@@ -44,7 +44,7 @@ enum Ctx : u8 { CTX_ROOT = 0, CTX_OBJ = 1, CTX_ARR = 2 };
 
 static constexpr u64 STRINGBUFBIT = 0x0080000000000000ull;  // parsed_json.go:29
 
-SJ_HD u8 token_kind(u8 c, bool ndjson) {
+SJ_HDC u8 token_kind(u8 c, bool ndjson) {
     switch (c) {
     case '{': return K_OPEN_OBJ;
     case '[': return K_OPEN_ARR;
@@ -61,10 +61,10 @@ SJ_HD u8 token_kind(u8 c, bool ndjson) {
     default: return (c >= '0' && c <= '9') ? K_NUM : K_BAD;
     }
 }
-SJ_HD bool is_open(u8 k) { return k == K_OPEN_OBJ || k == K_OPEN_ARR; }
-SJ_HD bool is_close(u8 k) { return k == K_CLOSE_OBJ || k == K_CLOSE_ARR; }
-SJ_HD bool is_bracket(u8 k) { return k >= K_OPEN_OBJ && k <= K_CLOSE_ARR; }
-SJ_HD i32 depth_delta(u8 k) { return is_open(k) ? 1 : (is_close(k) ? -1 : 0); }
+SJ_HDC bool is_open(u8 k) { return k == K_OPEN_OBJ || k == K_OPEN_ARR; }
+SJ_HDC bool is_close(u8 k) { return k == K_CLOSE_OBJ || k == K_CLOSE_ARR; }
+SJ_HDC bool is_bracket(u8 k) { return k >= K_OPEN_OBJ && k <= K_CLOSE_ARR; }
+SJ_HDC i32 depth_delta(u8 k) { return is_open(k) ? 1 : (is_close(k) ? -1 : 0); }
 
 // number of tape words a token writes (stage2_build_tape_amd64.go: write_tape call sites).
 // A newline token writes the "close root / open root" pair (:213-218) iff it is the last one of
@@ -305,91 +305,22 @@ found:
     return k;
 }
 
-// ---- per-token views -----------------------------------------------------------------------------
-struct Tokens {
-    const u32 *pos;   // structural byte positions (stage 1 output)
-    u32 n;
-    const u8 *kind;
-    const i32 *depth;     // depth AFTER the token
-    const u32 *tape_off;  // tape index of the token's first word
-    const u32 *str_off;   // Strings.B offset for copied strings
-    const u32 *last_br;   // 1 + index of the last bracket token <= i (0: none)
-    const u32 *match;     // brackets: index of the partner
-    const u8 *ctxb;       // close brackets: context after the close
-    // NDJSON shards: where this shard's tape / Strings.B / Message window start inside the merged
-    // ParsedJson (all zero for an unsharded parse).  Every index the tape stores is rebased by these.
-    u64 tape_base = 0, strings_base = 0, msg_base = 0;
-};
-
-// context of the gap in front of token i
-SJ_HD u8 gap_ctx(const Tokens &t, u32 i) {
-    if (i == 0) return CTX_ROOT;
-    const u32 b = t.last_br[i - 1];
-    if (b == 0) return CTX_ROOT;
-    const u8 k = t.kind[b - 1];
-    if (k == K_OPEN_OBJ) return CTX_OBJ;
-    if (k == K_OPEN_ARR) return CTX_ARR;
-    return t.ctxb[b - 1];
-}
-
-// bracket pass: for a close bracket find its partner and the context that resumes after it
-SJ_HD void bracket_resolve(const MinTree &mt, const u8 *kind, const i32 *depth, u32 i, u32 *match, u8 *ctxb) {
-    const i32 d = depth[i] + 1;  // depth before the close
-    if (d <= 0) {                 // closes nothing: the grammar check rejects it (context is ROOT)
-        match[i] = 0;
-        ctxb[i] = CTX_ROOT;
-        return;
-    }
-    const i64 j = psv(mt, (i64)i, d) + 1;  // the open bracket that raised the depth to d
-    match[i] = (u32)j;
-    match[j] = i;
-    u8 ctx = CTX_ROOT;
-    if (d - 1 > 0) {
-        const i64 p = psv(mt, j, d - 1) + 1;  // the enclosing container's open bracket
-        ctx = kind[p] == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
-    }
-    ctxb[i] = ctx;
-}
-
-// The same on the compact bracket view (br_tok[c] = token index of the c-th bracket, the tree is built over
-// br_depth[c] = depth after it): non-bracket tokens never change the depth, so the previous-smaller-value
-// queries give the same brackets, over an array that is ~10x shorter.
-SJ_HD void bracket_resolve_compact(const MinTree &mt, const u32 *br_tok, const u8 *kind, u32 c, u32 *match, u8 *ctxb) {
-    const u32 i = br_tok[c];
-    const i32 d = mt.lev[0][c] + 1;  // depth before the close
-    if (d <= 0) {                    // closes nothing: the grammar check rejects it (context is ROOT)
-        match[i] = 0;
-        ctxb[i] = CTX_ROOT;
-        return;
-    }
-    const i64 jc = psv(mt, (i64)c, d) + 1;  // the open bracket that raised the depth to d
-    const u32 j = br_tok[jc];
-    match[i] = j;
-    match[j] = i;
-    u8 ctx = CTX_ROOT;
-    if (d - 1 > 0) {
-        const i64 pc = psv(mt, jc, d - 1) + 1;  // the enclosing container's open bracket
-        ctx = kind[br_tok[pc]] == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
-    }
-    ctxb[i] = ctx;
-}
-
-// ---- grammar on values (the kernel preloads them; the pointer forms below feed the same functions) ----------
+// ---- grammar ------------------------------------------------------------------------------------------
 // a string token is an object key iff it sits in an object right after '{' or ','
-SJ_HD bool string_is_key_v(u8 ctx, bool has_prev, u8 prev_kind) {
+SJ_HDC bool string_is_key_v(u8 ctx, bool has_prev, u8 prev_kind) {
     return ctx == CTX_OBJ && has_prev && (prev_kind == K_OPEN_OBJ || prev_kind == K_COMMA);
 }
 // does a token of kind k (whose predecessor has kind prev_kind, if any) end a value of the container with context ctx?
-SJ_HD bool ends_value_v(u8 k, u8 ctx, bool has_prev, u8 prev_kind) {
+SJ_HDC bool ends_value_v(u8 k, u8 ctx, bool has_prev, u8 prev_kind) {
     if (k == K_CLOSE_OBJ || k == K_CLOSE_ARR || k == K_NUM || k == K_TRUE || k == K_FALSE || k == K_NULL) return true;
     if (k == K_STRING) return !string_is_key_v(ctx, has_prev, prev_kind);
     return false;
 }
 // Grammar check of token i (true = violation): k = its kind, pk / ppk = kinds of tokens i-1 / i-2 (if they
-// exist), G = context of the gap in front of it.  Mirrors the transitions of unifiedMachine:
-// continueRoot/startContinue (:176-221), object_begin/object_key_state/objectContinue (:225-325),
+// exist), G = context of the gap in front of it (the innermost open container).  Mirrors the transitions of
+// unifiedMachine: continueRoot/startContinue (:176-221), object_begin/object_key_state/objectContinue (:225-325),
 // arrayBegin/mainArraySwitch/arrayContinue (:346-426).
-SJ_HD bool grammar_violation_v(u32 i, u8 k, u8 pk, u8 ppk, u8 G) {
+SJ_HDC bool grammar_violation_v(u32 i, u8 k, u8 pk, u8 ppk, u8 G) {
     if (k == K_BAD) return true;
     if (i == 0) return !is_open(k);
     const bool has_pp = i > 1;
@@ -423,81 +354,120 @@ SJ_HD bool grammar_violation_v(u32 i, u8 k, u8 pk, u8 ppk, u8 G) {
         return true;
     }
 }
-// context from the last bracket in front of a token: b = its index + 1 (0: none), bk / bc = its kind / resume context
-SJ_HD u8 gap_ctx_v(u32 b, u8 bk, u8 bc) {
-    if (b == 0) return CTX_ROOT;
-    if (bk == K_OPEN_OBJ) return CTX_OBJ;
-    if (bk == K_OPEN_ARR) return CTX_ARR;
-    return bc;
+
+// The context G is only known once the brackets are matched, so the per-token pass evaluates the rule for all
+// three contexts at once: allowed_contexts = { G : token i is legal in context G } as a bit set (bit CTX_*).
+// The rule reads i only as "first token" / "has two predecessors" and ppk only as "the token before the
+// previous one makes a following string a key", which makes it a 1024-entry table:
+//   index = k | pk << 4 | key_prev << 8 | first << 9
+// All tokens between two brackets share one context, so the AND of their sets (a segmented scan, below) is
+// checked once per bracket against the context the bracket pass derives.
+SJ_HDC u32 grammar_lut_index(u32 i, u8 k, u8 pk, u8 ppk) {
+    const bool key_prev = i > 1 && (ppk == K_OPEN_OBJ || ppk == K_COMMA);
+    return (u32)k | ((u32)pk << 4) | (key_prev ? 256u : 0u) | (i == 0 ? 512u : 0u);
+}
+SJ_HDC u8 allowed_contexts_at(u32 index) {
+    const u8 k = (u8)(index & 15u), pk = (u8)((index >> 4) & 15u);
+    const bool key_prev = (index >> 8) & 1u, first = (index >> 9) & 1u;
+    const u32 i = first ? 0u : 2u;
+    const u8 ppk = key_prev ? (u8)K_COMMA : (u8)K_BAD;
+    u8 m = 0;
+    for (u8 G = 0; G < 3; G++)
+        if (!grammar_violation_v(i, k, pk, ppk, G)) m = (u8)(m | (1u << G));
+    return m;
+}
+struct GrammarLut {
+    u8 v[1024];
+};
+constexpr GrammarLut make_grammar_lut() {
+    GrammarLut t{};
+    for (u32 x = 0; x < 1024; x++) t.v[x] = allowed_contexts_at(x);
+    return t;
+}
+struct KindLut {
+    u8 v[256];  // token_kind(byte, ndjson = true); '\n' is demoted to K_BAD by the caller for plain JSON
+};
+constexpr KindLut make_kind_lut() {
+    KindLut t{};
+    for (u32 c = 0; c < 256; c++) t.v[c] = token_kind((u8)c, true);
+    return t;
 }
 
-SJ_HD bool string_is_key(const Tokens &t, u32 j, u8 ctx) { return string_is_key_v(ctx, j > 0, j > 0 ? t.kind[j - 1] : (u8)K_BAD); }
-SJ_HD bool grammar_violation(const Tokens &t, u32 i) {
-    return grammar_violation_v(i, t.kind[i], i > 0 ? t.kind[i - 1] : (u8)K_BAD, i > 1 ? t.kind[i - 2] : (u8)K_BAD,
-                               gap_ctx(t, i));
+// ---- the device-wide scan ---------------------------------------------------------------------------------
+// One element per token; the inclusive/exclusive prefixes give every token its depth, tape offset, Strings.B
+// offset (only when strings are copied selectively), record ordinal, compact bracket index, and the AND of the
+// allowed-context sets since the last bracket (am: bits 0-2 the set, bit 3 "a segment starts inside").
+struct Agg {
+    i32 d;
+    u32 w, s, nb, bc, am;
+};
+static constexpr u32 AM_ALL = 7u, AM_START = 8u;
+SJ_HD Agg agg_identity() { return Agg{0, 0u, 0u, 0u, 0u, AM_ALL}; }
+SJ_HD u32 am_combine(u32 a, u32 b) { return (b & AM_START) ? b : ((a & b & AM_ALL) | (a & AM_START)); }
+SJ_HD Agg agg_combine(const Agg &a, const Agg &b) {  // a in front of b
+    return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.nb + b.nb, a.bc + b.bc, am_combine(a.am, b.am)};
 }
-
-// ---- tape emission ---------------------------------------------------------------------------------
-// brackets and atoms (write_tape call sites of unifiedMachine).  Returns true on a violation.
-SJ_HD bool emit_simple(const Tokens &t, const MsgView &m, u32 i, u64 *tape) {
-    const u8 k = t.kind[i];
-    const u32 o = t.tape_off[i];
-    switch (k) {
-    case K_OPEN_OBJ:
-    case K_OPEN_ARR: {  // payload: tape index just after the matching close (annotate_previousloc, :336)
-        const u32 c = t.match[i];
-        const u64 after = (c < t.n) ? t.tape_base + t.tape_off[c] + 1 : 0;
-        tape[o] = ((u64)(k == K_OPEN_OBJ ? '{' : '[') << 56) | after;
-        return false;
-    }
-    case K_CLOSE_OBJ:
-    case K_CLOSE_ARR: {  // payload: tape index of the matching open (:335)
-        const u32 op = t.match[i];
-        tape[o] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (op < t.n ? t.tape_base + t.tape_off[op] : 0);
-        return false;
-    }
-    case K_TRUE:
-    case K_FALSE:
-    case K_NULL: {
-        tape[o] = (u64)(k == K_TRUE ? 't' : (k == K_FALSE ? 'f' : 'n')) << 56;
-        return !atom_valid(m, t.pos[i], k);
-    }
-    default: return false;
-    }
+// element of token i of n.  k / pk / ppk / nk: kinds of tokens i, i-1, i-2, i+1 (K_BAD where there is none);
+// copied: bytes the token appends to Strings.B through the scan (0 when the emit masks place the strings)
+SJ_HD Agg token_element(const u8 *glut, u32 i, u32 n, u8 k, u8 pk, u8 ppk, u8 nk, u32 copied) {
+    const bool last = i + 1 == n;
+    Agg a;
+    a.d = depth_delta(k);
+    a.w = tape_words(k, nk, last);
+    a.s = copied;
+    a.nb = (k == K_NL && !last && nk != K_NL) ? 1u : 0u;
+    a.bc = is_bracket(k) ? 1u : 0u;
+    a.am = (u32)glut[grammar_lut_index(i, k, pk, ppk)] | ((i > 0 && is_bracket(pk)) ? AM_START : 0u);  // a gap starts after a bracket
+    return a;
 }
+// allowed contexts of the gap that ends with token i (x = exclusive prefix, e = its element)
+SJ_HD u32 gap_mask(const Agg &x, const Agg &e) { return am_combine(x.am, e.am) & AM_ALL; }
 
-// strings (parseString, stage2_build_tape_amd64.go:72-113).  need_copy = copyStrings || src_len != dst_len
-// (parse_string_amd64.go:40).
-SJ_HD void emit_string(const Tokens &t, const MsgView &m, u32 i, bool need_copy, u32 dst_len, u64 *tape, u8 *strings) {
-    const u32 o = t.tape_off[i];
-    const u64 q = t.pos[i];
-    if (!need_copy) {
-        tape[o] = ((u64)'"' << 56) | (t.msg_base + q + 1);
-    } else {
-        if (strings) {  // nullptr: Strings.B is written by the byte-parallel path (sj_strings.h)
-            u32 sl, dl;
-            string_walk(m, q, strings + t.str_off[i], &sl, &dl);
-        }
-        tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + t.strings_base + t.str_off[i]);
-    }
-    tape[o + 1] = dst_len;
+// ---- brackets: partners and contexts over the compact bracket view ----------------------------------------------
+// The c-th bracket token has depth br_depth[c] after it (level 0 of the min tree), its tape word at br_off[c]
+// and br_info[c] = kind | gap_mask << 4 (the gap that ends with it).  Non-bracket tokens never change the
+// depth, so previous-smaller-value queries over the compact view find the same brackets as over all tokens.
+// Returns the context AFTER bracket c; a close bracket also writes both tape words of its pair
+// (payloads: annotate_previousloc, stage2_build_tape_amd64.go:335-336).
+SJ_HD u8 bracket_resolve(const MinTree &mt, const u32 *br_off, const u8 *br_info, u32 c, u64 tape_base, u64 *tape) {
+    const u8 k = br_info[c] & 15u;
+    if (k == K_OPEN_OBJ) return CTX_OBJ;
+    if (k == K_OPEN_ARR) return CTX_ARR;
+    const i32 d = mt.lev[0][c] + 1;  // depth before the close
+    if (d <= 0) return CTX_ROOT;     // closes nothing: its gap mask rejects it (a close needs OBJ / ARR)
+    const i64 jc = psv(mt, (i64)c, d) + 1;  // the open bracket that raised the depth to d
+    const u8 jk = br_info[jc] & 15u;
+    tape[br_off[c]] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (tape_base + br_off[jc]);
+    tape[br_off[jc]] = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (tape_base + br_off[c] + 1);
+    if (d - 1 <= 0) return CTX_ROOT;
+    const i64 pc = psv(mt, jc, d - 1) + 1;  // the enclosing container's open bracket
+    return (br_info[pc] & 15u) == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
 }
+SJ_HD bool context_allowed(u32 mask, u8 ctx) { return (mask >> ctx) & 1u; }
 
-// root words: tape[0], tape[tape_len-1] and the close/open pair written by every record-separating
-// newline run (startContinue, :196-221; succeed, :428-442).  nlb[r] = token index of the r-th such
-// newline; R = number of them.
-SJ_HD void emit_root(const u32 *nlb, u32 R, const u32 *tape_off, u32 tape_len, u32 r_plus1, u64 *tape, u64 tape_base = 0) {
+// ---- root words -------------------------------------------------------------------------------------------
+// tape[0], tape[tape_len-1] and the close/open pair written by every record-separating newline run
+// (startContinue, :196-221; succeed, :428-442).  nl_off[r] = tape offset of the r-th such newline's pair;
+// R = number of them; B rebases the stored indexes (NDJSON shard).
+SJ_HD void emit_root(const u32 *nl_off, u32 R, u32 tape_len, u32 r_plus1, u64 *tape, u64 B) {
     const u64 ROOT = (u64)'r' << 56;
-    const u64 B = tape_base;
     if (r_plus1 == 0) {  // first and last word
-        tape[0] = ROOT | (B + (R == 0 ? tape_len : tape_off[nlb[0]] + 1));
-        tape[tape_len - 1] = ROOT | (B + (R == 0 ? 0u : tape_off[nlb[R - 1]] + 1));
+        tape[0] = ROOT | (B + (R == 0 ? tape_len : nl_off[0] + 1));
+        tape[tape_len - 1] = ROOT | (B + (R == 0 ? 0u : nl_off[R - 1] + 1));
         return;
     }
     const u32 r = r_plus1 - 1;
-    const u32 o = tape_off[nlb[r]];
-    tape[o] = ROOT | (B + (r == 0 ? 0u : tape_off[nlb[r - 1]] + 1));                 // close root of record r
-    tape[o + 1] = ROOT | (B + (r + 1 == R ? tape_len : tape_off[nlb[r + 1]] + 1));  // open root of record r+1
+    const u32 o = nl_off[r];
+    tape[o] = ROOT | (B + (r == 0 ? 0u : nl_off[r - 1] + 1));                 // close root of record r
+    tape[o + 1] = ROOT | (B + (r + 1 == R ? tape_len : nl_off[r + 1] + 1));  // open root of record r+1
+}
+
+// ---- atoms and strings: tape words ---------------------------------------------------------------------------
+SJ_HD u64 atom_word(u8 k) { return (u64)(k == K_TRUE ? 't' : (k == K_FALSE ? 'f' : 'n')) << 56; }
+// parseString (stage2_build_tape_amd64.go:72-113): a copied string points into Strings.B (bit 55 set), the
+// others into the message
+SJ_HD u64 string_word(bool copied, u64 strings_off, u64 msg_off) {
+    return ((u64)'"' << 56) | (copied ? STRINGBUFBIT + strings_off : msg_off);
 }
 
 }  // namespace sj

@@ -1,9 +1,21 @@
 // stage2.hip -- stage 2 (tape build, string unescape, number parse) as follow-on kernels over the
 // structural-index array produced by stage 1.  Replaces unifiedMachine
 // (stage2_build_tape_amd64.go:160-446), parseString (:72-113), parse_string_amd64.s and
-// parseNumber (parse_number.go:65-135).  The per-token logic lives in sj_stage2.h / sj_number.h /
-// sj_bignum.h (host+device, replayed on the CPU by the test-suite); this file holds the kernels,
-// the device-wide scans and the launcher.  No host synchronisation happens between the kernels.
+// parseNumber (parse_number.go:65-135).  The per-token logic lives in sj_stage2.h / sj_strings.h /
+// sj_number.h / sj_bignum.h (host+device, replayed on the CPU by the test-suite); this file holds the
+// kernels, the device-wide scan and the launcher.  No host synchronisation happens between the kernels.
+//
+// Passes over the tokens (one token = one structural index):
+//   k_s2_reduce      kind of every token (1 byte, kept), scan element per token, one aggregate per 4096-token tile
+//   k_s2_scan_tiles  exclusive scan of the tile aggregates (one block) + totals: tape length, records, brackets
+//   k_s2_emit        rebuilds the elements, scans inside the tile, and writes every tape word that does not depend
+//                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
+//                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
+//                    separate records leave their tape offset
+//   k_min_level*, k_brackets   previous-smaller-value over the compact bracket view: partners' tape words,
+//                    container contexts, and the grammar check of every gap against its context
+//   k_roots          root words
+// plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -16,11 +28,20 @@
 
 namespace sj {
 
-static constexpr int S2_BLOCK = 256;
+static constexpr int S2_BLOCK = 1024;
 static constexpr int S2_ITEMS = 4;
 static constexpr int S2_TILE = S2_BLOCK * S2_ITEMS;
+static constexpr int S2_WAVES = S2_BLOCK / 64;
 static constexpr u32 DLEN_INVALID = 0xffffffffu;
 static constexpr u32 DLEN_COPY = 0x80000000u;
+
+__constant__ GrammarLut c_glut = make_grammar_lut();
+__constant__ KindLut c_klut = make_kind_lut();
+
+struct alignas(32) TileAgg {
+    Agg a;
+    u32 pad[2];
+};
 
 // device view of all stage-2 arrays (carved out of one workspace by the launcher)
 struct S2Dev {
@@ -30,20 +51,14 @@ struct S2Dev {
     u32 n;
     u32 ndjson, copy_strings;
     u8 *kind;      // [n]
-    u32 *dlen;     // [n] strings: unescaped length | DLEN_COPY, or DLEN_INVALID
-    i32 *depth;    // [n]
-    u32 *tape_off; // [n]
-    u32 *str_off;  // [n]
-    u32 *last_br;  // [n]
-    u32 *match;    // [n] brackets: partner; record-separating newline: its ordinal
-    u8 *ctxb;      // [n]
-    u32 *nlb;      // [n] token indexes of record-separating newlines
-    u32 *bigq;     // [n] queue of number tokens that need the big-integer tie-break
-    u32 *br_tok;   // [n] compact bracket view: token index of the c-th bracket
-    i32 *br_depth; // [n]                       depth after it (level 0 of the min tree)
-    // tile aggregates / exclusive prefixes
-    i32 *agg_d;
-    u32 *agg_w, *agg_s, *agg_lb, *agg_nb, *agg_bc;
+    u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
+    u32 *str_off;  // [n] selective copy only: Strings.B offset of a copied string
+    u32 *nl_off;   // [n] tape offset of the r-th record-separating newline
+    u32 *bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
+    i32 *br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
+    u32 *br_off;   // [n]                       its tape offset
+    u8 *br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
+    TileAgg *agg;  // [tiles] aggregates, then (k_s2_scan_tiles) exclusive prefixes
     u32 tiles;
     // min tree levels 1.. (level 0 is br_depth[])
     i32 *lev[MinTree::MAXLEV];
@@ -61,33 +76,6 @@ struct S2Dev {
     u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
     u64 units;
 };
-
-struct Agg {
-    i32 d;
-    u32 w, s, lb, nb, bc;
-};
-__device__ __forceinline__ Agg agg_combine(const Agg &a, const Agg &b) {
-    return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.lb > b.lb ? a.lb : b.lb, a.nb + b.nb, a.bc + b.bc};
-}
-__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
-    return Agg{__shfl_up(a.d, delta, 64), __shfl_up(a.w, delta, 64), __shfl_up(a.s, delta, 64), __shfl_up(a.lb, delta, 64),
-               __shfl_up(a.nb, delta, 64), __shfl_up(a.bc, delta, 64)};
-}
-
-__device__ __forceinline__ Agg token_agg(const S2Dev &p, u32 i) {
-    const u8 k = p.kind[i];
-    const bool last = i + 1 == p.n;
-    const u8 nk = last ? (u8)K_BAD : p.kind[i + 1];
-    Agg a;
-    a.d = depth_delta(k);
-    a.w = tape_words(k, nk, last);
-    const u32 dl = p.dlen[i];
-    a.s = (k == K_STRING && dl != DLEN_INVALID && (dl & DLEN_COPY)) ? (dl & ~DLEN_COPY) : 0u;
-    a.lb = is_bracket(k) ? i + 1 : 0u;
-    a.nb = (k == K_NL && !last && nk != K_NL) ? 1u : 0u;
-    a.bc = is_bracket(k) ? 1u : 0u;
-    return a;
-}
 
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
 __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
@@ -199,102 +187,148 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     if (tail < total) dst[tail] = s_out[wave][tail];
 }
 
-// ---- kernel 1: token kinds + string lengths (parseStringSimdValidateOnly) ---------------------------------
-__global__ __launch_bounds__(256) void k_string_measure(S2Dev p) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
-    const u8 kind = token_kind(p.msg[p.pos[i]], p.ndjson != 0);
-    p.kind[i] = kind;
-    u32 out = 0;
-    if (kind == K_STRING && p.sv.qm) {  // every string is copied: offset and length come from the emit masks
-        const u64 a0 = (u64)p.pos[i] + p.sv.lead + 1;
-        const u64 a1 = (i + 1 < p.n ? (u64)p.pos[i + 1] : p.len) + p.sv.lead;
-        out = (u32)(emitted_before(p.unit_cnt, p.chunk_pre, p.em, a1) - emitted_before(p.unit_cnt, p.chunk_pre, p.em, a0)) |
-              DLEN_COPY;
-    } else if (kind == K_STRING) {
-        const MsgView mv{p.msg, p.len};
-        u32 sl, dl;
-        if (!string_walk(mv, p.pos[i], nullptr, &sl, &dl)) {
-            out = DLEN_INVALID;
-            atomicOr(&p.st->err, 1u);
-        } else {
-            out = dl | ((p.copy_strings || sl != dl) ? DLEN_COPY : 0u);
-        }
-    }
-    p.dlen[i] = out;
+// ---- the token scan ----------------------------------------------------------------------------------------
+__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
+    return Agg{__shfl_up(a.d, delta, 64),          (u32)__shfl_up((int)a.w, delta, 64),  (u32)__shfl_up((int)a.s, delta, 64),
+               (u32)__shfl_up((int)a.nb, delta, 64), (u32)__shfl_up((int)a.bc, delta, 64), (u32)__shfl_up((int)a.am, delta, 64)};
 }
-
-// ---- kernels 3-5: device-wide scan of (depth, tape words, string bytes, last bracket, newline runs) -----
-__device__ __forceinline__ Agg block_reduce(Agg v, Agg *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ Agg wave_inclusive(Agg v, int lane) {
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
         const Agg o = agg_shfl_up(v, s);
         if (lane >= s) v = agg_combine(o, v);
     }
-    if (lane == 63) lds[wave] = v;
-    __syncthreads();
-    Agg tot = lds[0];
-    for (int w = 1; w < S2_BLOCK / 64; w++) tot = agg_combine(tot, lds[w]);
-    return tot;
+    return v;
 }
 
-__global__ __launch_bounds__(S2_BLOCK) void k_scan_reduce(S2Dev p) {
-    __shared__ Agg lds[S2_BLOCK / 64];
-    const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
-    Agg v{0, 0, 0, 0, 0, 0};
+// LDS image of a tile's kinds: s_kind[4 + j] = kind of token t0 + j (K_BAD beyond the end), [2] [3] the two
+// tokens in front of the tile, [4 + S2_TILE] the one behind it
+static constexpr int KIND_LDS = S2_TILE + 8;
+
+__device__ __forceinline__ void tile_elements(const u8 *s_glut, const u8 *s_kind, u32 n, u32 base, int j0,
+                                              const u32 (&copied)[S2_ITEMS], Agg (&e)[S2_ITEMS]) {
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++)
-        if (base + k < p.n) v = agg_combine(v, token_agg(p, base + k));
-    const Agg tot = block_reduce(v, lds);
-    if (threadIdx.x == 0) {
-        p.agg_d[blockIdx.x] = tot.d;
-        p.agg_w[blockIdx.x] = tot.w;
-        p.agg_s[blockIdx.x] = tot.s;
-        p.agg_lb[blockIdx.x] = tot.lb;
-        p.agg_nb[blockIdx.x] = tot.nb;
-        p.agg_bc[blockIdx.x] = tot.bc;
+    for (int k = 0; k < S2_ITEMS; k++) {
+        const u32 i = base + k;
+        const int j = 4 + j0 + k;
+        e[k] = i < n ? token_element(s_glut, i, n, s_kind[j], s_kind[j - 1], s_kind[j - 2], s_kind[j + 1], copied[k])
+                     : agg_identity();
     }
 }
 
-// one block: exclusive scan over the tile aggregates (in place) + totals
-__global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
+// ---- pass 1: token kinds + tile aggregates ---------------------------------------------------------------------
+__global__ __launch_bounds__(S2_BLOCK) void k_s2_reduce(S2Dev p) {
+    __shared__ u8 s_glut[1024];
+    __shared__ u8 s_klut[256];
+    __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
+    __shared__ Agg s_w[S2_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_glut[tid] = c_glut.v[tid];
+    if (tid < 256) s_klut[tid] = c_klut.v[tid];
+    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
+    u32 ps[S2_ITEMS] = {0, 0, 0, 0};
+    if (base + 3 < p.n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p.pos + base);
+        ps[0] = v.x; ps[1] = v.y; ps[2] = v.z; ps[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++)
+            if (base + k < p.n) ps[k] = p.pos[base + k];
+    }
+    u8 b[S2_ITEMS];
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) b[k] = base + k < p.n ? p.msg[ps[k]] : (u8)0;
+    // the neighbours of the tile: two tokens in front, one behind
+    u8 hb = 0;
+    bool hv = false;
+    if (tid < 2 && t0 + (u32)tid >= 2u) {
+        hb = p.msg[p.pos[t0 + (u32)tid - 2u]];
+        hv = true;
+    } else if (tid == 2 && (u64)t0 + S2_TILE < p.n) {
+        hb = p.msg[p.pos[t0 + S2_TILE]];
+        hv = true;
+    }
+    __syncthreads();
+    auto kind_of = [&](u8 c) {
+        const u8 k = s_klut[c];
+        return (k == K_NL && !p.ndjson) ? (u8)K_BAD : k;
+    };
+    u8 kd[S2_ITEMS];
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) kd[k] = base + k < p.n ? kind_of(b[k]) : (u8)K_BAD;
+    const u32 packed = (u32)kd[0] | ((u32)kd[1] << 8) | ((u32)kd[2] << 16) | ((u32)kd[3] << 24);
+    *reinterpret_cast<u32 *>(&s_kind[4 + tid * S2_ITEMS]) = packed;
+    if (base + 3 < p.n) {
+        *reinterpret_cast<u32 *>(p.kind + base) = packed;
+    } else {
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++)
+            if (base + k < p.n) p.kind[base + k] = kd[k];
+    }
+    if (tid < 2) s_kind[2 + tid] = hv ? kind_of(hb) : (u8)K_BAD;
+    if (tid == 2) s_kind[4 + S2_TILE] = hv ? kind_of(hb) : (u8)K_BAD;
+    // selective copy (WithCopyStrings(false)): a string goes to Strings.B only if unescaping changes it, so every
+    // string is measured here (parseStringSimdValidateOnly); with copy_strings the emit masks give the lengths
+    u32 copied[S2_ITEMS] = {0, 0, 0, 0};
+    if (!p.sv.qm) {
+        const MsgView mv{p.msg, p.len};
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++) {
+            if (kd[k] != K_STRING) continue;
+            u32 sl, dl, out;
+            if (!string_walk(mv, ps[k], nullptr, &sl, &dl)) {
+                out = DLEN_INVALID;
+                atomicOr(&p.st->err, 1u);
+            } else {
+                const bool cp = p.copy_strings || sl != dl;
+                out = dl | (cp ? DLEN_COPY : 0u);
+                copied[k] = cp ? dl : 0u;
+            }
+            p.dlen[base + k] = out;
+        }
+    }
+    __syncthreads();
+    Agg e[S2_ITEMS];
+    tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
+    Agg v = agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3]));
+    v = wave_inclusive(v, lane);
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+        Agg tot = s_w[0];
+        for (int w = 1; w < S2_WAVES; w++) tot = agg_combine(tot, s_w[w]);
+        p.agg[blockIdx.x].a = tot;
+    }
+}
+
+// ---- pass 2: one block, exclusive scan over the tile aggregates (in place) + totals ---------------------------
+__global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
     __shared__ Agg lds[16];
     __shared__ Agg carry_s;
-    __shared__ unsigned long long words64;
+    __shared__ unsigned long long words64, bytes64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
-        carry_s = Agg{0, 0, 0, 0, 0, 0};
+        carry_s = agg_identity();
         words64 = 0;
+        bytes64 = 0;
     }
     __syncthreads();
     for (u32 start = 0; start < p.tiles; start += 1024) {
         const u32 t = start + threadIdx.x;
-        Agg incl{0, 0, 0, 0, 0};
-        if (t < p.tiles) incl = Agg{p.agg_d[t], p.agg_w[t], p.agg_s[t], p.agg_lb[t], p.agg_nb[t], p.agg_bc[t]};
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {  // inclusive scan inside the wave
-            const Agg o = agg_shfl_up(incl, s);
-            if (lane >= s) incl = agg_combine(o, incl);
-        }
+        Agg incl = t < p.tiles ? p.agg[t].a : agg_identity();
+        incl = wave_inclusive(incl, lane);
         if (lane == 63) lds[wave] = incl;
         __syncthreads();
         Agg before = carry_s;  // everything in front of this wave
         for (int w = 0; w < wave; w++) before = agg_combine(before, lds[w]);
         const Agg prev = agg_shfl_up(incl, 1);
         const Agg excl = lane > 0 ? agg_combine(before, prev) : before;
-        if (t < p.tiles) {
-            p.agg_d[t] = excl.d;
-            p.agg_w[t] = excl.w;
-            p.agg_s[t] = excl.s;
-            p.agg_lb[t] = excl.lb;
-            p.agg_nb[t] = excl.nb;
-            p.agg_bc[t] = excl.bc;
-        }
+        if (t < p.tiles) p.agg[t].a = excl;
         __syncthreads();
         if (threadIdx.x == 1023) {
             const Agg total = agg_combine(before, incl);
-            words64 += (unsigned long long)(u32)(total.w - carry_s.w);  // chunk sum < 2^32
+            words64 += (unsigned long long)(u32)(total.w - carry_s.w);  // sum of one round < 2^32
+            bytes64 += (unsigned long long)(u32)(total.s - carry_s.s);
             carry_s = total;
         }
         __syncthreads();
@@ -303,61 +337,172 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(S2Dev p) {
         const Agg tot = carry_s;
         p.st->final_depth = tot.d;
         p.st->tape_len = words64 + 2ull;  // + opening root + closing root
-        p.st->strings_len = tot.s;
+        p.st->strings_len = p.sv.qm ? p.st->strings_len_masks : bytes64;
         p.st->records = tot.nb;
         p.st->n_br = tot.bc;
-        if (words64 + 2ull > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
+        // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
+        p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : (tot.am & AM_ALL);
+        if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
         if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
     }
 }
 
-__global__ __launch_bounds__(S2_BLOCK) void k_scan_apply(S2Dev p) {
-    __shared__ Agg lds[S2_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 base = blockIdx.x * S2_TILE + threadIdx.x * S2_ITEMS;
-    Agg item[S2_ITEMS];
-    Agg v{0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        item[k] = (base + k < p.n) ? token_agg(p, base + k) : Agg{0, 0, 0, 0, 0, 0};
-        v = agg_combine(v, item[k]);
+// ---- pass 3: offsets + every tape word that needs no bracket partner ----------------------------------------------
+// Numbers are the expensive tokens (a byte loop and a 128-bit multiply) and only ~10 % of all tokens: every
+// block first handles everything else and queues its number tokens in LDS, then parses them with the lanes
+// packed densely, so that a wave of commas does not pay for the one number among them.
+__global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
+    __shared__ u8 s_glut[1024];
+    __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
+    __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
+    __shared__ Agg s_w[S2_WAVES];
+    __shared__ uint2 s_num[S2_TILE];       // (message offset, tape offset) of the queued numbers
+    __shared__ u32 s_nb[S2_BLOCK][9];      // 32-byte windows, 36-byte stride (bank-conflict free)
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
+    const u64 tape_len = p.st->tape_len;
+    if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
+    s_glut[tid] = c_glut.v[tid];
+    if (tid == 0) s_cnt = 0;
+    const u32 endpos = (u32)p.len;
+    uint4 pv = make_uint4(endpos, endpos, endpos, endpos);
+    u32 kv = 0;  // K_BAD x4
+    if (base + 3 < p.n) {
+        pv = *reinterpret_cast<const uint4 *>(p.pos + base);
+        kv = *reinterpret_cast<const u32 *>(p.kind + base);
+    } else {
+        if (base < p.n) { pv.x = p.pos[base]; kv |= (u32)p.kind[base]; }
+        if (base + 1 < p.n) { pv.y = p.pos[base + 1]; kv |= (u32)p.kind[base + 1] << 8; }
+        if (base + 2 < p.n) { pv.z = p.pos[base + 2]; kv |= (u32)p.kind[base + 2] << 16; }
     }
-    Agg incl = v;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const Agg o = agg_shfl_up(incl, s);
-        if (lane >= s) incl = agg_combine(o, incl);
+    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS]) = pv;
+    *reinterpret_cast<u32 *>(&s_kind[4 + tid * S2_ITEMS]) = kv;
+    if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_BAD;
+    if (tid == 2) {
+        const bool more = (u64)t0 + S2_TILE < p.n;
+        s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_BAD;
+        s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
     }
-    if (lane == 63) lds[wave] = incl;
+    u32 copied[S2_ITEMS] = {0, 0, 0, 0};
+    u32 dl[S2_ITEMS] = {0, 0, 0, 0};
+    if (!p.sv.qm) {
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++)
+            if (((kv >> (8 * k)) & 0xffu) == K_STRING) {
+                dl[k] = p.dlen[base + k];
+                copied[k] = (dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
+            }
+    }
     __syncthreads();
-    Agg run{p.agg_d[blockIdx.x], p.agg_w[blockIdx.x], p.agg_s[blockIdx.x], p.agg_lb[blockIdx.x], p.agg_nb[blockIdx.x],
-            p.agg_bc[blockIdx.x]};
-    for (int w = 0; w < wave; w++) run = agg_combine(run, lds[w]);
+    Agg e[S2_ITEMS];
+    tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
+    const Agg mine = agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3]));
+    const Agg incl = wave_inclusive(mine, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    Agg run = p.agg[blockIdx.x].a;  // exclusive prefix of the tile
+    for (int w = 0; w < wave; w++) run = agg_combine(run, s_w[w]);
     {
         const Agg prev = agg_shfl_up(incl, 1);
         if (lane > 0) run = agg_combine(run, prev);
     }
-    // run = exclusive prefix for this thread's first token
+    // run = exclusive prefix of this thread's first token
+    const MsgView mv{p.msg, p.len};
+    bool bad = false;
+    const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 i = base + k;
         if (i >= p.n) break;
-        const Agg a = item[k];
-        p.tape_off[i] = run.w + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-        p.str_off[i] = run.s;
-        if (a.nb) {
-            p.nlb[run.nb] = i;
-            p.match[i] = run.nb;
+        const u8 kd = (u8)((kv >> (8 * k)) & 0xffu);
+        const u32 o = run.w + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
+        if ((e[k].am & AM_ALL) == 0) bad = true;  // legal in no context at all
+        switch (kd) {
+        case K_OPEN_OBJ:
+        case K_OPEN_ARR:
+        case K_CLOSE_OBJ:
+        case K_CLOSE_ARR: {
+            const u32 c = run.bc;  // brackets in front of this one
+            p.br_depth[c] = run.d + e[k].d;
+            p.br_off[c] = o;
+            p.br_info[c] = (u8)(kd | (gap_mask(run, e[k]) << 4));
+            break;
         }
-        const u32 c = run.bc;  // brackets in front of this token
-        run = agg_combine(run, a);
-        p.depth[i] = run.d;
-        p.last_br[i] = run.lb;
-        if (a.bc) {
-            p.br_tok[c] = i;
-            p.br_depth[c] = run.d;
+        case K_TRUE:
+        case K_FALSE:
+        case K_NULL:
+            p.tape[o] = atom_word(kd);
+            bad |= !atom_valid(mv, pp[k], kd);
+            break;
+        case K_NUM: {  // wave-aggregated append: one LDS atomic per wave
+            const u64 act = __ballot(1);
+            const int leader = (int)__builtin_ctzll(act);
+            u32 slot = 0;
+            if (lane == leader) slot = atomicAdd(&s_cnt, (u32)__builtin_popcountll(act));
+            slot = (u32)__shfl((int)slot, leader, 64) + (u32)__builtin_popcountll(act & ((1ull << lane) - 1));
+            s_num[slot] = make_uint2(pp[k], o);
+            break;
+        }
+        case K_STRING:
+            if (p.sv.qm) {  // every string copied: offset and length come from the emit masks (sj_strings.h)
+                const u64 a0 = (u64)pp[k] + p.sv.lead + 1;
+                const u64 a1 = (u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead;
+                const u64 so = emitted_before(p.unit_cnt, p.chunk_pre, p.em, a0);
+                const u64 se = emitted_before(p.unit_cnt, p.chunk_pre, p.em, a1);
+                p.tape[o] = string_word(true, p.strings_base + so, 0);
+                p.tape[o + 1] = se - so;
+            } else if (dl[k] != DLEN_INVALID) {
+                const bool cp = (dl[k] & DLEN_COPY) != 0;
+                p.tape[o] = string_word(cp, p.strings_base + run.s, p.msg_base + pp[k] + 1);
+                p.tape[o + 1] = dl[k] & ~DLEN_COPY;
+                p.str_off[i] = run.s;
+            }
+            break;
+        case K_NL:
+            if (e[k].nb) p.nl_off[run.nb] = o;
+            break;
+        default: break;
+        }
+        run = agg_combine(run, e[k]);
+    }
+    __syncthreads();
+    // the queued numbers: the first 32 bytes of each go to LDS (two unaligned 16-byte loads instead of one
+    // dependent byte load per digit); longer numbers fall back to the message itself
+    const u32 cnt = s_cnt;
+    for (u32 j0 = 0; j0 < cnt; j0 += S2_BLOCK) {
+        const u32 j = j0 + (u32)tid;
+        if (j >= cnt) break;
+        const uint2 q = s_num[j];
+        const u32 at = q.x;
+        const u64 rest = p.len - at;
+        u32 *w = s_nb[tid];
+        if (rest >= 32) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(p.msg + at), b = *reinterpret_cast<const uint4 *>(p.msg + at + 16);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else {
+            u8 *wb = reinterpret_cast<u8 *>(w);
+            for (u32 k = 0; k < (u32)rest; k++) wb[k] = p.msg[at + k];
+        }
+        u64 tag = 0, val = 0;
+        u32 numlen = 0;
+        const u32 avail = rest < 32 ? (u32)rest : 32u;
+        int st = parse_number(reinterpret_cast<const u8 *>(w), avail, &tag, &val, &numlen);
+        if (numlen == 32 && rest > 32) st = parse_number(p.msg + at, (u32)rest, &tag, &val, &numlen);
+        if (st == NUM_FAIL) {
+            bad = true;
+        } else {
+            p.tape[q.y] = tag;
+            p.tape[q.y + 1] = val;
+            if (st == NUM_NEEDS_BIGNUM) {
+                const u32 slot = atomicAdd(&p.st->bignum_count, 1u);
+                p.bigq[2 * slot] = at;
+                p.bigq[2 * slot + 1] = q.y;
+            }
         }
     }
+    if (bad) atomicOr(&p.st->err, 1u);
 }
 
 // ---- kernel 6: one level of the 64-ary min tree over br_depth[] (one wave per group) -----------------------
@@ -393,151 +538,53 @@ __global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
     }
 }
 
-__device__ __forceinline__ Tokens make_tokens(const S2Dev &p) {
-    Tokens t{p.pos, p.n, p.kind, p.depth, p.tape_off, p.str_off, p.last_br, p.match, p.ctxb};
-    t.tape_base = p.tape_base;
-    t.strings_base = p.strings_base;
-    t.msg_base = p.msg_base;
-    return t;
-}
 
-// ---- kernel 7: bracket partners and resume contexts -------------------------------------------------------
+// ---- bracket partners, contexts and the grammar check of every gap ----------------------------------------------
 __global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
     const u32 n_br = p.st->n_br;
     const MinTree mt = make_tree(p);
-    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256)  // compact bracket index
-        if (is_close(p.kind[p.br_tok[c]])) bracket_resolve_compact(mt, p.br_tok, p.kind, c, p.match, p.ctxb);
-}
-
-// ---- kernel 8: grammar check + tape words of brackets, atoms, numbers and roots ----------------------------
-// Numbers are the expensive tokens (a byte loop and a 128-bit multiply) and only ~10 % of all tokens: every
-// block first handles everything else and queues its number tokens in LDS, then parses them with the lanes
-// packed densely, so that a wave of commas does not pay for the one number among them.
-static constexpr int EMIT_BLOCK = 1024;
-__global__ __launch_bounds__(EMIT_BLOCK) void k_emit(S2Dev p) {
-    __shared__ u32 s_num[EMIT_BLOCK];
-    __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
-    __shared__ u32 s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const u32 i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
-    const Tokens t = make_tokens(p);
-    const MsgView mv{p.msg, p.len};
-    const u64 tape_len = p.st->tape_len;
-    if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
     bool bad = false;
-    if (i < p.n) {
-        // round 1: everything that only depends on i, issued together (one memory round trip)
-        const u8 k = p.kind[i];
-        const u8 pk = i > 0 ? p.kind[i - 1] : (u8)K_BAD, ppk = i > 1 ? p.kind[i - 2] : (u8)K_BAD;
-        const u8 nk = i + 1 < p.n ? p.kind[i + 1] : (u8)K_BAD;
-        const u32 lb = i > 0 ? p.last_br[i - 1] : 0u;
-        const u32 o = p.tape_off[i], m = p.match[i], dl = p.dlen[i], so = p.str_off[i];
-        // round 2: the last bracket in front (context) and the partner of a bracket
-        const u8 bk = lb ? p.kind[lb - 1] : (u8)K_BAD, bc = lb ? p.ctxb[lb - 1] : (u8)CTX_ROOT;
-        const bool br = is_bracket(k) && m < p.n;
-        const u32 mo = br ? p.tape_off[m] : 0u;
-        bad = grammar_violation_v(i, k, pk, ppk, gap_ctx_v(lb, bk, bc));
-        switch (k) {
-        case K_OPEN_OBJ:
-        case K_OPEN_ARR:  // payload: tape index just after the matching close (annotate_previousloc, :336)
-            p.tape[o] = ((u64)(k == K_OPEN_OBJ ? '{' : '[') << 56) | (br ? p.tape_base + mo + 1 : 0ull);
-            break;
-        case K_CLOSE_OBJ:
-        case K_CLOSE_ARR:  // payload: tape index of the matching open (:335)
-            p.tape[o] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (br ? p.tape_base + mo : 0ull);
-            break;
-        case K_TRUE:
-        case K_FALSE:
-        case K_NULL:
-            p.tape[o] = (u64)(k == K_TRUE ? 't' : (k == K_FALSE ? 'f' : 'n')) << 56;
-            bad |= !atom_valid(mv, p.pos[i], k);
-            break;
-        case K_NUM: {  // wave-aggregated append: one LDS atomic per wave
-            const u64 act = __ballot(1);
-            const int lane = threadIdx.x & 63;
-            const int leader = (int)__builtin_ctzll(act);
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&s_cnt, (u32)__builtin_popcountll(act));
-            base = (u32)__shfl((int)base, leader, 64);
-            s_num[base + (u32)__builtin_popcountll(act & ((1ull << lane) - 1))] = i;
-            break;
-        }
-        case K_STRING:
-            if (p.sv.qm && dl != DLEN_INVALID) {  // copy mode: the bytes are written by k_str_emit, only the tape words here
-                p.tape[o] = ((u64)'"' << 56) | (STRINGBUFBIT + p.strings_base + so);
-                p.tape[o + 1] = dl & ~DLEN_COPY;
-            }
-            break;
-        case K_NL:
-            if (i + 1 < p.n && nk != K_NL)
-                emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, m + 1, p.tape, p.tape_base);
-            break;
-        default: break;
-        }
-        if (i == 0) emit_root(p.nlb, p.st->records, p.tape_off, (u32)tape_len, 0, p.tape, p.tape_base);
-    }
-    __syncthreads();
-    // the queued numbers, 256 at a time: the first 32 bytes of each go to LDS (two unaligned 16-byte loads instead
-    // of one dependent byte load per digit); longer numbers fall back to the message itself
-    const u32 cnt = s_cnt;
-    for (u32 j0 = 0; j0 < cnt; j0 += 256) {
-        const u32 j = j0 + threadIdx.x;
-        if (threadIdx.x < 256 && j < cnt) {
-            const u32 q = s_num[j];
-            const u32 at = p.pos[q];
-            const u64 rest = p.len - at;
-            u32 *w = s_nb[threadIdx.x];
-            if (rest >= 32) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(p.msg + at), b = *reinterpret_cast<const uint4 *>(p.msg + at + 16);
-                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-                w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-            } else {
-                u8 *wb = reinterpret_cast<u8 *>(w);
-                for (u32 k = 0; k < (u32)rest; k++) wb[k] = p.msg[at + k];
-            }
-            u64 tag = 0, val = 0;
-            u32 numlen = 0;
-            const u32 avail = rest < 32 ? (u32)rest : 32u;
-            int st = parse_number(reinterpret_cast<const u8 *>(w), avail, &tag, &val, &numlen);
-            if (numlen == 32 && rest > 32) st = parse_number(p.msg + at, (u32)rest, &tag, &val, &numlen);
-            if (st == NUM_FAIL) {
-                bad = true;
-            } else {
-                const u32 o = p.tape_off[q];
-                p.tape[o] = tag;
-                p.tape[o + 1] = val;
-                if (st == NUM_NEEDS_BIGNUM) p.bigq[atomicAdd(&p.st->bignum_count, 1u)] = q;
-            }
-        }
+    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256) {  // compact bracket index
+        const u8 ctx = bracket_resolve(mt, p.br_off, p.br_info, c, p.tape_base, p.tape);
+        const u32 next = c + 1 < n_br ? (u32)(p.br_info[c + 1] >> 4) : p.st->tail_mask;  // the gap behind bracket c
+        bad |= !context_allowed(next, ctx);
+        if (c == 0) bad |= !context_allowed((u32)(p.br_info[0] >> 4), CTX_ROOT);
     }
     if (bad) atomicOr(&p.st->err, 1u);
 }
 
-// ---- kernel 9: strings (tape words + unescaped copy into Strings.B) -----------------------------------------
+// ---- root words --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_roots(S2Dev p) {
+    const u32 R = p.st->records;
+    const u64 tape_len = p.st->tape_len;
+    if (tape_len > p.tape_cap) return;
+    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r <= R; r += (u64)gridDim.x * 256)
+        emit_root(p.nl_off, R, (u32)tape_len, (u32)r, p.tape, p.tape_base);
+}
+
+// ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
 __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     if (p.kind[i] != K_STRING) return;
     const u32 dl = p.dlen[i];
-    if (dl == DLEN_INVALID) return;
-    if ((u64)p.str_off[i] + (dl & ~DLEN_COPY) > p.strings_cap) return;
-    const Tokens t = make_tokens(p);
+    if (dl == DLEN_INVALID || !(dl & DLEN_COPY)) return;
+    const u32 so = p.str_off[i];
+    if ((u64)so + (dl & ~DLEN_COPY) > p.strings_cap) return;
     const MsgView mv{p.msg, p.len};
-    emit_string(t, mv, i, (dl & DLEN_COPY) != 0, dl & ~DLEN_COPY, p.tape, p.sv.qm ? nullptr : p.strings);
+    u32 sl, dl2;
+    string_walk(mv, p.pos[i], p.strings + so, &sl, &dl2);
 }
 
-// ---- kernel 10: exact tie-break for >19-digit mantissas whose neighbours disagree ------------------------------
+// ---- exact tie-break for >19-digit mantissas whose neighbours disagree --------------------------------------------
 __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
     const u32 cnt = p.st->bignum_count;
     Big X, Y;
     for (u32 q = blockIdx.x * 64 + threadIdx.x; q < cnt; q += gridDim.x * 64) {
-        const u32 i = p.bigq[q];
-        const u32 at = p.pos[i];
+        const u32 at = p.bigq[2 * q], o = p.bigq[2 * q + 1];
         u64 tag, val;
         u32 numlen = 0;
         (void)parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
-        const u32 o = p.tape_off[i];
         const u64 cand = p.tape[o + 1];
         const u64 sign = cand & 0x8000000000000000ull;
         const u64 r = bignum_round(p.msg + at, numlen, cand & ~0x8000000000000000ull, X, Y);
@@ -551,10 +598,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = sizeof(S2State) + 256;
-    b += align_up(n, 256) * 2;                      // kind, ctxb
-    b += align_up(n * 4, 256) * 11;                 // dlen depth tape_off str_off last_br match nlb bigq br_tok br_depth (+1)
+    b += align_up(n + 16, 256) * 2;                 // kind, br_info
+    b += align_up(n * 4, 256) * 7;                  // dlen str_off nl_off bigq(x2) br_depth br_off
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
-    b += align_up(tiles * 4, 256) * 6;
+    b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
     for (int l = 1; l < MinTree::MAXLEV; l++) {
         lv = (lv + 63) / 64;
@@ -580,25 +627,16 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.n = (u32)n;
     p.ndjson = flags & 1u;
     p.copy_strings = (flags >> 1) & 1u;
-    p.kind = reinterpret_cast<u8 *>(carve(n));
-    p.ctxb = reinterpret_cast<u8 *>(carve(n));
+    p.kind = reinterpret_cast<u8 *>(carve(n + 16));
+    p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
-    p.depth = reinterpret_cast<i32 *>(carve(n * 4));
-    p.tape_off = reinterpret_cast<u32 *>(carve(n * 4));
     p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
-    p.last_br = reinterpret_cast<u32 *>(carve(n * 4));
-    p.match = reinterpret_cast<u32 *>(carve(n * 4));
-    p.nlb = reinterpret_cast<u32 *>(carve(n * 4));
-    p.bigq = reinterpret_cast<u32 *>(carve(n * 4));
-    p.br_tok = reinterpret_cast<u32 *>(carve(n * 4));
+    p.nl_off = reinterpret_cast<u32 *>(carve(n * 4));
+    p.bigq = reinterpret_cast<u32 *>(carve(n * 8));
     p.br_depth = reinterpret_cast<i32 *>(carve(n * 4));
+    p.br_off = reinterpret_cast<u32 *>(carve(n * 4));
     p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
-    p.agg_d = reinterpret_cast<i32 *>(carve((size_t)p.tiles * 4));
-    p.agg_w = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
-    p.agg_s = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
-    p.agg_lb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
-    p.agg_nb = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
-    p.agg_bc = reinterpret_cast<u32 *>(carve((size_t)p.tiles * 4));
+    p.agg = reinterpret_cast<TileAgg *>(carve((size_t)(p.tiles + 1) * sizeof(TileAgg)));
     p.nlev = 1;
     p.lev[0] = nullptr;
     p.lev_size[0] = n;
@@ -642,31 +680,26 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
     return p;
 }
 
-// Phase 1: token kinds, string lengths and the device-wide scan.  Afterwards S2State holds tape_len /
-// strings_len of this message (what an NDJSON shard exchanges with the other shards) and every token
-// knows its depth and its tape / Strings.B offsets.
+// Phase 1: token kinds and the device-wide scan of the tile aggregates.  Afterwards S2State holds tape_len /
+// strings_len of this message (what an NDJSON shard exchanges with the other shards).
 hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws,
                                  hipStream_t stream, void *str_aux) {
     const S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
     hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(p.match, 0, n * 4, stream);
-    if (e != hipSuccess) return e;
-    const u32 gb = (u32)((n + 255) / 256);
+    if (n == 0) return hipSuccess;
     if (p.sv.qm) {
         hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(k_str_scan, dim3(1), dim3(1024), 0, stream, p);
     }
-    hipLaunchKernelGGL(k_string_measure, dim3(gb), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(k_scan_apply, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_s2_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 
-// Phase 2: bracket matching, grammar check, tape and Strings.B.  The three bases rebase every index the
-// tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message, the exclusive
-// prefix sums over the preceding shards for an NDJSON shard.
+// Phase 2: tape words, bracket matching with the grammar check, roots and Strings.B.  The three bases rebase
+// every index the tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message, the
+// exclusive prefix sums over the preceding shards for an NDJSON shard.
 hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
                               size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base, u64 strings_base,
                               u64 msg_base, hipStream_t stream, void *str_aux) {
@@ -674,13 +707,15 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
     p.tape_base = tape_base;
     p.strings_base = strings_base;
     p.msg_base = msg_base;
+    if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
+    hipLaunchKernelGGL(k_s2_emit, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     for (int l = 1; l < p.nlev; l++) {  // grid-stride: the kernels use the real bracket count
         const u64 want = (p.lev_size[l] + 3) / 4;
         hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
     }
     hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_emit, dim3((u32)((n + EMIT_BLOCK - 1) / EMIT_BLOCK)), dim3(EMIT_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_roots, dim3(256), dim3(256), 0, stream, p);
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
