@@ -28,7 +28,8 @@ struct S2State {
     uint32_t n_br;           // number of bracket tokens (size of the compact bracket view)
     uint32_t tail_mask;      // allowed contexts of the gap behind the last bracket (sj_stage2.h)
     unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
-    uint32_t pad[4];
+    uint32_t num_count;      // number tokens queued for k_numbers
+    uint32_t pad[3];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 

@@ -262,15 +262,21 @@ SJ_HD bool atom_terminator(u8 c) {
     default: return false;
     }
 }
-SJ_HD bool atom_valid(const MsgView &m, u64 p, u8 kind) {
-    const u64 rem = m.len - p;
-    if (kind == K_TRUE)
-        return rem >= 5 && m.p[p + 1] == 'r' && m.p[p + 2] == 'u' && m.p[p + 3] == 'e' && atom_terminator(m.p[p + 4]);
-    if (kind == K_NULL)
-        return rem >= 5 && m.p[p + 1] == 'u' && m.p[p + 2] == 'l' && m.p[p + 3] == 'l' && atom_terminator(m.p[p + 4]);
-    return rem >= 6 && m.p[p + 1] == 'a' && m.p[p + 2] == 'l' && m.p[p + 3] == 's' && m.p[p + 4] == 'e' &&
-           atom_terminator(m.p[p + 5]);
+// w8 = the 8 message bytes at the token (little endian, zero beyond the end), rem = bytes from the token to the
+// end of the message
+SJ_HD bool atom_valid_word(u64 w8, u64 rem, u8 kind) {
+    const u32 lo = (u32)w8;
+    if (kind == K_TRUE) return rem >= 5 && lo == 0x65757274u && atom_terminator((u8)(w8 >> 32));
+    if (kind == K_NULL) return rem >= 5 && lo == 0x6c6c756eu && atom_terminator((u8)(w8 >> 32));
+    return rem >= 6 && (w8 & 0x000000ffffffffffull) == 0x00000065736c6166ull && atom_terminator((u8)(w8 >> 40));
 }
+SJ_HD u64 load8_guarded(const MsgView &m, u64 p) {
+    if (p + 8 <= m.len) return load_u64(m.p + p);
+    u64 v = 0;
+    for (u32 k = 0; k < 8 && p + k < m.len; k++) v |= (u64)m.p[p + k] << (8 * k);
+    return v;
+}
+SJ_HD bool atom_valid(const MsgView &m, u64 p, u8 kind) { return atom_valid_word(load8_guarded(m, p), m.len - p, kind); }
 
 // ---- previous-smaller-value over depth[] with a 64-ary min tree ------------------------------------
 struct MinTree {

@@ -54,6 +54,7 @@ struct S2Dev {
     u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     u32 *str_off;  // [n] selective copy only: Strings.B offset of a copied string
     u32 *nl_off;   // [n] tape offset of the r-th record-separating newline
+    uint2 *numq;   // [n] (message offset, tape offset) of every number token, in no particular order
     u32 *bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
     i32 *br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
     u32 *br_off;   // [n]                       its tape offset
@@ -188,6 +189,64 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
 }
 
 // ---- the token scan ----------------------------------------------------------------------------------------
+// Inside a 4096-token tile every quantity fits a few bits, so the block-level scan runs on a packed form:
+//   x = w (14 bits) | bc << 14 (13 bits) | am << 28        y = opens (13 bits) | nb << 13        s = Strings.B bytes
+// (depth = 2 * opens - brackets).  Wave scans use DPP row shifts / broadcasts (no LDS traffic).
+struct PAgg {
+    u32 x, y, s;
+};
+static constexpr u32 PX_SUM = 0x0fffffffu, PX_ID = AM_ALL << 28;
+__device__ __forceinline__ PAgg pagg_pack(const Agg &a) {
+    return PAgg{a.w | (a.bc << 14) | (a.am << 28), (u32)((a.d + (i32)a.bc) >> 1) | (a.nb << 13), a.s};
+}
+__device__ __forceinline__ Agg pagg_unpack(const PAgg &v) {
+    const u32 bc = (v.x >> 14) & 0x1fffu, op = v.y & 0x1fffu;
+    return Agg{(i32)(2u * op) - (i32)bc, v.x & 0x3fffu, v.s, v.y >> 13, bc, v.x >> 28};
+}
+__device__ __forceinline__ PAgg pagg_combine(const PAgg &a, const PAgg &b) {  // a in front of b
+    return PAgg{((a.x & PX_SUM) + (b.x & PX_SUM)) | (am_combine(a.x >> 28, b.x >> 28) << 28), a.y + b.y, a.s + b.s};
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ PAgg pagg_dpp(const PAgg &v) {  // lanes without a source read the identity
+    return PAgg{(u32)__builtin_amdgcn_update_dpp((int)PX_ID, (int)v.x, CTRL, ROW_MASK, 0xf, false),
+                (u32)__builtin_amdgcn_update_dpp(0, (int)v.y, CTRL, ROW_MASK, 0xf, false),
+                (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false)};
+}
+__device__ __forceinline__ PAgg pagg_wave_inclusive(PAgg v) {
+    v = pagg_combine(pagg_dpp<0x111, 0xf>(v), v);  // row_shr:1
+    v = pagg_combine(pagg_dpp<0x112, 0xf>(v), v);  // row_shr:2
+    v = pagg_combine(pagg_dpp<0x114, 0xf>(v), v);  // row_shr:4
+    v = pagg_combine(pagg_dpp<0x118, 0xf>(v), v);  // row_shr:8
+    v = pagg_combine(pagg_dpp<0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
+    v = pagg_combine(pagg_dpp<0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ PAgg pagg_lane_above(const PAgg &v) {  // value of lane - 1, identity in lane 0 (wave_shr:1)
+    return pagg_dpp<0x138, 0xf>(v);
+}
+__device__ __forceinline__ PAgg pagg_readlane(const PAgg &v, int l) {
+    return PAgg{(u32)__builtin_amdgcn_readlane((int)v.x, l), (u32)__builtin_amdgcn_readlane((int)v.y, l),
+                (u32)__builtin_amdgcn_readlane((int)v.s, l)};
+}
+// Block-level exclusive prefix of one value per thread (S2_WAVES waves); returns the exclusive prefix of the
+// calling thread and, in `total`, the sum over the block.  s_w: S2_WAVES entries of LDS.
+__device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w, int lane, int wave, PAgg &total) {
+    const PAgg incl = pagg_wave_inclusive(mine);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    // every wave scans the 16 wave totals in its first row
+    PAgg t = lane < S2_WAVES ? s_w[lane] : PAgg{PX_ID, 0u, 0u};
+    t = pagg_combine(pagg_dpp<0x111, 0xf>(t), t);
+    t = pagg_combine(pagg_dpp<0x112, 0xf>(t), t);
+    t = pagg_combine(pagg_dpp<0x114, 0xf>(t), t);
+    t = pagg_combine(pagg_dpp<0x118, 0xf>(t), t);
+    total = pagg_readlane(t, S2_WAVES - 1);
+    PAgg before = PAgg{PX_ID, 0u, 0u};
+    if (wave > 0) before = pagg_readlane(t, (wave - 1) & 15);
+    return pagg_combine(before, pagg_lane_above(incl));
+}
+
+// the full-width scan of the tile aggregates (one block, k_s2_scan_tiles)
 __device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
     return Agg{__shfl_up(a.d, delta, 64),          (u32)__shfl_up((int)a.w, delta, 64),  (u32)__shfl_up((int)a.s, delta, 64),
                (u32)__shfl_up((int)a.nb, delta, 64), (u32)__shfl_up((int)a.bc, delta, 64), (u32)__shfl_up((int)a.am, delta, 64)};
@@ -221,8 +280,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_reduce(S2Dev p) {
     __shared__ u8 s_glut[1024];
     __shared__ u8 s_klut[256];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
-    __shared__ Agg s_w[S2_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ PAgg s_w[S2_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     s_glut[tid] = c_glut.v[tid];
     if (tid < 256) s_klut[tid] = c_klut.v[tid];
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
@@ -290,15 +349,10 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_reduce(S2Dev p) {
     __syncthreads();
     Agg e[S2_ITEMS];
     tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
-    Agg v = agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3]));
-    v = wave_inclusive(v, lane);
-    if (lane == 63) s_w[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-        Agg tot = s_w[0];
-        for (int w = 1; w < S2_WAVES; w++) tot = agg_combine(tot, s_w[w]);
-        p.agg[blockIdx.x].a = tot;
-    }
+    const PAgg mine = pagg_pack(agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3])));
+    PAgg total;
+    (void)pagg_block_exclusive(mine, s_w, lane, wave, total);
+    if (tid == 0) p.agg[blockIdx.x].a = pagg_unpack(total);
 }
 
 // ---- pass 2: one block, exclusive scan over the tile aggregates (in place) + totals ---------------------------
@@ -348,18 +402,17 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
 }
 
 // ---- pass 3: offsets + every tape word that needs no bracket partner ----------------------------------------------
-// Numbers are the expensive tokens (a byte loop and a 128-bit multiply) and only ~10 % of all tokens: every
-// block first handles everything else and queues its number tokens in LDS, then parses them with the lanes
-// packed densely, so that a wave of commas does not pay for the one number among them.
+// Everything a token needs from memory (the 8 bytes of an atom, the emit-mask words of a string) is requested
+// for all four tokens of a thread before the first use: one memory round trip per tile, not one per token.
+// Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
 __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     __shared__ u8 s_glut[1024];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
-    __shared__ Agg s_w[S2_WAVES];
-    __shared__ uint2 s_num[S2_TILE];       // (message offset, tape offset) of the queued numbers
-    __shared__ u32 s_nb[S2_BLOCK][9];      // 32-byte windows, 36-byte stride (bank-conflict free)
-    __shared__ u32 s_cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ PAgg s_w[S2_WAVES];
+    __shared__ uint2 s_num[S2_TILE];  // (message offset, tape offset) of the tile's numbers
+    __shared__ u32 s_cnt, s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
@@ -384,33 +437,56 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
         s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_BAD;
         s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
     }
-    u32 copied[S2_ITEMS] = {0, 0, 0, 0};
-    u32 dl[S2_ITEMS] = {0, 0, 0, 0};
-    if (!p.sv.qm) {
+    const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
+    const MsgView mv{p.msg, p.len};
+    const bool masks = p.sv.qm != nullptr;  // every string copied: offsets and lengths come from the emit masks
+    // ---- loads that only depend on the token itself
+    u64 aw[S2_ITEMS];                  // atoms: the 8 message bytes at the token
+    u32 dl[S2_ITEMS], copied[S2_ITEMS];  // selective copy: measured lengths
+    u32 uc0[S2_ITEMS], cp0[S2_ITEMS];  // strings (masks): the three words of E(a0)
+    u64 em0[S2_ITEMS];
 #pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++)
-            if (((kv >> (8 * k)) & 0xffu) == K_STRING) {
+    for (int k = 0; k < S2_ITEMS; k++) {
+        const u8 kd = (u8)((kv >> (8 * k)) & 0xffu);
+        aw[k] = 0;
+        dl[k] = copied[k] = 0;
+        uc0[k] = cp0[k] = 0;
+        em0[k] = 0;
+        if (kd == K_TRUE || kd == K_FALSE || kd == K_NULL) aw[k] = load8_guarded(mv, pp[k]);
+        if (kd == K_STRING) {
+            if (masks) {
+                const u64 a0 = (u64)pp[k] + p.sv.lead + 1;
+                uc0[k] = p.unit_cnt[a0 >> 12];
+                cp0[k] = p.chunk_pre[a0 >> 6];
+                em0[k] = p.em[a0 >> 6];
+            } else {
                 dl[k] = p.dlen[base + k];
                 copied[k] = (dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
             }
+        }
     }
     __syncthreads();
+    // ---- the second half of the string loads needs the next token's position (LDS)
+    u32 uc1[S2_ITEMS], cp1[S2_ITEMS];
+    u64 em1[S2_ITEMS];
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) {
+        uc1[k] = cp1[k] = 0;
+        em1[k] = 0;
+        if (masks && ((kv >> (8 * k)) & 0xffu) == K_STRING) {
+            const u64 a1 = (u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead;
+            uc1[k] = p.unit_cnt[a1 >> 12];
+            cp1[k] = p.chunk_pre[a1 >> 6];
+            em1[k] = p.em[a1 >> 6];
+        }
+    }
     Agg e[S2_ITEMS];
     tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
-    const Agg mine = agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3]));
-    const Agg incl = wave_inclusive(mine, lane);
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    Agg run = p.agg[blockIdx.x].a;  // exclusive prefix of the tile
-    for (int w = 0; w < wave; w++) run = agg_combine(run, s_w[w]);
-    {
-        const Agg prev = agg_shfl_up(incl, 1);
-        if (lane > 0) run = agg_combine(run, prev);
-    }
-    // run = exclusive prefix of this thread's first token
-    const MsgView mv{p.msg, p.len};
+    const PAgg mine = pagg_pack(agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3])));
+    PAgg total;
+    const PAgg local = pagg_block_exclusive(mine, s_w, lane, wave, total);
+    Agg run = agg_combine(p.agg[blockIdx.x].a, pagg_unpack(local));  // exclusive prefix of this thread's first token
     bool bad = false;
-    const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 i = base + k;
@@ -433,7 +509,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
         case K_FALSE:
         case K_NULL:
             p.tape[o] = atom_word(kd);
-            bad |= !atom_valid(mv, pp[k], kd);
+            bad |= !atom_valid_word(aw[k], p.len - pp[k], kd);
             break;
         case K_NUM: {  // wave-aggregated append: one LDS atomic per wave
             const u64 act = __ballot(1);
@@ -445,11 +521,11 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             break;
         }
         case K_STRING:
-            if (p.sv.qm) {  // every string copied: offset and length come from the emit masks (sj_strings.h)
-                const u64 a0 = (u64)pp[k] + p.sv.lead + 1;
-                const u64 a1 = (u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead;
-                const u64 so = emitted_before(p.unit_cnt, p.chunk_pre, p.em, a0);
-                const u64 se = emitted_before(p.unit_cnt, p.chunk_pre, p.em, a1);
+            if (masks) {
+                const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
+                const u32 b1 = (u32)(((u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead) & 63u);
+                const u64 so = (u64)uc0[k] + cp0[k] + (u64)popc64(b0 ? (em0[k] & (~0ull >> (64 - b0))) : 0ull);
+                const u64 se = (u64)uc1[k] + cp1[k] + (u64)popc64(b1 ? (em1[k] & (~0ull >> (64 - b1))) : 0ull);
                 p.tape[o] = string_word(true, p.strings_base + so, 0);
                 p.tape[o + 1] = se - so;
             } else if (dl[k] != DLEN_INVALID) {
@@ -466,17 +542,28 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
         }
         run = agg_combine(run, e[k]);
     }
-    __syncthreads();
-    // the queued numbers: the first 32 bytes of each go to LDS (two unaligned 16-byte loads instead of one
-    // dependent byte load per digit); longer numbers fall back to the message itself
+    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
+    // the tile's numbers move to the global queue (coalesced; the order of the queue does not matter)
     const u32 cnt = s_cnt;
-    for (u32 j0 = 0; j0 < cnt; j0 += S2_BLOCK) {
-        const u32 j = j0 + (u32)tid;
-        if (j >= cnt) break;
-        const uint2 q = s_num[j];
+    if (cnt == 0) return;
+    if (tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
+    __syncthreads();
+    const u32 qb = s_base;
+    for (u32 j = (u32)tid; j < cnt; j += S2_BLOCK) p.numq[qb + j] = s_num[j];
+}
+
+// ---- numbers (parseNumber, parse_number.go:65-135): one queued number per lane ------------------------------------
+// The first 32 bytes of each number go to LDS (two unaligned 16-byte loads instead of one dependent byte load
+// per digit); longer numbers fall back to the message itself.
+__global__ __launch_bounds__(256) void k_numbers(S2Dev p) {
+    __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
+    const u32 cnt = p.st->num_count;
+    bool bad = false;
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
+        const uint2 q = p.numq[j];
         const u32 at = q.x;
         const u64 rest = p.len - at;
-        u32 *w = s_nb[tid];
+        u32 *w = s_nb[threadIdx.x];
         if (rest >= 32) {
             const uint4 a = *reinterpret_cast<const uint4 *>(p.msg + at), b = *reinterpret_cast<const uint4 *>(p.msg + at + 16);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
@@ -599,7 +686,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = sizeof(S2State) + 256;
     b += align_up(n + 16, 256) * 2;                 // kind, br_info
-    b += align_up(n * 4, 256) * 7;                  // dlen str_off nl_off bigq(x2) br_depth br_off
+    b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
@@ -632,6 +719,7 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
     p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
     p.nl_off = reinterpret_cast<u32 *>(carve(n * 4));
+    p.numq = reinterpret_cast<uint2 *>(carve(n * 8));
     p.bigq = reinterpret_cast<u32 *>(carve(n * 8));
     p.br_depth = reinterpret_cast<i32 *>(carve(n * 4));
     p.br_off = reinterpret_cast<u32 *>(carve(n * 4));
@@ -710,6 +798,7 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
     hipLaunchKernelGGL(k_s2_emit, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_numbers, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     for (int l = 1; l < p.nlev; l++) {  // grid-stride: the kernels use the real bracket count
         const u64 want = (p.lev_size[l] + 3) / 4;
         hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
