@@ -120,7 +120,7 @@ static int stage1_verdict(const Stage1State &st, size_t len, uint8_t last_byte) 
 }
 
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux) {
+                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -128,7 +128,7 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux),
+    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind),
            "stage1 launch");
     Stage1State *hs = (Stage1State *)ctx->h_scratch;
     HIPCHK(hipMemcpyAsync(hs, ctx->d_ws.p, sizeof(Stage1State), hipMemcpyDeviceToHost, ctx->stream), "D2H state");

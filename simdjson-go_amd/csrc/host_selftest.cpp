@@ -176,8 +176,8 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     if (len == 0 || err || inq || n == 0 || !(msg[len - 1] == '}' || msg[len - 1] == ']')) return 1;
     const MsgView mv{msg, len};
     // stage 2: the kernels of stage2.hip as loops, in launch order
-    static constexpr GrammarLut GLUT = make_grammar_lut();
     static constexpr KindLut KLUT = make_kind_lut();
+    static constexpr ElementLut ELUT = make_element_lut();
     u32 bad = 0;
     // k_str_masks / k_str_scan (every string copied)
     const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data()};
@@ -229,10 +229,11 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     Agg run = agg_identity();
     u64 words = 0, sbytes = 0;
     for (size_t i = 0; i < n; i++) {
-        const Agg e = token_element(GLUT.v, (u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), copied[i]);
-        // the table must agree with the rule it was generated from
-        for (u8 G = 0; G < 3; G++)
-            if (context_allowed(e.am & AM_ALL, G) == grammar_violation_v((u32)i, kind[i], kind_at(i, -1), kind_at(i, -2), G)) return 98;
+        const Agg e = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), copied[i]);
+        {  // the packed table form the kernels use must be the same element
+            const PAgg pe = token_pelement(ELUT.v, kind_window(kind.data(), (u32)i, (u32)n), copied[i]), want = pagg_pack(e);
+            if (pe.x != want.x || pe.y != want.y || pe.s != want.s) return 97;
+        }
         toff[i] = run.w + 1u;
         soff[i] = run.s;
         if ((e.am & AM_ALL) == 0) bad = 1;

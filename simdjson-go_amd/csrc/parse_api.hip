@@ -38,10 +38,13 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         aux = ctx->d_aux.p;
     }
     for (int attempt = 0; attempt < 2; attempt++) {
-        int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * sizeof(uint32_t));
+        pos_cap = (pos_cap + 63) / 64 * 64;
+        // positions, then the token kinds stage 1 writes next to them (1 byte each, 256-byte aligned)
+        int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * (sizeof(uint32_t) + 1));
         if (rc) return rc;
+        ctx->p_kind = (uint8_t *)ctx->d_pos.p + (pos_cap + 64) * sizeof(uint32_t);
         rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                               have_last, &n, &ok, aux);
+                               have_last, &n, &ok, aux, ctx->p_kind);
         if (rc) return rc;
         if (n <= pos_cap) break;
         pos_cap = n;
@@ -53,7 +56,8 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_strings, len + 64);
     if (rc) return rc;
-    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, n, flags, ctx->d_s2.p, ctx->stream, aux),
+    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, flags, ctx->d_s2.p, ctx->stream,
+                                 aux),
            "stage2 launch (measure)");
     ctx->p_aux = aux;
     ctx->pending = 1;
@@ -80,7 +84,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     ctx->pending = 0;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t n = ctx->p_n, len = ctx->p_len;
-    HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, n, ctx->p_flags, ctx->d_s2.p,
+    HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags, ctx->d_s2.p,
                               (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
                               strings_base, msg_base, ctx->stream, ctx->p_aux),
            "stage2 launch (emit)");

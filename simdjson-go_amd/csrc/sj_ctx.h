@@ -29,6 +29,7 @@ struct sjhip_ctx {
     size_t p_len = 0, p_n = 0;
     uint32_t p_flags = 0;
     void *p_aux = nullptr;
+    uint8_t *p_kind = nullptr;  // token kinds of the pending parse (behind the positions in d_pos)
     char err[256];
 };
 
@@ -37,5 +38,5 @@ void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                      uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr);
+                      uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr);
 }  // namespace sj

@@ -34,14 +34,11 @@ struct S2State {
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 
 size_t stage2_workspace_bytes(size_t n_tokens);
-hipError_t stage2_launch(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
-                         uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
-                         hipStream_t stream);
-
-hipError_t stage2_launch_measure(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
-                                 hipStream_t stream, void *str_aux = nullptr);
-hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_pos, size_t n, uint32_t flags, void *ws,
-                              uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
+// d_kind: the token kinds stage 1 wrote next to the positions
+hipError_t stage2_launch_measure(const void *d_msg, size_t len, const uint32_t *d_pos, const uint8_t *d_kind, size_t n,
+                                 uint32_t flags, void *ws, hipStream_t stream, void *str_aux = nullptr);
+hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_pos, const uint8_t *d_kind, size_t n,
+                              uint32_t flags, void *ws, uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
                               uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, hipStream_t stream,
                               void *str_aux = nullptr);
 
@@ -79,9 +76,10 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     return a;
 }
 inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).bytes + 256; }
+// aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
-                                  void *ws, hipStream_t stream, void *aux_buf = nullptr);
+                                  void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr);
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf = nullptr);
+                         hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr);
 
 }  // namespace sj

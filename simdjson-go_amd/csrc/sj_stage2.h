@@ -39,6 +39,7 @@ enum Kind : u8 {
     K_FALSE = 10,
     K_NULL = 11,
     K_NL = 12,
+    K_NONE = 15,  // no token: stands in front of the first token wherever a predecessor's kind is asked for
 };
 enum Ctx : u8 { CTX_ROOT = 0, CTX_OBJ = 1, CTX_ARR = 2 };
 
@@ -69,7 +70,7 @@ SJ_HDC i32 depth_delta(u8 k) { return is_open(k) ? 1 : (is_close(k) ? -1 : 0); }
 // number of tape words a token writes (stage2_build_tape_amd64.go: write_tape call sites).
 // A newline token writes the "close root / open root" pair (:213-218) iff it is the last one of
 // its run and another token follows.
-SJ_HD u32 tape_words(u8 k, u8 next_kind, bool is_last) {
+SJ_HDC u32 tape_words(u8 k, u8 next_kind, bool is_last) {
     switch (k) {
     case K_OPEN_OBJ:
     case K_OPEN_ARR:
@@ -364,17 +365,18 @@ SJ_HDC bool grammar_violation_v(u32 i, u8 k, u8 pk, u8 ppk, u8 G) {
 // The context G is only known once the brackets are matched, so the per-token pass evaluates the rule for all
 // three contexts at once: allowed_contexts = { G : token i is legal in context G } as a bit set (bit CTX_*).
 // The rule reads i only as "first token" / "has two predecessors" and ppk only as "the token before the
-// previous one makes a following string a key", which makes it a 1024-entry table:
-//   index = k | pk << 4 | key_prev << 8 | first << 9
+// previous one makes a following string a key".  With K_NONE standing for the missing predecessors of the
+// first two tokens that makes it a 512-entry table:
+//   index = k | pk << 4 | key_prev << 8         (pk == K_NONE: first token)
 // All tokens between two brackets share one context, so the AND of their sets (a segmented scan, below) is
 // checked once per bracket against the context the bracket pass derives.
-SJ_HDC u32 grammar_lut_index(u32 i, u8 k, u8 pk, u8 ppk) {
-    const bool key_prev = i > 1 && (ppk == K_OPEN_OBJ || ppk == K_COMMA);
-    return (u32)k | ((u32)pk << 4) | (key_prev ? 256u : 0u) | (i == 0 ? 512u : 0u);
+static constexpr u32 LUT_SIZE = 512;
+SJ_HDC u32 grammar_lut_index(u8 k, u8 pk, u8 ppk) {
+    return (u32)k | ((u32)pk << 4) | ((ppk == K_OPEN_OBJ || ppk == K_COMMA) ? 256u : 0u);
 }
 SJ_HDC u8 allowed_contexts_at(u32 index) {
     const u8 k = (u8)(index & 15u), pk = (u8)((index >> 4) & 15u);
-    const bool key_prev = (index >> 8) & 1u, first = (index >> 9) & 1u;
+    const bool key_prev = (index >> 8) & 1u, first = pk == K_NONE;
     const u32 i = first ? 0u : 2u;
     const u8 ppk = key_prev ? (u8)K_COMMA : (u8)K_BAD;
     u8 m = 0;
@@ -382,20 +384,31 @@ SJ_HDC u8 allowed_contexts_at(u32 index) {
         if (!grammar_violation_v(i, k, pk, ppk, G)) m = (u8)(m | (1u << G));
     return m;
 }
-struct GrammarLut {
-    u8 v[1024];
-};
-constexpr GrammarLut make_grammar_lut() {
-    GrammarLut t{};
-    for (u32 x = 0; x < 1024; x++) t.v[x] = allowed_contexts_at(x);
-    return t;
-}
 struct KindLut {
     u8 v[256];  // token_kind(byte, ndjson = true); '\n' is demoted to K_BAD by the caller for plain JSON
 };
 constexpr KindLut make_kind_lut() {
     KindLut t{};
     for (u32 c = 0; c < 256; c++) t.v[c] = token_kind((u8)c, true);
+    return t;
+}
+// The same index also selects everything else a token contributes to the scan except what depends on the
+// NEXT token (a newline writes its root pair only as the last one of its run): one 32-bit entry per index,
+//   bits 0-1 tape words (newline: 0) | bit 14 bracket | bit 27 open bracket | bits 28-30 allowed contexts |
+//   bit 31 "a gap starts here" (the previous token is a bracket)
+// i.e. the packed in-tile form of the scan element (stage2.hip, PAgg) with the open-bracket count in bit 27.
+struct ElementLut {
+    u32 v[LUT_SIZE];
+};
+constexpr ElementLut make_element_lut() {
+    ElementLut t{};
+    for (u32 x = 0; x < LUT_SIZE; x++) {
+        const u8 k = (u8)(x & 15u), pk = (u8)((x >> 4) & 15u);
+        const bool first = pk == K_NONE;
+        const u32 w = k == K_NL ? 0u : tape_words(k, (u8)K_BAD, false);
+        t.v[x] = w | (is_bracket(k) ? 1u << 14 : 0u) | (is_open(k) ? 1u << 27 : 0u) | ((u32)allowed_contexts_at(x) << 28) |
+                 ((!first && is_bracket(pk)) ? 1u << 31 : 0u);
+    }
     return t;
 }
 
@@ -415,7 +428,7 @@ SJ_HD Agg agg_combine(const Agg &a, const Agg &b) {  // a in front of b
 }
 // element of token i of n.  k / pk / ppk / nk: kinds of tokens i, i-1, i-2, i+1 (K_BAD where there is none);
 // copied: bytes the token appends to Strings.B through the scan (0 when the emit masks place the strings)
-SJ_HD Agg token_element(const u8 *glut, u32 i, u32 n, u8 k, u8 pk, u8 ppk, u8 nk, u32 copied) {
+SJ_HD Agg token_element(u32 i, u32 n, u8 k, u8 pk, u8 ppk, u8 nk, u32 copied) {
     const bool last = i + 1 == n;
     Agg a;
     a.d = depth_delta(k);
@@ -423,11 +436,54 @@ SJ_HD Agg token_element(const u8 *glut, u32 i, u32 n, u8 k, u8 pk, u8 ppk, u8 nk
     a.s = copied;
     a.nb = (k == K_NL && !last && nk != K_NL) ? 1u : 0u;
     a.bc = is_bracket(k) ? 1u : 0u;
-    a.am = (u32)glut[grammar_lut_index(i, k, pk, ppk)] | ((i > 0 && is_bracket(pk)) ? AM_START : 0u);  // a gap starts after a bracket
+    u32 allowed = 0;
+    for (u8 G = 0; G < 3; G++)
+        if (!grammar_violation_v(i, k, pk, ppk, G)) allowed |= 1u << G;
+    a.am = allowed | ((i > 0 && is_bracket(pk)) ? AM_START : 0u);  // a gap starts after a bracket
     return a;
 }
 // allowed contexts of the gap that ends with token i (x = exclusive prefix, e = its element)
 SJ_HD u32 gap_mask(const Agg &x, const Agg &e) { return am_combine(x.am, e.am) & AM_ALL; }
+
+// ---- packed form of the scan inside one 4096-token tile ----------------------------------------------------------
+// Inside a tile every quantity fits a few bits:
+//   x = w (14 bits) | bc << 14 (13 bits) | am << 28        y = opens (13 bits) | nb << 13        s = Strings.B bytes
+// (depth = 2 * opens - brackets).
+struct PAgg {
+    u32 x, y, s;
+};
+static constexpr u32 PX_SUM = 0x0fffffffu, PX_ID = AM_ALL << 28;
+SJ_HD PAgg pagg_pack(const Agg &a) {
+    return PAgg{a.w | (a.bc << 14) | (a.am << 28), (u32)((a.d + (i32)a.bc) >> 1) | (a.nb << 13), a.s};
+}
+SJ_HD Agg pagg_unpack(const PAgg &v) {
+    const u32 bc = (v.x >> 14) & 0x1fffu, op = v.y & 0x1fffu;
+    return Agg{(i32)(2u * op) - (i32)bc, v.x & 0x3fffu, v.s, v.y >> 13, bc, v.x >> 28};
+}
+SJ_HD PAgg pagg_combine(const PAgg &a, const PAgg &b) {  // a in front of b
+    return PAgg{((a.x & PX_SUM) + (b.x & PX_SUM)) | (am_combine(a.x >> 28, b.x >> 28) << 28), a.y + b.y, a.s + b.s};
+}
+// Packed scan element of a token from the kinds (ppk, pk, k, nk) in the four bytes of `win`, through the table
+// (token_element is the reference form; the table is generated from the same rules).  Missing neighbours are
+// sentinels: K_NONE in front of the first token, K_NL behind the last one (a newline run at the very end
+// writes no root pair).
+SJ_HD PAgg token_pelement(const u32 *elut, u32 win, u32 copied) {
+    const u32 ppk = win & 0xffu, pk = (win >> 8) & 0xffu, k = (win >> 16) & 0xffu, nk = win >> 24;
+    u32 x = elut[grammar_lut_index((u8)k, (u8)pk, (u8)ppk)];
+    u32 y = (x >> 27) & 1u;  // open bracket
+    x &= ~(1u << 27);
+    if (k == K_NL && nk != K_NL) {  // the last newline of a run separates two records: root pair
+        x += 2u;
+        y |= 1u << 13;
+    }
+    return PAgg{x, y, copied};
+}
+// the kinds around token i of a kind array, with the sentinels
+SJ_HD u32 kind_window(const u8 *kind, u32 i, u32 n) {
+    const u32 ppk = i >= 2 ? kind[i - 2] : (u32)K_NONE, pk = i >= 1 ? kind[i - 1] : (u32)K_NONE;
+    const u32 nk = i + 1 < n ? kind[i + 1] : (u32)K_NL;
+    return ppk | (pk << 8) | ((u32)kind[i] << 16) | (nk << 24);
+}
 
 // ---- brackets: partners and contexts over the compact bracket view ----------------------------------------------
 // The c-th bracket token has depth br_depth[c] after it (level 0 of the min tree), its tape word at br_off[c]

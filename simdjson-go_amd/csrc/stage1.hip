@@ -26,15 +26,18 @@
 
 #include "sj_chunk.h"
 #include "sj_device.h"
+#include "sj_stage2.h"
 
 namespace sj {
 
 // optional extra outputs for the whole parse (all null for stage 1 alone): per 64-byte chunk the in-string mask
 // relative to the unit start, the unescaped quotes and the escape starters; per 4 KiB unit the resolved state
 struct S1Aux {
-    u64 *qm, *q, *st;
+    u64 *qm, *q, *st;  // null unless every string is copied (byte-parallel unescape)
     u8 *unit_h;
+    u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
 };
+__constant__ KindLut c_s1_klut = make_kind_lut();
 
 // ---- tile descriptors ------------------------------------------------------------------
 // One naturally aligned 8-byte granule per tile, status and payload together, relaxed
@@ -336,7 +339,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
-        if (AUX && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+        if (AUX && aux.qm && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.q[ci] = quote_bits;
@@ -375,7 +378,8 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 template <int BLOCK, int CH>
 __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
-                                             u64 &tile_end, u8 *unit_h, u64 len_) {
+                                             u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
+                                             const u8 *s_klut) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     constexpr u32 CAP = CH * 256;  // u32 slots in the wave's window (CH * 2 * 64 u64)
@@ -411,19 +415,42 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
         const u32 loc = wave_incl_scan(n) - n;  // offset of this lane's first position inside the unit
         u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
         __builtin_amdgcn_wave_barrier();  // the window is free: all masks are in registers / already copied out
+        // copies the first cnt staged positions to out_pos[gd ...] (and their kinds to kind_out)
+        auto copy_out = [&](u32 cnt, u64 gd) {
+            if (kind_out) {  // whole parse: the kind of every token next to its position (sj_stage2.h)
+                for (u32 i0 = 0; i0 < cnt; i0 += 256) {  // four gathers in flight per lane; the tile's bytes are still in L2
+                    u32 at[4];
+                    u8 b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 i = i0 + q * 64 + lane;
+                        at[q] = stage[i < cnt ? i : 0];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) b[q] = msg0[at[q]];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 i = i0 + q * 64 + lane;
+                        if (i < cnt && (fits || gd + i < pos_cap)) {
+                            out_pos[gd + i] = at[q];
+                            kind_out[gd + i] = s_klut[b[q]];
+                        }
+                    }
+                }
+            } else if (fits) {
+                for (u32 i = lane; i < cnt; i += 64) out_pos[gd + i] = stage[i];
+            } else {
+                for (u32 i = lane; i < cnt; i += 64)
+                    if (gd + i < pos_cap) out_pos[gd + i] = stage[i];
+            }
+        };
         if (C <= CAP) {
             u32 *p = stage + loc;
             for (u32 lo = lo0; lo != 0; lo &= lo - 1) *p++ = pos0 + (u32)__builtin_ctz(lo);
             pos0 += 32;
             for (u32 hi = hi0; hi != 0; hi &= hi - 1) *p++ = pos0 + (u32)__builtin_ctz(hi);
             __builtin_amdgcn_wave_barrier();
-            u32 *dst = out_pos + g;
-            if (fits) {
-                for (u32 i = lane; i < C; i += 64) dst[i] = stage[i];
-            } else {
-                for (u32 i = lane; i < C; i += 64)
-                    if (g + i < pos_cap) dst[i] = stage[i];
-            }
+            copy_out(C, g);
         } else {
             u64 r = s;
             u32 l = loc;
@@ -435,9 +462,7 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
                     l++;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const u32 cnt = C - r0 < CAP ? C - r0 : CAP;
-                for (u32 i = lane; i < cnt; i += 64)
-                    if (fits || g + r0 + i < pos_cap) out_pos[g + r0 + i] = stage[i];
+                copy_out(C - r0 < CAP ? C - r0 : CAP, g + r0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -461,8 +486,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_unit[3][UNITS];
     __shared__ u32 s_res[4];  // look-back result of the current tile: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
+    __shared__ u8 s_klut[AUX ? 256 : 4];
 
     const int tid = threadIdx.x;
+    if (AUX && tid < 256) {  // '\n' is a token only in NDJSON
+        const u8 k = c_s1_klut.v[tid];
+        s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
+    }
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end, AUX ? aux.unit_h : nullptr, len);
+                                       tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
         P0 = P1;
@@ -624,7 +654,7 @@ hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream)
 
 // d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                                  hipStream_t stream, void *aux_buf) {
+                                  hipStream_t stream, void *aux_buf, u8 *d_kind) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -634,7 +664,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr};
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind};
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = a.qm;
@@ -647,7 +677,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
                        0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles, aux)
 #define S1_LAUNCH2(B, C, W, ND)           \
     do {                                  \
-        if (aux_buf)                      \
+        if (aux_buf || d_kind)            \
             S1_LAUNCH3(B, C, W, ND, true);  \
         else                              \
             S1_LAUNCH3(B, C, W, ND, false); \
@@ -673,10 +703,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 }
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf) {
+                         hipStream_t stream, void *aux_buf, u8 *d_kind) {
     hipError_t e = stage1_prepare(len, reinterpret_cast<uintptr_t>(d_msg) & 63, ws, stream);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind);
 }
 
 }  // namespace sj

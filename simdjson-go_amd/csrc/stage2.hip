@@ -6,7 +6,7 @@
 // kernels, the device-wide scan and the launcher.  No host synchronisation happens between the kernels.
 //
 // Passes over the tokens (one token = one structural index):
-//   k_s2_reduce      kind of every token (1 byte, kept), scan element per token, one aggregate per 4096-token tile
+//   k_s2_reduce      scan element per token from the token kinds (written by stage 1), one aggregate per 4096-token tile
 //   k_s2_scan_tiles  exclusive scan of the tile aggregates (one block) + totals: tape length, records, brackets
 //   k_s2_emit        rebuilds the elements, scans inside the tile, and writes every tape word that does not depend
 //                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
@@ -35,8 +35,7 @@ static constexpr int S2_WAVES = S2_BLOCK / 64;
 static constexpr u32 DLEN_INVALID = 0xffffffffu;
 static constexpr u32 DLEN_COPY = 0x80000000u;
 
-__constant__ GrammarLut c_glut = make_grammar_lut();
-__constant__ KindLut c_klut = make_kind_lut();
+__constant__ ElementLut c_elut = make_element_lut();
 
 struct alignas(32) TileAgg {
     Agg a;
@@ -50,7 +49,7 @@ struct S2Dev {
     const u32 *pos;
     u32 n;
     u32 ndjson, copy_strings;
-    u8 *kind;      // [n]
+    const u8 *kind;  // [n] token kinds (stage 1 writes them next to the positions)
     u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     u32 *str_off;  // [n] selective copy only: Strings.B offset of a copied string
     u32 *nl_off;   // [n] tape offset of the r-th record-separating newline
@@ -189,23 +188,8 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
 }
 
 // ---- the token scan ----------------------------------------------------------------------------------------
-// Inside a 4096-token tile every quantity fits a few bits, so the block-level scan runs on a packed form:
-//   x = w (14 bits) | bc << 14 (13 bits) | am << 28        y = opens (13 bits) | nb << 13        s = Strings.B bytes
-// (depth = 2 * opens - brackets).  Wave scans use DPP row shifts / broadcasts (no LDS traffic).
-struct PAgg {
-    u32 x, y, s;
-};
-static constexpr u32 PX_SUM = 0x0fffffffu, PX_ID = AM_ALL << 28;
-__device__ __forceinline__ PAgg pagg_pack(const Agg &a) {
-    return PAgg{a.w | (a.bc << 14) | (a.am << 28), (u32)((a.d + (i32)a.bc) >> 1) | (a.nb << 13), a.s};
-}
-__device__ __forceinline__ Agg pagg_unpack(const PAgg &v) {
-    const u32 bc = (v.x >> 14) & 0x1fffu, op = v.y & 0x1fffu;
-    return Agg{(i32)(2u * op) - (i32)bc, v.x & 0x3fffu, v.s, v.y >> 13, bc, v.x >> 28};
-}
-__device__ __forceinline__ PAgg pagg_combine(const PAgg &a, const PAgg &b) {  // a in front of b
-    return PAgg{((a.x & PX_SUM) + (b.x & PX_SUM)) | (am_combine(a.x >> 28, b.x >> 28) << 28), a.y + b.y, a.s + b.s};
-}
+// Inside a tile the scan runs on the packed form PAgg (sj_stage2.h); wave scans use DPP row shifts / broadcasts
+// (no LDS traffic).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ PAgg pagg_dpp(const PAgg &v) {  // lanes without a source read the identity
     return PAgg{(u32)__builtin_amdgcn_update_dpp((int)PX_ID, (int)v.x, CTRL, ROW_MASK, 0xf, false),
@@ -264,78 +248,55 @@ __device__ __forceinline__ Agg wave_inclusive(Agg v, int lane) {
 // tokens in front of the tile, [4 + S2_TILE] the one behind it
 static constexpr int KIND_LDS = S2_TILE + 8;
 
-__device__ __forceinline__ void tile_elements(const u8 *s_glut, const u8 *s_kind, u32 n, u32 base, int j0,
-                                              const u32 (&copied)[S2_ITEMS], Agg (&e)[S2_ITEMS]) {
+// the four elements of a thread: kv = its packed kinds, the neighbours come from the LDS image
+__device__ __forceinline__ void tile_elements(const u32 *s_elut, const u8 *s_kind, u32 n, u32 base, int tid, u32 kv,
+                                              const u32 (&copied)[S2_ITEMS], PAgg (&e)[S2_ITEMS]) {
+    const u32 *k32 = reinterpret_cast<const u32 *>(s_kind);
+    const u32 prev = k32[tid], next = k32[tid + 2];
+    const u64 w = (u64)(prev >> 16) | ((u64)kv << 16) | ((u64)(next & 0xffu) << 48);
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        const u32 i = base + k;
-        const int j = 4 + j0 + k;
-        e[k] = i < n ? token_element(s_glut, i, n, s_kind[j], s_kind[j - 1], s_kind[j - 2], s_kind[j + 1], copied[k])
-                     : agg_identity();
-    }
+    for (int k = 0; k < S2_ITEMS; k++)
+        e[k] = base + k < n ? token_pelement(s_elut, (u32)(w >> (8 * k)), copied[k]) : PAgg{PX_ID, 0u, 0u};
 }
 
-// ---- pass 1: token kinds + tile aggregates ---------------------------------------------------------------------
-__global__ __launch_bounds__(S2_BLOCK) void k_s2_reduce(S2Dev p) {
-    __shared__ u8 s_glut[1024];
-    __shared__ u8 s_klut[256];
-    __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
-    __shared__ PAgg s_w[S2_WAVES];
+// ---- pass 1: tile aggregates ------------------------------------------------------------------------------------
+// 256 threads x 16 tokens: a thread reads its 16 kinds with one 16-byte load; the neighbours' kinds come from LDS.
+static constexpr int RD_BLOCK = 256, RD_ITEMS = S2_TILE / RD_BLOCK;
+static_assert(RD_ITEMS == 16, "one uint4 of kinds per thread");
+__global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
+    __shared__ u32 s_elut[LUT_SIZE];
+    __shared__ __attribute__((aligned(16))) u32 s_k[RD_BLOCK * 4 + 8];  // dword 4 + 4 * tid: the thread's kinds
+    __shared__ PAgg s_w[RD_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_glut[tid] = c_glut.v[tid];
-    if (tid < 256) s_klut[tid] = c_klut.v[tid];
-    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
-    u32 ps[S2_ITEMS] = {0, 0, 0, 0};
-    if (base + 3 < p.n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p.pos + base);
-        ps[0] = v.x; ps[1] = v.y; ps[2] = v.z; ps[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++)
-            if (base + k < p.n) ps[k] = p.pos[base + k];
+    s_elut[tid] = c_elut.v[tid];
+    s_elut[tid + 256] = c_elut.v[tid + 256];
+    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * RD_ITEMS;
+    constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
+    uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
+    if (base + RD_ITEMS <= p.n) {
+        kv = *reinterpret_cast<const uint4 *>(p.kind + base);
+    } else if (base < p.n) {
+        u32 d[4] = {NL4, NL4, NL4, NL4};
+        for (u32 j = 0; base + j < p.n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[base + j] << (8 * (j & 3)));
+        kv = make_uint4(d[0], d[1], d[2], d[3]);
     }
-    u8 b[S2_ITEMS];
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) b[k] = base + k < p.n ? p.msg[ps[k]] : (u8)0;
-    // the neighbours of the tile: two tokens in front, one behind
-    u8 hb = 0;
-    bool hv = false;
-    if (tid < 2 && t0 + (u32)tid >= 2u) {
-        hb = p.msg[p.pos[t0 + (u32)tid - 2u]];
-        hv = true;
-    } else if (tid == 2 && (u64)t0 + S2_TILE < p.n) {
-        hb = p.msg[p.pos[t0 + S2_TILE]];
-        hv = true;
-    }
-    __syncthreads();
-    auto kind_of = [&](u8 c) {
-        const u8 k = s_klut[c];
-        return (k == K_NL && !p.ndjson) ? (u8)K_BAD : k;
-    };
-    u8 kd[S2_ITEMS];
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) kd[k] = base + k < p.n ? kind_of(b[k]) : (u8)K_BAD;
-    const u32 packed = (u32)kd[0] | ((u32)kd[1] << 8) | ((u32)kd[2] << 16) | ((u32)kd[3] << 24);
-    *reinterpret_cast<u32 *>(&s_kind[4 + tid * S2_ITEMS]) = packed;
-    if (base + 3 < p.n) {
-        *reinterpret_cast<u32 *>(p.kind + base) = packed;
-    } else {
-#pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++)
-            if (base + k < p.n) p.kind[base + k] = kd[k];
-    }
-    if (tid < 2) s_kind[2 + tid] = hv ? kind_of(hb) : (u8)K_BAD;
-    if (tid == 2) s_kind[4 + S2_TILE] = hv ? kind_of(hb) : (u8)K_BAD;
+    *reinterpret_cast<uint4 *>(&s_k[4 + 4 * tid]) = kv;
+    if (tid == 0)  // the two tokens in front of the tile (K_NONE in front of the message)
+        s_k[3] = t0 == 0 ? 0x01010101u * K_NONE : ((u32)p.kind[t0 - 2] << 16) | ((u32)p.kind[t0 - 1] << 24);
+    if (tid == 1) s_k[4 + 4 * RD_BLOCK] = (u64)t0 + S2_TILE < p.n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL;
     // selective copy (WithCopyStrings(false)): a string goes to Strings.B only if unescaping changes it, so every
     // string is measured here (parseStringSimdValidateOnly); with copy_strings the emit masks give the lengths
-    u32 copied[S2_ITEMS] = {0, 0, 0, 0};
+    u32 copied[RD_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RD_ITEMS; k++) copied[k] = 0;
+    const u32 kd4[4] = {kv.x, kv.y, kv.z, kv.w};
     if (!p.sv.qm) {
         const MsgView mv{p.msg, p.len};
 #pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++) {
-            if (kd[k] != K_STRING) continue;
+        for (int k = 0; k < RD_ITEMS; k++) {
+            if (base + k >= p.n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
             u32 sl, dl, out;
-            if (!string_walk(mv, ps[k], nullptr, &sl, &dl)) {
+            if (!string_walk(mv, p.pos[base + k], nullptr, &sl, &dl)) {
                 out = DLEN_INVALID;
                 atomicOr(&p.st->err, 1u);
             } else {
@@ -347,12 +308,24 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_reduce(S2Dev p) {
         }
     }
     __syncthreads();
-    Agg e[S2_ITEMS];
-    tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
-    const PAgg mine = pagg_pack(agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3])));
-    PAgg total;
-    (void)pagg_block_exclusive(mine, s_w, lane, wave, total);
-    if (tid == 0) p.agg[blockIdx.x].a = pagg_unpack(total);
+    // byte stream: two kinds of the thread in front, the 16 own ones, one of the thread behind
+    const u32 D[6] = {s_k[3 + 4 * tid], kv.x, kv.y, kv.z, kv.w, s_k[8 + 4 * tid]};
+    PAgg acc = PAgg{PX_ID, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < RD_ITEMS; k++) {
+        const int off = 2 + k;  // byte offset of ppk in the stream
+        const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
+        const PAgg e = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : PAgg{PX_ID, 0u, 0u};
+        acc = pagg_combine(acc, e);
+    }
+    const PAgg incl = pagg_wave_inclusive(acc);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        PAgg tot = s_w[0];
+        for (int w = 1; w < RD_BLOCK / 64; w++) tot = pagg_combine(tot, s_w[w]);
+        p.agg[blockIdx.x].a = pagg_unpack(tot);
+    }
 }
 
 // ---- pass 2: one block, exclusive scan over the tile aggregates (in place) + totals ---------------------------
@@ -406,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
 // for all four tokens of a thread before the first use: one memory round trip per tile, not one per token.
 // Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
 __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
-    __shared__ u8 s_glut[1024];
+    __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
     __shared__ PAgg s_w[S2_WAVES];
@@ -416,25 +389,25 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    s_glut[tid] = c_glut.v[tid];
+    if (tid < (int)LUT_SIZE) s_elut[tid] = c_elut.v[tid];
     if (tid == 0) s_cnt = 0;
     const u32 endpos = (u32)p.len;
     uint4 pv = make_uint4(endpos, endpos, endpos, endpos);
-    u32 kv = 0;  // K_BAD x4
+    u32 kv = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     if (base + 3 < p.n) {
         pv = *reinterpret_cast<const uint4 *>(p.pos + base);
         kv = *reinterpret_cast<const u32 *>(p.kind + base);
     } else {
-        if (base < p.n) { pv.x = p.pos[base]; kv |= (u32)p.kind[base]; }
-        if (base + 1 < p.n) { pv.y = p.pos[base + 1]; kv |= (u32)p.kind[base + 1] << 8; }
-        if (base + 2 < p.n) { pv.z = p.pos[base + 2]; kv |= (u32)p.kind[base + 2] << 16; }
+        if (base < p.n) { pv.x = p.pos[base]; kv = (kv & 0xffffff00u) | (u32)p.kind[base]; }
+        if (base + 1 < p.n) { pv.y = p.pos[base + 1]; kv = (kv & 0xffff00ffu) | ((u32)p.kind[base + 1] << 8); }
+        if (base + 2 < p.n) { pv.z = p.pos[base + 2]; kv = (kv & 0xff00ffffu) | ((u32)p.kind[base + 2] << 16); }
     }
     *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS]) = pv;
     *reinterpret_cast<u32 *>(&s_kind[4 + tid * S2_ITEMS]) = kv;
-    if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_BAD;
+    if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_NONE;
     if (tid == 2) {
         const bool more = (u64)t0 + S2_TILE < p.n;
-        s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_BAD;
+        s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_NL;
         s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
     }
     const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
@@ -480,29 +453,31 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             em1[k] = p.em[a1 >> 6];
         }
     }
-    Agg e[S2_ITEMS];
-    tile_elements(s_glut, s_kind, p.n, base, tid * S2_ITEMS, copied, e);
-    const PAgg mine = pagg_pack(agg_combine(agg_combine(e[0], e[1]), agg_combine(e[2], e[3])));
+    PAgg e[S2_ITEMS];
+    tile_elements(s_elut, s_kind, p.n, base, tid, kv, copied, e);
+    const PAgg mine = pagg_combine(pagg_combine(e[0], e[1]), pagg_combine(e[2], e[3]));
     PAgg total;
-    const PAgg local = pagg_block_exclusive(mine, s_w, lane, wave, total);
-    Agg run = agg_combine(p.agg[blockIdx.x].a, pagg_unpack(local));  // exclusive prefix of this thread's first token
+    PAgg lp = pagg_block_exclusive(mine, s_w, lane, wave, total);  // prefix inside the tile, in front of this thread
+    const Agg tp = p.agg[blockIdx.x].a;                            // prefix of the tile
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 i = base + k;
         if (i >= p.n) break;
         const u8 kd = (u8)((kv >> (8 * k)) & 0xffu);
-        const u32 o = run.w + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-        if ((e[k].am & AM_ALL) == 0) bad = true;  // legal in no context at all
+        const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
+        if (((e[k].x >> 28) & AM_ALL) == 0) bad = true;  // legal in no context at all
         switch (kd) {
         case K_OPEN_OBJ:
         case K_OPEN_ARR:
         case K_CLOSE_OBJ:
         case K_CLOSE_ARR: {
-            const u32 c = run.bc;  // brackets in front of this one
-            p.br_depth[c] = run.d + e[k].d;
+            const u32 lbc = (lp.x >> 14) & 0x1fffu;
+            const u32 c = tp.bc + lbc;  // brackets in front of this one
+            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
+            p.br_depth[c] = d_before + (is_open(kd) ? 1 : -1);
             p.br_off[c] = o;
-            p.br_info[c] = (u8)(kd | (gap_mask(run, e[k]) << 4));
+            p.br_info[c] = (u8)(kd | ((am_combine(am_combine(tp.am, lp.x >> 28), e[k].x >> 28) & AM_ALL) << 4));
             break;
         }
         case K_TRUE:
@@ -530,17 +505,18 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
                 p.tape[o + 1] = se - so;
             } else if (dl[k] != DLEN_INVALID) {
                 const bool cp = (dl[k] & DLEN_COPY) != 0;
-                p.tape[o] = string_word(cp, p.strings_base + run.s, p.msg_base + pp[k] + 1);
+                const u32 so = tp.s + lp.s;
+                p.tape[o] = string_word(cp, p.strings_base + so, p.msg_base + pp[k] + 1);
                 p.tape[o + 1] = dl[k] & ~DLEN_COPY;
-                p.str_off[i] = run.s;
+                p.str_off[i] = so;
             }
             break;
         case K_NL:
-            if (e[k].nb) p.nl_off[run.nb] = o;
+            if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
             break;
         default: break;
         }
-        run = agg_combine(run, e[k]);
+        lp = pagg_combine(lp, e[k]);
     }
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
     // the tile's numbers move to the global queue (coalesced; the order of the queue does not matter)
@@ -685,7 +661,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = sizeof(S2State) + 256;
-    b += align_up(n + 16, 256) * 2;                 // kind, br_info
+    b += align_up(n + 16, 256);                     // br_info
     b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
@@ -698,7 +674,7 @@ size_t stage2_workspace_bytes(size_t n) {
 }
 
 // carve the device view out of the workspace (deterministic: both phases rebuild the same view)
-static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
+static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags, void *ws, u64 *d_tape,
                          size_t tape_cap, u8 *d_strings, size_t strings_cap, void *str_aux) {
     S2Dev p;
     char *w = reinterpret_cast<char *>(ws);
@@ -714,7 +690,7 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
     p.n = (u32)n;
     p.ndjson = flags & 1u;
     p.copy_strings = (flags >> 1) & 1u;
-    p.kind = reinterpret_cast<u8 *>(carve(n + 16));
+    p.kind = d_kind;
     p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
     p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
@@ -770,9 +746,9 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, size_t
 
 // Phase 1: token kinds and the device-wide scan of the tile aggregates.  Afterwards S2State holds tape_len /
 // strings_len of this message (what an NDJSON shard exchanges with the other shards).
-hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws,
-                                 hipStream_t stream, void *str_aux) {
-    const S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
+hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,
+                                 void *ws, hipStream_t stream, void *str_aux) {
+    const S2Dev p = stage2_view(d_msg, len, d_pos, d_kind, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
     hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
     if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
@@ -780,7 +756,7 @@ hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos
         hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(k_str_scan, dim3(1), dim3(1024), 0, stream, p);
     }
-    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_s2_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
@@ -788,10 +764,10 @@ hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos
 // Phase 2: tape words, bracket matching with the grammar check, roots and Strings.B.  The three bases rebase
 // every index the tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message, the
 // exclusive prefix sums over the preceding shards for an NDJSON shard.
-hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
-                              size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base, u64 strings_base,
-                              u64 msg_base, hipStream_t stream, void *str_aux) {
-    S2Dev p = stage2_view(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, str_aux);
+hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,
+                              void *ws, u64 *d_tape, size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base,
+                              u64 strings_base, u64 msg_base, hipStream_t stream, void *str_aux) {
+    S2Dev p = stage2_view(d_msg, len, d_pos, d_kind, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, str_aux);
     p.tape_base = tape_base;
     p.strings_base = strings_base;
     p.msg_base = msg_base;
@@ -809,14 +785,6 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, s
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
     return hipGetLastError();
-}
-
-hipError_t stage2_launch(const void *d_msg, size_t len, const u32 *d_pos, size_t n, u32 flags, void *ws, u64 *d_tape,
-                         size_t tape_cap, u8 *d_strings, size_t strings_cap, hipStream_t stream) {
-    hipError_t e = stage2_launch_measure(d_msg, len, d_pos, n, flags, ws, stream, nullptr);
-    if (e != hipSuccess) return e;
-    return stage2_launch_emit(d_msg, len, d_pos, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, 0, 0, 0, stream,
-                              nullptr);
 }
 
 }  // namespace sj
