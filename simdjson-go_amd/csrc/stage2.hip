@@ -12,8 +12,8 @@
 //                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
 //                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
 //                    separate records leave their tape offset
-//   k_min_level*, k_brackets   previous-smaller-value over the compact bracket view: partners' tape words,
-//                    container contexts, and the grammar check of every gap against its context
+//   k_min_level*, k_br_match, k_br_check   previous-smaller-value over the compact bracket view: partners' tape
+//                    words, container contexts, and the grammar check of every gap against its context
 //   k_roots          root words
 // plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
 #include <hip/hip_runtime.h>
@@ -58,6 +58,8 @@ struct S2Dev {
     i32 *br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
     u32 *br_off;   // [n]                       its tape offset
     u8 *br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
+    u32 *br_match; // [n]                       close: its partner (k_br_match)
+    u8 *br_pctx;   // [n]                       open: the context in front of it
     TileAgg *agg;  // [tiles] aggregates, then (k_s2_scan_tiles) exclusive prefixes
     u32 tiles;
     // min tree levels 1.. (level 0 is br_depth[])
@@ -603,15 +605,120 @@ __global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
 
 
 // ---- bracket partners, contexts and the grammar check of every gap ----------------------------------------------
-__global__ __launch_bounds__(256) void k_brackets(S2Dev p) {
+// Every bracket asks one previous-smaller-value question over the compact view (sj_stage2.h: bracket_resolve is the
+// per-bracket statement): a close for its partner, an open for its parent.  Because consecutive depths differ
+// by one, "the last bracket in front with depth <= q" is the last one with depth == q as long as the brackets
+// in between are deeper, so a wave answers the 64 questions of one group with ballots over its own 64 depths
+// (no memory traffic, no serial walk); what is not answered inside the group is looked up in the group in
+// front and then through the min tree, the whole wave loading 64 entries per step.
+__device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); }  // m != 0
+
+// last k < `idx` with lev[L][k] <= v, resolved down to level 0 (wave-cooperative, uniform arguments); -1: none
+__device__ i64 wave_psv_tree(const MinTree &mt, int L, u64 idx, i32 v, int lane) {
+    u64 h = 0;
+    for (;;) {
+        if (idx == 0) return -1;
+        const u64 hb = ((idx - 1) >> 6) << 6;
+        const u64 e = hb + (u64)lane;
+        const i32 val = e < idx ? mt.lev[L][e] : 0x7fffffff;
+        const u64 m = __ballot(val <= v);
+        if (m) {
+            h = hb + (u64)top_bit(m);
+            break;
+        }
+        if (hb == 0 || L + 1 >= mt.nlev) return -1;
+        idx = hb >> 6;
+        L++;
+    }
+    while (L > 0) {
+        L--;
+        const u64 e = (h << 6) + (u64)lane;
+        const i32 val = e < mt.size[L] ? mt.lev[L][e] : 0x7fffffff;
+        const u64 m = __ballot(val <= v);  // not empty: the parent entry is the minimum of these
+        h = (h << 6) + (u64)top_bit(m);
+    }
+    return (i64)h;
+}
+
+static constexpr u32 BR_NONE = 0xffffffffu;
+__global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
     const u32 n_br = p.st->n_br;
     const MinTree mt = make_tree(p);
+    const int lane = threadIdx.x & 63;
+    const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
+    const u32 waves = gridDim.x * 4;
+    for (u32 g = blockIdx.x * 4 + (threadIdx.x >> 6); (u64)g * 64 < n_br; g += waves) {  // wave-uniform
+        const u32 c = g * 64 + (u32)lane;
+        const bool valid = c < n_br;
+        const i32 dep = valid ? p.br_depth[c] : 0x7fffffff;
+        const u8 kd = valid ? (u8)(p.br_info[c] & 15u) : (u8)K_BAD;
+        const bool close = is_close(kd);
+        const i32 q = close ? dep : dep - 2;  // a close looks for its partner, an open for its parent
+        const bool need = valid && q >= 0;
+        i64 res = -1;      // compact index of the bracket in front of the partner / parent
+        bool pend = need;  // not answered yet
+        // inside the group: one ballot per distinct q
+        for (u64 pm = __ballot(pend); pm != 0;) {
+            const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pm));
+            const u64 at = __ballot(dep == v) & lt;
+            const bool mine = need && q == v;
+            if (mine && at != 0) {
+                res = (i64)g * 64 + top_bit(at);
+                pend = false;
+            }
+            pm &= ~__ballot(mine);
+        }
+        // the group in front, then the tree: one question per distinct q that is still open
+        u64 pm = __ballot(pend);
+        if (pm != 0 && g > 0) {
+            const i32 pd = p.br_depth[(u64)(g - 1) * 64 + lane];
+            while (pm != 0) {
+                const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pm));
+                const u64 at = __ballot(pd <= v);
+                const i64 k = at ? (i64)(g - 1) * 64 + top_bit(at)
+                                 : (mt.nlev > 1 ? wave_psv_tree(mt, 1, (u64)(g - 1), v, lane) : -1);
+                const bool mine = pend && q == v;
+                if (mine) {
+                    res = k;
+                    pend = false;
+                }
+                pm &= ~__ballot(mine);
+            }
+        }
+        if (!valid) continue;
+        const u32 j = (u32)(res + 1);  // partner (close) / parent (open); bracket 0 if nothing was found
+        if (close) {
+            if (q >= 0) {  // payloads: annotate_previousloc (stage2_build_tape_amd64.go:335-336)
+                const u32 oc = p.br_off[c], oj = p.br_off[j];
+                const u8 jk = (u8)(p.br_info[j] & 15u);
+                p.tape[oc] = ((u64)(kd == K_CLOSE_OBJ ? '}' : ']') << 56) | (p.tape_base + oj);
+                p.tape[oj] = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
+                p.br_match[c] = j;
+            } else {
+                p.br_match[c] = BR_NONE;  // closes nothing: its gap mask rejects it (a close needs OBJ / ARR)
+            }
+        } else {  // the context in front of an open bracket = the type of its parent
+            p.br_pctx[c] = q >= 0 ? ((p.br_info[j] & 15u) == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR) : (u8)CTX_ROOT;
+        }
+    }
+}
+
+// the context behind every bracket against the allowed contexts of the gap that follows it
+__global__ __launch_bounds__(256) void k_br_check(S2Dev p) {
+    const u32 n_br = p.st->n_br;
     bool bad = false;
-    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256) {  // compact bracket index
-        const u8 ctx = bracket_resolve(mt, p.br_off, p.br_info, c, p.tape_base, p.tape);
+    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256) {
+        const u8 info = p.br_info[c], kd = info & 15u;
+        u8 ctx;
+        if (kd == K_OPEN_OBJ) ctx = CTX_OBJ;
+        else if (kd == K_OPEN_ARR) ctx = CTX_ARR;
+        else {  // behind a close the context in front of its partner resumes
+            const u32 j = p.br_match[c];
+            ctx = j == BR_NONE ? (u8)CTX_ROOT : p.br_pctx[j];
+        }
         const u32 next = c + 1 < n_br ? (u32)(p.br_info[c + 1] >> 4) : p.st->tail_mask;  // the gap behind bracket c
         bad |= !context_allowed(next, ctx);
-        if (c == 0) bad |= !context_allowed((u32)(p.br_info[0] >> 4), CTX_ROOT);
+        if (c == 0) bad |= !context_allowed((u32)(info >> 4), CTX_ROOT);
     }
     if (bad) atomicOr(&p.st->err, 1u);
 }
@@ -661,8 +768,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = sizeof(S2State) + 256;
-    b += align_up(n + 16, 256);                     // br_info
-    b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
+    b += align_up(n + 16, 256) * 2;                 // br_info br_pctx
+    b += align_up(n * 4, 256) * 10;                 // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off br_match
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
@@ -692,6 +799,8 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
     p.copy_strings = (flags >> 1) & 1u;
     p.kind = d_kind;
     p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
+    p.br_pctx = reinterpret_cast<u8 *>(carve(n + 16));
+    p.br_match = reinterpret_cast<u32 *>(carve(n * 4));
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
     p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
     p.nl_off = reinterpret_cast<u32 *>(carve(n * 4));
@@ -779,7 +888,8 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, c
         const u64 want = (p.lev_size[l] + 3) / 4;
         hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
     }
-    hipLaunchKernelGGL(k_brackets, dim3(gb < 8192 ? gb : 8192), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_br_check, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_roots, dim3(256), dim3(256), 0, stream, p);
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
