@@ -185,7 +185,11 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     u64 masks_total = 0;
     if (copy) {
         for (size_t c = 0; c < used_units * 64; c++)
-            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c])) bad = 1;
+        {
+            bool esc_flag;
+            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c], &esc_flag)) bad = 1;
+            if (esc_flag != str_chunk_has_escapes(sv, c)) return 96;
+        }
         for (size_t u = 0; u < used_units; u++) {
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
@@ -232,11 +236,11 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         const Agg e = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), copied[i]);
         {  // the packed table form the kernels use must be the same element
             const PAgg pe = token_pelement(ELUT.v, kind_window(kind.data(), (u32)i, (u32)n), copied[i]), want = pagg_pack(e);
-            if (pe.x != want.x || pe.y != want.y || pe.s != want.s) return 97;
+            if (pe.x != want.x || pe.y != want.y || pe.z != want.z || pe.s != want.s) return 97;
         }
         toff[i] = run.w + 1u;
         soff[i] = run.s;
-        if ((e.am & AM_ALL) == 0) bad = 1;
+        if (am_value(e.am) == 0) bad = 1;
         if (is_bracket(kind[i])) {
             br_depth.push_back(run.d + e.d);
             br_off.push_back(toff[i]);
@@ -250,7 +254,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     if (copy) sbytes = masks_total;
     const u32 tlen = (u32)words + 2;  // + opening and closing root
     if (run.d != 0) bad = 1;
-    const u32 tail_mask = is_bracket(kind[n - 1]) ? AM_ALL : (run.am & AM_ALL);
+    const u32 tail_mask = is_bracket(kind[n - 1]) ? AM_ALL : am_value(run.am);
     u64 *tape = (u64 *)calloc(tlen + 2, sizeof(u64));
     u8 *strs = (u8 *)malloc(sbytes + 64);
     for (size_t i = 0; i < n; i++) {
@@ -307,10 +311,15 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         if (c == 0 && !context_allowed((u32)(br_info[0] >> 4), CTX_ROOT)) bad = 1;
     }
     if (n_br == 0) bad = 1;  // unreachable: token 0 must be an open bracket
-    if (copy && !bad)  // k_str_emit
-        for (size_t c = 0; c < used_units * 64; c++)
-            str_chunk_emit(sv, c, v_em[c], v_um[c], c ? v_um[c - 1] : 0ull, strs + v_ucnt[c >> 6] + v_pre[c],
-                           [&](u32 p) { return sv.at(c * 64 + p); });
+    if (copy && !bad)  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
+        for (size_t c = 0; c < used_units * 64; c++) {
+            if (v_em[c] == 0) continue;
+            u8 chunk[64];
+            for (u32 q = 0; q < 64; q++) chunk[q] = sv.at(c * 64 + q);
+            if (str_chunk_has_escapes(sv, c)) str_chunk_patch(sv, c, [&](u32 q, u8 v) { chunk[q] = v; });
+            u8 *dst = strs + v_ucnt[c >> 6] + v_pre[c];
+            for (u64 r = v_em[c]; r != 0; r &= r - 1) *dst++ = chunk[ctz64(r)];
+        }
     for (u32 r = 0; r <= nl_off.size(); r++) emit_root(nl_off.data(), (u32)nl_off.size(), tlen, r, tape, tape_base);  // k_roots
     if (bad) {
         free(tape);

@@ -394,9 +394,8 @@ constexpr KindLut make_kind_lut() {
 }
 // The same index also selects everything else a token contributes to the scan except what depends on the
 // NEXT token (a newline writes its root pair only as the last one of its run): one 32-bit entry per index,
-//   bits 0-1 tape words (newline: 0) | bit 14 bracket | bit 27 open bracket | bits 28-30 allowed contexts |
-//   bit 31 "a gap starts here" (the previous token is a bracket)
-// i.e. the packed in-tile form of the scan element (stage2.hip, PAgg) with the open-bracket count in bit 27.
+//   bits 0-1 tape words (newline: 0) | bit 14 bracket | bit 24 open bracket | bits 26-31 the context function
+// i.e. the packed in-tile form of the scan element (PAgg below) in one word.
 struct ElementLut {
     u32 v[LUT_SIZE];
 };
@@ -406,23 +405,31 @@ constexpr ElementLut make_element_lut() {
         const u8 k = (u8)(x & 15u), pk = (u8)((x >> 4) & 15u);
         const bool first = pk == K_NONE;
         const u32 w = k == K_NL ? 0u : tape_words(k, (u8)K_BAD, false);
-        t.v[x] = w | (is_bracket(k) ? 1u << 14 : 0u) | (is_open(k) ? 1u << 27 : 0u) | ((u32)allowed_contexts_at(x) << 28) |
-                 ((!first && is_bracket(pk)) ? 1u << 31 : 0u);
+        const u32 A = allowed_contexts_at(x);
+        const u32 z = (!first && is_bracket(pk)) ? A << 3 : A;  // a gap starts behind a bracket
+        t.v[x] = w | (is_bracket(k) ? 1u << 14 : 0u) | (is_open(k) ? 1u << 24 : 0u) | (z << 26);
     }
     return t;
 }
 
 // ---- the device-wide scan ---------------------------------------------------------------------------------
 // One element per token; the inclusive/exclusive prefixes give every token its depth, tape offset, Strings.B
-// offset (only when strings are copied selectively), record ordinal, compact bracket index, and the AND of the
-// allowed-context sets since the last bracket (am: bits 0-2 the set, bit 3 "a segment starts inside").
+// offset (only when strings are copied selectively), record ordinal, compact bracket index, and the allowed
+// contexts of the gap it lies in.  The last one is a segmented AND (segments start behind brackets); it is
+// carried as the function it applies to the set v in front of it, v -> (v & p) | q, stored as am = p | q << 3:
+// a token inside a gap is (A, 0), the first token of a gap is (0, A), and functions compose with two bit
+// operations (am_combine).  Applied to "all contexts" it yields the set itself: am_value.
 struct Agg {
     i32 d;
     u32 w, s, nb, bc, am;
 };
-static constexpr u32 AM_ALL = 7u, AM_START = 8u;
+static constexpr u32 AM_ALL = 7u;  // also the identity function (p = all, q = none)
 SJ_HD Agg agg_identity() { return Agg{0, 0u, 0u, 0u, 0u, AM_ALL}; }
-SJ_HD u32 am_combine(u32 a, u32 b) { return (b & AM_START) ? b : ((a & b & AM_ALL) | (a & AM_START)); }
+SJ_HD u32 am_combine(u32 a, u32 b) {  // a in front of b
+    const u32 bp = b & 7u;
+    return (a & (bp | (bp << 3))) | (b & 0x38u);
+}
+SJ_HD u32 am_value(u32 am) { return (am | (am >> 3)) & AM_ALL; }
 SJ_HD Agg agg_combine(const Agg &a, const Agg &b) {  // a in front of b
     return Agg{a.d + b.d, a.w + b.w, a.s + b.s, a.nb + b.nb, a.bc + b.bc, am_combine(a.am, b.am)};
 }
@@ -439,29 +446,29 @@ SJ_HD Agg token_element(u32 i, u32 n, u8 k, u8 pk, u8 ppk, u8 nk, u32 copied) {
     u32 allowed = 0;
     for (u8 G = 0; G < 3; G++)
         if (!grammar_violation_v(i, k, pk, ppk, G)) allowed |= 1u << G;
-    a.am = allowed | ((i > 0 && is_bracket(pk)) ? AM_START : 0u);  // a gap starts after a bracket
+    a.am = (i > 0 && is_bracket(pk)) ? allowed << 3 : allowed;  // a gap starts behind a bracket
     return a;
 }
 // allowed contexts of the gap that ends with token i (x = exclusive prefix, e = its element)
-SJ_HD u32 gap_mask(const Agg &x, const Agg &e) { return am_combine(x.am, e.am) & AM_ALL; }
+SJ_HD u32 gap_mask(const Agg &x, const Agg &e) { return am_value(am_combine(x.am, e.am)); }
 
 // ---- packed form of the scan inside one 4096-token tile ----------------------------------------------------------
 // Inside a tile every quantity fits a few bits:
-//   x = w (14 bits) | bc << 14 (13 bits) | am << 28        y = opens (13 bits) | nb << 13        s = Strings.B bytes
-// (depth = 2 * opens - brackets).
+//   x = w (14 bits) | bc << 14 (13 bits)      y = opens (13 bits) | nb << 13      z = am      s = Strings.B bytes
+// (depth = 2 * opens - brackets); x, y and s simply add.
 struct PAgg {
-    u32 x, y, s;
+    u32 x, y, z, s;
 };
-static constexpr u32 PX_SUM = 0x0fffffffu, PX_ID = AM_ALL << 28;
+SJ_HD PAgg pagg_identity() { return PAgg{0u, 0u, AM_ALL, 0u}; }
 SJ_HD PAgg pagg_pack(const Agg &a) {
-    return PAgg{a.w | (a.bc << 14) | (a.am << 28), (u32)((a.d + (i32)a.bc) >> 1) | (a.nb << 13), a.s};
+    return PAgg{a.w | (a.bc << 14), (u32)((a.d + (i32)a.bc) >> 1) | (a.nb << 13), a.am, a.s};
 }
 SJ_HD Agg pagg_unpack(const PAgg &v) {
-    const u32 bc = (v.x >> 14) & 0x1fffu, op = v.y & 0x1fffu;
-    return Agg{(i32)(2u * op) - (i32)bc, v.x & 0x3fffu, v.s, v.y >> 13, bc, v.x >> 28};
+    const u32 bc = v.x >> 14, op = v.y & 0x1fffu;
+    return Agg{(i32)(2u * op) - (i32)bc, v.x & 0x3fffu, v.s, v.y >> 13, bc, v.z};
 }
 SJ_HD PAgg pagg_combine(const PAgg &a, const PAgg &b) {  // a in front of b
-    return PAgg{((a.x & PX_SUM) + (b.x & PX_SUM)) | (am_combine(a.x >> 28, b.x >> 28) << 28), a.y + b.y, a.s + b.s};
+    return PAgg{a.x + b.x, a.y + b.y, am_combine(a.z, b.z), a.s + b.s};
 }
 // Packed scan element of a token from the kinds (ppk, pk, k, nk) in the four bytes of `win`, through the table
 // (token_element is the reference form; the table is generated from the same rules).  Missing neighbours are
@@ -469,14 +476,13 @@ SJ_HD PAgg pagg_combine(const PAgg &a, const PAgg &b) {  // a in front of b
 // writes no root pair).
 SJ_HD PAgg token_pelement(const u32 *elut, u32 win, u32 copied) {
     const u32 ppk = win & 0xffu, pk = (win >> 8) & 0xffu, k = (win >> 16) & 0xffu, nk = win >> 24;
-    u32 x = elut[grammar_lut_index((u8)k, (u8)pk, (u8)ppk)];
-    u32 y = (x >> 27) & 1u;  // open bracket
-    x &= ~(1u << 27);
+    const u32 e = elut[grammar_lut_index((u8)k, (u8)pk, (u8)ppk)];
+    u32 x = e & 0x4003u, y = (e >> 24) & 1u;
     if (k == K_NL && nk != K_NL) {  // the last newline of a run separates two records: root pair
         x += 2u;
         y |= 1u << 13;
     }
-    return PAgg{x, y, copied};
+    return PAgg{x, y, e >> 26, copied};
 }
 // the kinds around token i of a kind array, with the sentinels
 SJ_HD u32 kind_window(const u8 *kind, u32 i, u32 n) {

@@ -14,7 +14,7 @@
 //         position (the starter emits nothing); a \uXXXX escape owns the five positions 'u',X,X,X,X and emits
 //         its n = 1..3 UTF-8 bytes at the first n of them; a surrogate pair emits 4 bytes at the high
 //         half's positions and nothing at the low half's.
-//   UM  = positions of the 'u' of unicode escapes inside strings.
+//   UM  = positions of the 'u' of unicode escapes inside strings (kept for inspection; pass 2 re-derives them).
 // E(a) = emitted bytes in front of aligned offset a = unit_base[a>>12] + chunk_pre[a>>6] + popc(EM & below),
 // which gives every string token its Strings.B offset and unescaped length without walking the string.
 // All quirks of the reference's string parser are kept (sj_stage2.h string_walk is the per-string
@@ -125,16 +125,26 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
     return r;
 }
 
+// chunk_pre[] entries: bits 0-14 the emitted bytes of the unit in front of the chunk, bit 15 "the chunk takes
+// the byte-serial pass 2" (it holds an escape, or a unicode escape of the previous chunk reaches into it)
+static constexpr u32 CHUNK_PRE_MASK = 0x7fffu, CHUNK_SLOW = 0x8000u;
+SJ_HD bool str_chunk_has_escapes(const StrView &m, u64 c) {
+    if ((m.esc(c) & m.sm(c)) != 0) return true;
+    return c > 0 && ((m.esc(c - 1) & m.sm(c - 1)) >> 60) != 0;
+}
+
 // Pass 1, one chunk: the emit mask and the 'u' mask of chunk c; returns false on an invalid escape.
-SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out) {
+SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bool *escapes_out = nullptr) {
     const u64 sm = m.sm(c);
     const u64 e = m.esc(c) & sm;  // escaped characters inside strings
     u64 em = sm & ~m.st[c];
     u64 um = 0;
     bool ok = true;
+    bool escapes = e != 0;  // == str_chunk_has_escapes(m, c)
     // escapes whose 'u' lies in the last four bytes of the previous chunk reach into this one
     if (c > 0) {
         u64 pe = (m.esc(c - 1) & m.sm(c - 1)) >> 60;
+        escapes |= pe != 0;
         for (u32 k = 0; pe != 0; k++, pe >>= 1) {
             if (!(pe & 1u)) continue;
             const u64 au = (c - 1) * 64 + 60 + k;
@@ -170,42 +180,43 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out) {
     }
     *em_out = em;
     *um_out = um;
+    if (escapes_out) *escapes_out = escapes;
     return ok;
 }
 
-// Pass 2, one chunk: writes the popc(em) bytes of chunk c to dst (ascending positions).
-// em / um are the masks of pass 1 (um of the previous chunk for escapes that reach into this one);
-// byte_at(p) returns byte p of the chunk (the kernel serves it from LDS, the host replay from memory).
-template <typename ByteAt>
-SJ_HD void str_chunk_emit(const StrView &m, u64 c, u64 em, u64 um, u64 um_prev, u8 *dst, ByteAt byte_at) {
-    const u64 e = m.esc(c);
-    // positions 1..4 behind a 'u' (hex digit slots): handled by the unicode path
-    const u64 uh = (um << 1) | (um << 2) | (um << 3) | (um << 4) | (um_prev >> 63) | (um_prev >> 62) | (um_prev >> 61) |
-                   (um_prev >> 60);
-    u32 o = 0;
-    for (u64 r = em; r != 0; r &= r - 1) {
+// Pass 2, one chunk: Strings.B receives the bytes of chunk c selected by its emit mask, in order, after the
+// bytes that differ from the message have been patched: put(p, v) is called for every position p (0..63) of the
+// chunk whose emitted byte is v instead of the message byte -- the character behind a simple escape, and the
+// first n positions of 'u',X,X,X,X of a unicode escape (also of one that starts in the last four bytes of the
+// previous chunk).  Same traversal as pass 1.
+template <typename Put>
+SJ_HD void str_chunk_patch(const StrView &m, u64 c, Put put) {
+    if (c > 0) {
+        u64 pe = (m.esc(c - 1) & m.sm(c - 1)) >> 60;
+        for (u32 k = 0; pe != 0; k++, pe >>= 1) {
+            if (!(pe & 1u)) continue;
+            const u64 au = (c - 1) * 64 + 60 + k;
+            if (m.at(au) != 'u') continue;
+            const UEscape u = unicode_escape(m, au);
+            for (u32 j = 1; j <= 4; j++) {
+                const u64 a = au + j;
+                if ((a >> 6) == c && j < u.n) put((u32)(a & 63), u.b[j]);
+            }
+        }
+    }
+    for (u64 r = m.esc(c) & m.sm(c); r != 0; r &= r - 1) {
         const u32 p = (u32)ctz64(r);
         const u64 a = c * 64 + p;
-        const u64 bit = 1ull << p;
-        u8 v;
-        if ((um | uh) & bit) {
-            u64 au = a;  // find the 'u' this position belongs to (itself or 1..4 positions back)
-            u32 j = 0;
-            if (!(um & bit)) {
-                for (j = 1; j <= 4; j++) {
-                    const u64 cand = a - j;
-                    const u64 cm = (cand >> 6) == c ? um : um_prev;
-                    if ((cm >> (cand & 63)) & 1u) break;
-                }
-                au = a - j;
-            }
-            v = unicode_escape(m, au).b[j];
-        } else if (e & bit) {
-            v = escape_value(byte_at(p));
-        } else {
-            v = byte_at(p);
+        const u8 b = m.at(a);
+        if (b != 'u') {
+            put(p, escape_value(b));
+            continue;
         }
-        dst[o++] = v;
+        const UEscape u = unicode_escape(m, a);
+        for (u32 j = 0; j <= 4; j++) {
+            const u64 aj = a + j;
+            if ((aj >> 6) == c && j < u.n) put((u32)(aj & 63), u.b[j]);
+        }
     }
 }
 
@@ -214,7 +225,7 @@ SJ_HD u64 emitted_before(const u32 *unit_base, const uint16_t *chunk_pre, const 
     const u64 c = a >> 6;
     const u32 bit = (u32)(a & 63);
     const u64 below = bit ? (em[c] & (~0ull >> (64 - bit))) : 0ull;
-    return (u64)unit_base[a >> 12] + chunk_pre[c] + (u64)popc64(below);
+    return (u64)unit_base[a >> 12] + (chunk_pre[c] & CHUNK_PRE_MASK) + (u64)popc64(below);
 }
 
 }  // namespace sj

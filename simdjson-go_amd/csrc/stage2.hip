@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     const int lane = threadIdx.x & 63;
     if (c >= p.units * 64) return;  // whole waves
     u64 em, um;
-    if (!str_chunk_masks(p.sv, c, &em, &um)) atomicOr(&p.st->err, 1u);
+    bool escapes;
+    if (!str_chunk_masks(p.sv, c, &em, &um, &escapes)) atomicOr(&p.st->err, 1u);
     p.em[c] = em;
     p.um[c] = um;
     const u32 n = (u32)popc64(em);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
         const u32 o = __shfl_up(incl, s, 64);
         if (lane >= s) incl += o;
     }
-    p.chunk_pre[c] = (uint16_t)(incl - n);
+    p.chunk_pre[c] = (uint16_t)((incl - n) | (escapes ? CHUNK_SLOW : 0u));
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
@@ -151,31 +152,84 @@ __global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
     if (threadIdx.x == 0) p.st->strings_len_masks = total;
 }
 
+// selector of v_perm_b32 that moves the bytes named by the 4-bit mask `nib` to the low end of a dword (zeros above)
+constexpr u32 compress_selector(u32 nib) {
+    u32 sel = 0x0c0c0c0cu;
+    int o = 0;
+    for (u32 b = 0; b < 4; b++)
+        if ((nib >> b) & 1u) {
+            sel = (sel & ~(0xffu << (8 * o))) | (b << (8 * o));
+            o++;
+        }
+    return sel;
+}
+struct SelLut {
+    u32 v[16];
+};
+constexpr SelLut make_sel_lut() {
+    SelLut t{};
+    for (u32 x = 0; x < 16; x++) t.v[x] = compress_selector(x);
+    return t;
+}
+__constant__ SelLut c_sel = make_sel_lut();
+
+// Pass 2 of the string path: one 4 KiB unit per wave, one 64-byte chunk per lane.  A chunk is compacted four
+// bytes at a time: v_perm_b32 squeezes the emitted bytes of a dword together and one unaligned LDS store
+// appends them; the up to four stale bytes such a store leaves behind the lane's data are repaired after a wave
+// barrier, when every lane rewrites the first four bytes of its own region.  Chunks with escapes (flagged by
+// k_str_masks) first patch the translated bytes into their LDS copy of the chunk (sj_strings.h).
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
-    __shared__ u32 s_in[4][16][64];       // the wave's 64 chunks, dword-major (bank = lane)
-    __shared__ u8 s_out[4][4096 + 16];    // the unit's unescaped bytes
+    __shared__ u32 s_in[4][16][64];                                  // chunks with escapes, dword-major (bank = lane)
+    __shared__ __attribute__((aligned(16))) u8 s_out[4][4096 + 16];  // the unit's unescaped bytes
+    __shared__ u32 s_sel[16];
+    if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
+    __syncthreads();
     const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (c >= p.units * 64) return;
     const u64 unit = c >> 6;
     const u64 em = p.em[c];
-    const u32 pre = p.chunk_pre[c];
+    const u32 pre_raw = p.chunk_pre[c];
+    const u32 pre = pre_raw & CHUNK_PRE_MASK;
+    const bool patched = (pre_raw & CHUNK_SLOW) != 0;
     const u32 n = (u32)popc64(em);
     const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
     if (total == 0) return;  // wave-uniform
+    u8 *out = &s_out[wave][pre];
+    u8 *in8 = reinterpret_cast<u8 *>(&s_in[wave][0][0]);
+    auto byte_ix = [&](u32 q) { return ((q >> 2) * 64 + lane) * 4 + (q & 3); };
     if (em != 0) {  // the chunk holds message bytes: its 64-byte line is readable
         const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + c * 64);
+        u32 w[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 v = src[q];
-            s_in[wave][4 * q + 0][lane] = v.x;
-            s_in[wave][4 * q + 1][lane] = v.y;
-            s_in[wave][4 * q + 2][lane] = v.z;
-            s_in[wave][4 * q + 3][lane] = v.w;
+            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
-        const u8 *in8 = reinterpret_cast<const u8 *>(&s_in[wave][0][0]);
-        str_chunk_emit(p.sv, c, em, p.um[c], c ? p.um[c - 1] : 0ull, &s_out[wave][pre],
-                       [&](u32 q) { return in8[((q >> 2) * 64 + lane) * 4 + (q & 3)]; });
+        if (patched) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) s_in[wave][q][lane] = w[q];
+            str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
+#pragma unroll
+            for (int q = 0; q < 16; q++) w[q] = s_in[wave][q][lane];
+        }
+        u32 o = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const u32 nib = (u32)(em >> (4 * q)) & 15u;
+            *reinterpret_cast<u32 *>(out + o) = __builtin_amdgcn_perm(0u, w[q], s_sel[nib]);
+            o += (u32)__builtin_popcount(nib);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (em != 0) {  // the first four bytes again: the lane in front may have left stale bytes there
+        u32 j = 0;
+        if (patched) {
+            for (u64 r = em; r != 0 && j < 4; r &= r - 1, j++) out[j] = in8[byte_ix((u32)ctz64(r))];
+        } else {
+            for (u64 r = em; r != 0 && j < 4; r &= r - 1, j++) out[j] = p.sv.base[c * 64 + (u32)ctz64(r)];
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -191,45 +245,49 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
 
 // ---- the token scan ----------------------------------------------------------------------------------------
 // Inside a tile the scan runs on the packed form PAgg (sj_stage2.h); wave scans use DPP row shifts / broadcasts
-// (no LDS traffic).
-template <int CTRL, int ROW_MASK>
+// (no LDS traffic).  S = false drops the Strings.B byte count (every string copied: the emit masks place them).
+template <bool S>
+__device__ __forceinline__ PAgg pagg_comb(const PAgg &a, const PAgg &b) {  // a in front of b
+    return PAgg{a.x + b.x, a.y + b.y, am_combine(a.z, b.z), S ? a.s + b.s : 0u};
+}
+template <bool S, int CTRL, int ROW_MASK>
 __device__ __forceinline__ PAgg pagg_dpp(const PAgg &v) {  // lanes without a source read the identity
-    return PAgg{(u32)__builtin_amdgcn_update_dpp((int)PX_ID, (int)v.x, CTRL, ROW_MASK, 0xf, false),
+    return PAgg{(u32)__builtin_amdgcn_update_dpp(0, (int)v.x, CTRL, ROW_MASK, 0xf, false),
                 (u32)__builtin_amdgcn_update_dpp(0, (int)v.y, CTRL, ROW_MASK, 0xf, false),
-                (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false)};
+                (u32)__builtin_amdgcn_update_dpp((int)AM_ALL, (int)v.z, CTRL, ROW_MASK, 0xf, false),
+                S ? (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false) : 0u};
 }
+template <bool S>
 __device__ __forceinline__ PAgg pagg_wave_inclusive(PAgg v) {
-    v = pagg_combine(pagg_dpp<0x111, 0xf>(v), v);  // row_shr:1
-    v = pagg_combine(pagg_dpp<0x112, 0xf>(v), v);  // row_shr:2
-    v = pagg_combine(pagg_dpp<0x114, 0xf>(v), v);  // row_shr:4
-    v = pagg_combine(pagg_dpp<0x118, 0xf>(v), v);  // row_shr:8
-    v = pagg_combine(pagg_dpp<0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
-    v = pagg_combine(pagg_dpp<0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
+    v = pagg_comb<S>(pagg_dpp<S, 0x111, 0xf>(v), v);  // row_shr:1
+    v = pagg_comb<S>(pagg_dpp<S, 0x112, 0xf>(v), v);  // row_shr:2
+    v = pagg_comb<S>(pagg_dpp<S, 0x114, 0xf>(v), v);  // row_shr:4
+    v = pagg_comb<S>(pagg_dpp<S, 0x118, 0xf>(v), v);  // row_shr:8
+    v = pagg_comb<S>(pagg_dpp<S, 0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
+    v = pagg_comb<S>(pagg_dpp<S, 0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
     return v;
-}
-__device__ __forceinline__ PAgg pagg_lane_above(const PAgg &v) {  // value of lane - 1, identity in lane 0 (wave_shr:1)
-    return pagg_dpp<0x138, 0xf>(v);
 }
 __device__ __forceinline__ PAgg pagg_readlane(const PAgg &v, int l) {
     return PAgg{(u32)__builtin_amdgcn_readlane((int)v.x, l), (u32)__builtin_amdgcn_readlane((int)v.y, l),
-                (u32)__builtin_amdgcn_readlane((int)v.s, l)};
+                (u32)__builtin_amdgcn_readlane((int)v.z, l), (u32)__builtin_amdgcn_readlane((int)v.s, l)};
 }
-// Block-level exclusive prefix of one value per thread (S2_WAVES waves); returns the exclusive prefix of the
-// calling thread and, in `total`, the sum over the block.  s_w: S2_WAVES entries of LDS.
+// Block-level exclusive prefix of one value per thread (WAVES <= 16 waves); returns the exclusive prefix of the
+// calling thread and, in `total`, the sum over the block.  s_w: WAVES entries of LDS.
+template <bool S, int WAVES>
 __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w, int lane, int wave, PAgg &total) {
-    const PAgg incl = pagg_wave_inclusive(mine);
+    const PAgg incl = pagg_wave_inclusive<S>(mine);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    // every wave scans the 16 wave totals in its first row
-    PAgg t = lane < S2_WAVES ? s_w[lane] : PAgg{PX_ID, 0u, 0u};
-    t = pagg_combine(pagg_dpp<0x111, 0xf>(t), t);
-    t = pagg_combine(pagg_dpp<0x112, 0xf>(t), t);
-    t = pagg_combine(pagg_dpp<0x114, 0xf>(t), t);
-    t = pagg_combine(pagg_dpp<0x118, 0xf>(t), t);
-    total = pagg_readlane(t, S2_WAVES - 1);
-    PAgg before = PAgg{PX_ID, 0u, 0u};
+    // every wave scans the wave totals in its first row
+    PAgg t = lane < WAVES ? s_w[lane] : pagg_identity();
+    t = pagg_comb<S>(pagg_dpp<S, 0x111, 0xf>(t), t);
+    t = pagg_comb<S>(pagg_dpp<S, 0x112, 0xf>(t), t);
+    t = pagg_comb<S>(pagg_dpp<S, 0x114, 0xf>(t), t);
+    t = pagg_comb<S>(pagg_dpp<S, 0x118, 0xf>(t), t);
+    total = pagg_readlane(t, WAVES - 1);
+    PAgg before = pagg_identity();
     if (wave > 0) before = pagg_readlane(t, (wave - 1) & 15);
-    return pagg_combine(before, pagg_lane_above(incl));
+    return pagg_comb<S>(before, pagg_dpp<S, 0x138, 0xf>(incl));  // wave_shr:1: the lane in front, identity in lane 0
 }
 
 // the full-width scan of the tile aggregates (one block, k_s2_scan_tiles)
@@ -258,7 +316,7 @@ __device__ __forceinline__ void tile_elements(const u32 *s_elut, const u8 *s_kin
     const u64 w = (u64)(prev >> 16) | ((u64)kv << 16) | ((u64)(next & 0xffu) << 48);
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++)
-        e[k] = base + k < n ? token_pelement(s_elut, (u32)(w >> (8 * k)), copied[k]) : PAgg{PX_ID, 0u, 0u};
+        e[k] = base + k < n ? token_pelement(s_elut, (u32)(w >> (8 * k)), copied[k]) : pagg_identity();
 }
 
 // ---- pass 1: tile aggregates ------------------------------------------------------------------------------------
@@ -312,20 +370,20 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
     __syncthreads();
     // byte stream: two kinds of the thread in front, the 16 own ones, one of the thread behind
     const u32 D[6] = {s_k[3 + 4 * tid], kv.x, kv.y, kv.z, kv.w, s_k[8 + 4 * tid]};
-    PAgg acc = PAgg{PX_ID, 0u, 0u};
+    PAgg acc = pagg_identity();
 #pragma unroll
     for (int k = 0; k < RD_ITEMS; k++) {
         const int off = 2 + k;  // byte offset of ppk in the stream
         const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-        const PAgg e = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : PAgg{PX_ID, 0u, 0u};
-        acc = pagg_combine(acc, e);
+        const PAgg e = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
+        acc = pagg_comb<true>(acc, e);
     }
-    const PAgg incl = pagg_wave_inclusive(acc);
+    const PAgg incl = pagg_wave_inclusive<true>(acc);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
     if (tid == 0) {
         PAgg tot = s_w[0];
-        for (int w = 1; w < RD_BLOCK / 64; w++) tot = pagg_combine(tot, s_w[w]);
+        for (int w = 1; w < RD_BLOCK / 64; w++) tot = pagg_comb<true>(tot, s_w[w]);
         p.agg[blockIdx.x].a = pagg_unpack(tot);
     }
 }
@@ -370,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
         p.st->records = tot.nb;
         p.st->n_br = tot.bc;
         // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
-        p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : (tot.am & AM_ALL);
+        p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am);
         if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
         if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
     }
@@ -380,6 +438,9 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
 // Everything a token needs from memory (the 8 bytes of an atom, the emit-mask words of a string) is requested
 // for all four tokens of a thread before the first use: one memory round trip per tile, not one per token.
 // Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
+// MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
+// lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
+template <bool MASKS>
 __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
@@ -414,25 +475,32 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     }
     const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
     const MsgView mv{p.msg, p.len};
-    const bool masks = p.sv.qm != nullptr;  // every string copied: offsets and lengths come from the emit masks
+    u8 kd[S2_ITEMS];
+    bool live[S2_ITEMS], is_str[S2_ITEMS], is_atom[S2_ITEMS];
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) {
+        kd[k] = (u8)((kv >> (8 * k)) & 0xffu);
+        live[k] = base + k < p.n;
+        is_str[k] = live[k] && kd[k] == K_STRING;
+        is_atom[k] = live[k] && (u32)(kd[k] - K_TRUE) < 3u;
+    }
     // ---- loads that only depend on the token itself
-    u64 aw[S2_ITEMS];                  // atoms: the 8 message bytes at the token
+    u64 aw[S2_ITEMS];                    // atoms: the 8 message bytes at the token
     u32 dl[S2_ITEMS], copied[S2_ITEMS];  // selective copy: measured lengths
-    u32 uc0[S2_ITEMS], cp0[S2_ITEMS];  // strings (masks): the three words of E(a0)
+    u32 uc0[S2_ITEMS], cp0[S2_ITEMS];    // strings (masks): the three words of E(a0)
     u64 em0[S2_ITEMS];
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
-        const u8 kd = (u8)((kv >> (8 * k)) & 0xffu);
         aw[k] = 0;
         dl[k] = copied[k] = 0;
         uc0[k] = cp0[k] = 0;
         em0[k] = 0;
-        if (kd == K_TRUE || kd == K_FALSE || kd == K_NULL) aw[k] = load8_guarded(mv, pp[k]);
-        if (kd == K_STRING) {
-            if (masks) {
+        if (is_atom[k]) aw[k] = load8_guarded(mv, pp[k]);
+        if (is_str[k]) {
+            if (MASKS) {
                 const u64 a0 = (u64)pp[k] + p.sv.lead + 1;
                 uc0[k] = p.unit_cnt[a0 >> 12];
-                cp0[k] = p.chunk_pre[a0 >> 6];
+                cp0[k] = p.chunk_pre[a0 >> 6] & CHUNK_PRE_MASK;
                 em0[k] = p.em[a0 >> 6];
             } else {
                 dl[k] = p.dlen[base + k];
@@ -448,57 +516,31 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     for (int k = 0; k < S2_ITEMS; k++) {
         uc1[k] = cp1[k] = 0;
         em1[k] = 0;
-        if (masks && ((kv >> (8 * k)) & 0xffu) == K_STRING) {
+        if (MASKS && is_str[k]) {
             const u64 a1 = (u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead;
             uc1[k] = p.unit_cnt[a1 >> 12];
-            cp1[k] = p.chunk_pre[a1 >> 6];
+            cp1[k] = p.chunk_pre[a1 >> 6] & CHUNK_PRE_MASK;
             em1[k] = p.em[a1 >> 6];
         }
     }
     PAgg e[S2_ITEMS];
     tile_elements(s_elut, s_kind, p.n, base, tid, kv, copied, e);
-    const PAgg mine = pagg_combine(pagg_combine(e[0], e[1]), pagg_combine(e[2], e[3]));
+    const PAgg mine = pagg_comb<!MASKS>(pagg_comb<!MASKS>(e[0], e[1]), pagg_comb<!MASKS>(e[2], e[3]));
     PAgg total;
-    PAgg lp = pagg_block_exclusive(mine, s_w, lane, wave, total);  // prefix inside the tile, in front of this thread
-    const Agg tp = p.agg[blockIdx.x].a;                            // prefix of the tile
+    PAgg lp = pagg_block_exclusive<!MASKS, S2_WAVES>(mine, s_w, lane, wave, total);  // prefix inside the tile
+    const Agg tp = p.agg[blockIdx.x].a;                                               // prefix of the tile
     bool bad = false;
+    u32 nnum = 0;  // numbers of this thread
+#pragma unroll
+    for (int k = 0; k < S2_ITEMS; k++) nnum += (live[k] && kd[k] == K_NUM) ? 1u : 0u;
+    u32 slot = 0;
+    if (nnum) slot = atomicAdd(&s_cnt, nnum);
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
-        const u32 i = base + k;
-        if (i >= p.n) break;
-        const u8 kd = (u8)((kv >> (8 * k)) & 0xffu);
         const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-        if (((e[k].x >> 28) & AM_ALL) == 0) bad = true;  // legal in no context at all
-        switch (kd) {
-        case K_OPEN_OBJ:
-        case K_OPEN_ARR:
-        case K_CLOSE_OBJ:
-        case K_CLOSE_ARR: {
-            const u32 lbc = (lp.x >> 14) & 0x1fffu;
-            const u32 c = tp.bc + lbc;  // brackets in front of this one
-            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
-            p.br_depth[c] = d_before + (is_open(kd) ? 1 : -1);
-            p.br_off[c] = o;
-            p.br_info[c] = (u8)(kd | ((am_combine(am_combine(tp.am, lp.x >> 28), e[k].x >> 28) & AM_ALL) << 4));
-            break;
-        }
-        case K_TRUE:
-        case K_FALSE:
-        case K_NULL:
-            p.tape[o] = atom_word(kd);
-            bad |= !atom_valid_word(aw[k], p.len - pp[k], kd);
-            break;
-        case K_NUM: {  // wave-aggregated append: one LDS atomic per wave
-            const u64 act = __ballot(1);
-            const int leader = (int)__builtin_ctzll(act);
-            u32 slot = 0;
-            if (lane == leader) slot = atomicAdd(&s_cnt, (u32)__builtin_popcountll(act));
-            slot = (u32)__shfl((int)slot, leader, 64) + (u32)__builtin_popcountll(act & ((1ull << lane) - 1));
-            s_num[slot] = make_uint2(pp[k], o);
-            break;
-        }
-        case K_STRING:
-            if (masks) {
+        if (live[k] && am_value(e[k].z) == 0) bad = true;  // legal in no context at all
+        if (is_str[k]) {
+            if (MASKS) {
                 const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
                 const u32 b1 = (u32)(((u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead) & 63u);
                 const u64 so = (u64)uc0[k] + cp0[k] + (u64)popc64(b0 ? (em0[k] & (~0ull >> (64 - b0))) : 0ull);
@@ -510,15 +552,24 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
                 const u32 so = tp.s + lp.s;
                 p.tape[o] = string_word(cp, p.strings_base + so, p.msg_base + pp[k] + 1);
                 p.tape[o + 1] = dl[k] & ~DLEN_COPY;
-                p.str_off[i] = so;
+                p.str_off[base + k] = so;
             }
-            break;
-        case K_NL:
-            if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
-            break;
-        default: break;
         }
-        lp = pagg_combine(lp, e[k]);
+        if (is_atom[k]) {
+            p.tape[o] = atom_word(kd[k]);
+            bad |= !atom_valid_word(aw[k], p.len - pp[k], kd[k]);
+        }
+        if (live[k] && (u32)(kd[k] - K_OPEN_OBJ) < 4u) {
+            const u32 lbc = lp.x >> 14;
+            const u32 c = tp.bc + lbc;  // brackets in front of this one
+            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
+            p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
+            p.br_off[c] = o;
+            p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
+        }
+        if (live[k] && kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
+        if (live[k] && (e[k].y >> 13)) p.nl_off[tp.nb + (lp.y >> 13)] = o;
+        lp = pagg_comb<!MASKS>(lp, e[k]);
     }
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
     // the tile's numbers move to the global queue (coalesced; the order of the queue does not matter)
@@ -882,7 +933,8 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, c
     p.msg_base = msg_base;
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
-    hipLaunchKernelGGL(k_s2_emit, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_numbers, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     for (int l = 1; l < p.nlev; l++) {  // grid-stride: the kernels use the real bracket count
         const u64 want = (p.lev_size[l] + 3) / 4;

@@ -157,6 +157,13 @@ def test_deep_nesting_and_long_flat_containers(ctx):
     check(ctx, b"[" + b",".join(b"[%d,%d]" % (i, i) for i in range(100000)) + b"]", False, "pairs")
     check(ctx, b"[" + b",".join(b'{"k":"v%d"}' % i for i in range(50000)) + b"]", False, "objs")
     check(ctx, b"\n".join(b'{"k":[%d,{"z":null}]}' % i for i in range(50000)), True, "nd-many")
+    # sawtooth depth: partners and parents spread over several 64-bracket groups and min-tree levels
+    saw = b"[" + b",".join(b"[" * (i % 70) + b"1" + b"]" * (i % 70) for i in range(1, 20000)) + b"]"
+    check(ctx, saw, False, "sawtooth")
+    check(ctx, saw[:-200] + b"}" + saw[-199:], False, "sawtooth-mismatch")
+    mixed = b'{"r":' * 200 + b"[" + b",".join(b'{"a":[1,{"b":[]},[[2]]]}' for _ in range(30000)) + b"]" + b"}" * 200
+    check(ctx, mixed, False, "mixed")
+    check(ctx, mixed[:-150] + b"]" + mixed[-149:], False, "mixed-mismatch")
 
 
 def test_trim_space_variants(ctx):
