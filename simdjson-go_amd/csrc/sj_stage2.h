@@ -256,20 +256,21 @@ SJ_HD bool string_walk(const MsgView &m, u64 q, u8 *dst, u32 *src_len, u32 *dst_
 }
 
 // ---- atoms (stage2_build_tape_amd64.go:124-158, table :455-476) ----------------------------------
-SJ_HD bool atom_terminator(u8 c) {
-    switch (c) {
-    case 0: case '\t': case '\n': case '\r': case ' ': case ',': case ':': case '[': case ']': case '{': case '}':
-        return true;
-    default: return false;
-    }
+SJ_HD bool atom_terminator(u8 c) {  // 0 \t \n \r space , : [ ] { }   (a bit set: no control flow under divergence)
+    const u64 LO = (1ull << 0) | (1ull << 9) | (1ull << 10) | (1ull << 13) | (1ull << 32) | (1ull << 44) | (1ull << 58);
+    const u64 HI = (1ull << ('[' - 64)) | (1ull << (']' - 64)) | (1ull << ('{' - 64)) | (1ull << ('}' - 64));
+    const u64 m = (c & 64u) ? HI : LO;
+    return (c < 128u) & (bool)((m >> (c & 63u)) & 1u);
 }
 // w8 = the 8 message bytes at the token (little endian, zero beyond the end), rem = bytes from the token to the
 // end of the message
 SJ_HD bool atom_valid_word(u64 w8, u64 rem, u8 kind) {
-    const u32 lo = (u32)w8;
-    if (kind == K_TRUE) return rem >= 5 && lo == 0x65757274u && atom_terminator((u8)(w8 >> 32));
-    if (kind == K_NULL) return rem >= 5 && lo == 0x6c6c756eu && atom_terminator((u8)(w8 >> 32));
-    return rem >= 6 && (w8 & 0x000000ffffffffffull) == 0x00000065736c6166ull && atom_terminator((u8)(w8 >> 40));
+    const u32 want = kind == K_TRUE ? 0x65757274u : (kind == K_NULL ? 0x6c6c756eu : 0x736c6166u);  // true null fals
+    const bool head = (u32)w8 == want;
+    const u8 b4 = (u8)(w8 >> 32), b5 = (u8)(w8 >> 40);
+    const bool ok5 = (rem >= 5) & head & atom_terminator(b4);
+    const bool ok6 = (rem >= 6) & head & (b4 == 'e') & atom_terminator(b5);
+    return kind == K_FALSE ? ok6 : ok5;
 }
 SJ_HD u64 load8_guarded(const MsgView &m, u64 p) {
     if (p + 8 <= m.len) return load_u64(m.p + p);

@@ -475,14 +475,14 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     }
     const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
     const MsgView mv{p.msg, p.len};
+    // tokens behind the end of the message have kind K_NL and the identity element: they fall through everything
     u8 kd[S2_ITEMS];
-    bool live[S2_ITEMS], is_str[S2_ITEMS], is_atom[S2_ITEMS];
+    bool is_str[S2_ITEMS], is_atom[S2_ITEMS];
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         kd[k] = (u8)((kv >> (8 * k)) & 0xffu);
-        live[k] = base + k < p.n;
-        is_str[k] = live[k] && kd[k] == K_STRING;
-        is_atom[k] = live[k] && (u32)(kd[k] - K_TRUE) < 3u;
+        is_str[k] = kd[k] == K_STRING;
+        is_atom[k] = (u32)(kd[k] - K_TRUE) < 3u;
     }
     // ---- loads that only depend on the token itself
     u64 aw[S2_ITEMS];                    // atoms: the 8 message bytes at the token
@@ -532,34 +532,37 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     bool bad = false;
     u32 nnum = 0;  // numbers of this thread
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) nnum += (live[k] && kd[k] == K_NUM) ? 1u : 0u;
+    for (int k = 0; k < S2_ITEMS; k++) nnum += kd[k] == K_NUM ? 1u : 0u;
     u32 slot = 0;
     if (nnum) slot = atomicAdd(&s_cnt, nnum);
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-        if (live[k] && am_value(e[k].z) == 0) bad = true;  // legal in no context at all
-        if (is_str[k]) {
-            if (MASKS) {
-                const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
-                const u32 b1 = (u32)(((u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead) & 63u);
-                const u64 so = (u64)uc0[k] + cp0[k] + (u64)popc64(b0 ? (em0[k] & (~0ull >> (64 - b0))) : 0ull);
-                const u64 se = (u64)uc1[k] + cp1[k] + (u64)popc64(b1 ? (em1[k] & (~0ull >> (64 - b1))) : 0ull);
-                p.tape[o] = string_word(true, p.strings_base + so, 0);
-                p.tape[o + 1] = se - so;
-            } else if (dl[k] != DLEN_INVALID) {
-                const bool cp = (dl[k] & DLEN_COPY) != 0;
-                const u32 so = tp.s + lp.s;
-                p.tape[o] = string_word(cp, p.strings_base + so, p.msg_base + pp[k] + 1);
-                p.tape[o + 1] = dl[k] & ~DLEN_COPY;
-                p.str_off[base + k] = so;
-            }
+        bad |= am_value(e[k].z) == 0;                // legal in no context at all
+        // strings and atoms: first word under one predicate, computed without control flow
+        u64 w0 = atom_word(kd[k]), w1 = 0;
+        bool two = false;
+        if (MASKS) {
+            const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
+            const u32 b1 = (u32)(((u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead) & 63u);
+            const u64 so = (u64)uc0[k] + cp0[k] + (u64)popc64(em0[k] & ~(~0ull << b0));
+            const u64 se = (u64)uc1[k] + cp1[k] + (u64)popc64(em1[k] & ~(~0ull << b1));
+            if (is_str[k]) w0 = string_word(true, p.strings_base + so, 0);
+            w1 = se - so;
+            two = is_str[k];
+        } else {
+            const bool cp = (dl[k] & DLEN_COPY) != 0;
+            two = is_str[k] & (dl[k] != DLEN_INVALID);
+            if (is_str[k]) w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1);
+            w1 = dl[k] & ~DLEN_COPY;
         }
-        if (is_atom[k]) {
-            p.tape[o] = atom_word(kd[k]);
-            bad |= !atom_valid_word(aw[k], p.len - pp[k], kd[k]);
+        if (is_atom[k]) bad |= !atom_valid_word(aw[k], p.len - pp[k], kd[k]);  // skipped by waves without atoms
+        if (two | is_atom[k]) p.tape[o] = w0;
+        if (two) {
+            p.tape[o + 1] = w1;
+            if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
         }
-        if (live[k] && (u32)(kd[k] - K_OPEN_OBJ) < 4u) {
+        if ((u32)(kd[k] - K_OPEN_OBJ) < 4u) {
             const u32 lbc = lp.x >> 14;
             const u32 c = tp.bc + lbc;  // brackets in front of this one
             const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
@@ -567,8 +570,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             p.br_off[c] = o;
             p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
         }
-        if (live[k] && kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
-        if (live[k] && (e[k].y >> 13)) p.nl_off[tp.nb + (lp.y >> 13)] = o;
+        if (kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
+        if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
         lp = pagg_comb<!MASKS>(lp, e[k]);
     }
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);

@@ -6,4 +6,4 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc -o parse -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc.log 2>&1
 cd $REPO && python tools/summarize_prof.py $OUT $OUT/summary.txt > /dev/null
-grep -E "pmc " $OUT/summary.txt | sed "s/(sj::S2Dev)//" | grep -E "k_s2_emit|k_str_emit|k_str_masks|1024, 2, 4, true, true|1024, 2, 4, false, true"
+grep -E "pmc " $OUT/summary.txt | sed "s/(sj::S2Dev)//" | grep -E "k_s2_emit"
