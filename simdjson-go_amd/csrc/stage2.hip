@@ -73,7 +73,7 @@ struct S2Dev {
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
     // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
-    u64 *em, *um;         // [chunks] emit mask, 'u' mask
+    u64 *em;              // [chunks] emit mask
     uint16_t *chunk_pre;  // [chunks] emitted bytes of the unit in front of the chunk
     u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
     u64 units;
@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     u64 em, um;
     bool escapes;
     if (!str_chunk_masks(p.sv, c, &em, &um, &escapes)) atomicOr(&p.st->err, 1u);
-    p.em[c] = em;
-    p.um[c] = um;
+    p.em[c] = em;  // (the 'u' mask is only an intermediate: pass 2 re-derives the escapes of flagged chunks)
     const u32 n = (u32)popc64(em);
     u32 incl = n;
 #pragma unroll
@@ -103,47 +102,62 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
 // one block of 1024 threads: exclusive scan of u32 data[n] in place (n padded to a multiple of 4 by the caller's
 // allocation), 4096 elements per round with 16-byte coalesced accesses; returns the total (valid in every thread)
 __device__ u64 block_exclusive_scan_u32(u32 *data, u64 n) {
-    __shared__ u32 s_wave[16];
-    __shared__ u64 s_carry;
+    __shared__ u32 s_wave[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (u64 start = 0; start < n; start += 4096) {
-        const u64 i = start + (u64)threadIdx.x * 4;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i + 3 < n) {
-            v = *reinterpret_cast<const uint4 *>(data + i);
+    u64 carry = 0;  // the same in every thread
+    int buf = 0;
+    for (u64 start = 0; start < n; start += 16384, buf ^= 1) {
+        const u64 i = start + (u64)threadIdx.x * 16;
+        u32 v[16];
+        if (i + 15 < n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(data + i + 4 * q);
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
         } else {
-            if (i < n) v.x = data[i];
-            if (i + 1 < n) v.y = data[i + 1];
-            if (i + 2 < n) v.z = data[i + 2];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = i + q < n ? data[i + q] : 0u;
         }
-        const u32 t = v.x + v.y + v.z + v.w;
+        u32 t = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += v[q];
         u32 incl = t;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const u32 o = __shfl_up(incl, s, 64);
             if (lane >= s) incl += o;
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        u32 before = 0;
-        for (int w = 0; w < wave; w++) before += s_wave[w];
-        const u64 carry = s_carry;
-        const u32 ex = (u32)carry + before + incl - t;  // positions are < 2^32
-        const uint4 o = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-        if (i + 3 < n) {
-            *reinterpret_cast<uint4 *>(data + i) = o;
-        } else {
-            if (i < n) data[i] = o.x;
-            if (i + 1 < n) data[i + 1] = o.y;
-            if (i + 2 < n) data[i + 2] = o.z;
+        if (lane == 63) s_wave[buf][wave] = incl;
+        __syncthreads();  // one barrier per round: the wave totals alternate between two buffers
+        u32 before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const u32 x = s_wave[buf][w];
+            before += w < wave ? x : 0u;
+            total += x;
         }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + before + incl;
-        __syncthreads();
+        u32 run = (u32)carry + before + incl - t;  // positions are < 2^32
+        if (i + 15 < n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint4 o;
+                o.x = run; run += v[4 * q];
+                o.y = run; run += v[4 * q + 1];
+                o.z = run; run += v[4 * q + 2];
+                o.w = run; run += v[4 * q + 3];
+                *reinterpret_cast<uint4 *>(data + i + 4 * q) = o;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if (i + q < n) data[i + q] = run;
+                run += v[q];
+            }
+        }
+        carry += total;
     }
-    return s_carry;
+    return carry;
 }
 
 // one block: exclusive scan of the unit counts (in place) + Strings.B length
@@ -291,16 +305,34 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
 }
 
 // the full-width scan of the tile aggregates (one block, k_s2_scan_tiles)
-__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int delta) {
-    return Agg{__shfl_up(a.d, delta, 64),          (u32)__shfl_up((int)a.w, delta, 64),  (u32)__shfl_up((int)a.s, delta, 64),
-               (u32)__shfl_up((int)a.nb, delta, 64), (u32)__shfl_up((int)a.bc, delta, 64), (u32)__shfl_up((int)a.am, delta, 64)};
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Agg agg_dpp(const Agg &v) {  // lanes without a source read the identity
+    return Agg{__builtin_amdgcn_update_dpp(0, v.d, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.nb, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.bc, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp((int)AM_ALL, (int)v.am, CTRL, ROW_MASK, 0xf, false)};
 }
-__device__ __forceinline__ Agg wave_inclusive(Agg v, int lane) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const Agg o = agg_shfl_up(v, s);
-        if (lane >= s) v = agg_combine(o, v);
-    }
+__device__ __forceinline__ Agg agg_readlane(const Agg &v, int l) {
+    return Agg{__builtin_amdgcn_readlane(v.d, l),
+               (u32)__builtin_amdgcn_readlane((int)v.w, l),
+               (u32)__builtin_amdgcn_readlane((int)v.s, l),
+               (u32)__builtin_amdgcn_readlane((int)v.nb, l),
+               (u32)__builtin_amdgcn_readlane((int)v.bc, l),
+               (u32)__builtin_amdgcn_readlane((int)v.am, l)};
+}
+__device__ __forceinline__ Agg agg_row_scan(Agg v) {  // inclusive inside rows of 16 lanes
+    v = agg_combine(agg_dpp<0x111, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x112, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x114, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x118, 0xf>(v), v);
+    return v;
+}
+__device__ __forceinline__ Agg agg_wave_inclusive(Agg v) {
+    v = agg_row_scan(v);
+    v = agg_combine(agg_dpp<0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
+    v = agg_combine(agg_dpp<0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -389,39 +421,74 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
 }
 
 // ---- pass 2: one block, exclusive scan over the tile aggregates (in place) + totals ---------------------------
+// Every thread owns K consecutive tiles (K <= 32 per round; one round up to 134 M tokens), so the block scans
+// once per round and the aggregates are read with four independent loads in flight per thread.
 __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
-    __shared__ Agg lds[16];
-    __shared__ Agg carry_s;
+    __shared__ Agg s_w[16];
     __shared__ unsigned long long words64, bytes64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        carry_s = agg_identity();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {
         words64 = 0;
         bytes64 = 0;
     }
     __syncthreads();
-    for (u32 start = 0; start < p.tiles; start += 1024) {
-        const u32 t = start + threadIdx.x;
-        Agg incl = t < p.tiles ? p.agg[t].a : agg_identity();
-        incl = wave_inclusive(incl, lane);
-        if (lane == 63) lds[wave] = incl;
-        __syncthreads();
-        Agg before = carry_s;  // everything in front of this wave
-        for (int w = 0; w < wave; w++) before = agg_combine(before, lds[w]);
-        const Agg prev = agg_shfl_up(incl, 1);
-        const Agg excl = lane > 0 ? agg_combine(before, prev) : before;
-        if (t < p.tiles) p.agg[t].a = excl;
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            const Agg total = agg_combine(before, incl);
-            words64 += (unsigned long long)(u32)(total.w - carry_s.w);  // sum of one round < 2^32
-            bytes64 += (unsigned long long)(u32)(total.s - carry_s.s);
-            carry_s = total;
+    Agg carry = agg_identity();  // everything in front of the round
+    for (u32 start = 0; start < p.tiles; start += 1024u * 32u) {
+        const u32 left = p.tiles - start;
+        const u32 K = left >= 1024u * 32u ? 32u : (left + 1023u) / 1024u;
+        const u32 first = start + (u32)tid * K;
+        Agg acc = agg_identity();
+        for (u32 j = 0; j < K; j += 4) {
+            Agg a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 t = first + j + q;
+                a[q] = (j + q < K && t < p.tiles) ? p.agg[t].a : agg_identity();
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = agg_combine(acc, a[q]);
         }
+        // 64-bit totals of the round (the 32-bit fields of the scan wrap; a failed size check needs the true sums)
+        {
+            unsigned long long ws = acc.w, bs = acc.s;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                ws += (unsigned long long)__shfl_xor((long long)ws, sh, 64);
+                bs += (unsigned long long)__shfl_xor((long long)bs, sh, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(&words64, ws);
+                atomicAdd(&bytes64, bs);
+            }
+        }
+        const Agg incl = agg_wave_inclusive(acc);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        Agg t = lane < 16 ? s_w[lane] : agg_identity();
+        t = agg_row_scan(t);
+        const Agg round_total = agg_readlane(t, 15);
+        Agg run = carry;
+        if (wave > 0) run = agg_combine(run, agg_readlane(t, (wave - 1) & 15));
+        run = agg_combine(run, agg_dpp<0x138, 0xf>(incl));  // wave_shr:1: the lane in front, identity in lane 0
+        for (u32 j = 0; j < K; j += 4) {
+            Agg a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 t2 = first + j + q;
+                a[q] = (j + q < K && t2 < p.tiles) ? p.agg[t2].a : agg_identity();
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 t2 = first + j + q;
+                if (j + q < K && t2 < p.tiles) p.agg[t2].a = run;
+                run = agg_combine(run, a[q]);
+            }
+        }
+        carry = agg_combine(carry, round_total);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const Agg tot = carry_s;
+    if (tid == 0) {
+        const Agg tot = carry;
         p.st->final_depth = tot.d;
         p.st->tape_len = words64 + 2ull;  // + opening root + closing root
         p.st->strings_len = p.sv.qm ? p.st->strings_len_masks : bytes64;
@@ -888,7 +955,7 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
     p.sv.end = p.sv.lead + len;
     p.sv.qm = p.sv.q = p.sv.st = nullptr;
     p.sv.unit_h = nullptr;
-    p.em = p.um = nullptr;
+    p.em = nullptr;
     p.chunk_pre = nullptr;
     p.unit_cnt = nullptr;
     p.units = 0;
@@ -899,7 +966,6 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
         p.sv.st = a.st;
         p.sv.unit_h = a.unit_h;
         p.em = a.em;
-        p.um = a.um;
         p.chunk_pre = a.chunk_pre;
         p.unit_cnt = a.unit_cnt;
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
