@@ -255,7 +255,8 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 t, u32 t_next, bool has_next,
-                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *s_unit, const S1Aux &aux) {
+                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
+                                        const S1Aux &aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // interior unit: all 4096 bytes belong to the message (wave-uniform -> scalar unit)
@@ -350,7 +351,9 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         const u32 bad = (__ballot(((u32)in_a | (u32)(in_a >> 32)) != 0) != 0 ? 1u : 0u) |
                         (__ballot(((u32)in_b | (u32)(in_b >> 32)) != 0) != 0 ? 2u : 0u);
         // unit totals of both counts at once (16-bit fields: a wave holds <= 4096 bits)
-        const u32 tot = lane63(wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16)));
+        const u32 incl = wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16));
+        pre[k * 64 + lane] = incl;  // flatten needs the lane's offset inside the unit: kept instead of scanned again
+        const u32 tot = lane63(incl);
         if (lane == 0)
             s_unit[k * WAVES + wave] =
                 (((u32)popc64(par_ballot) & 1u) << 31) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
@@ -376,7 +379,7 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 // held the masks: they are read into registers first), then the wave copies the window out with
 // coalesced 256-byte stores.  A unit with more than CAP positions takes several rounds.
 template <int BLOCK, int CH>
-__device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
+__device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
                                              u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
                                              const u8 *s_klut) {
@@ -395,10 +398,13 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
     const bool err = lane < UNITS && ((v >> (26 + hl)) & 1u) != 0;  // any lane: the caller ballots
 
     u64 sel[CH];
+    u32 upto[CH];  // structurals of the unit up to and including this lane's chunk
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
         sel[k] = m[(k * 2 + (int)h) * 64 + lane];
+        const u32 both = pre[k * 64 + lane];
+        upto[k] = h ? both >> 16 : both & 0xffffu;
         if (unit_h && lane == 0 && ((u64)t * UNITS + (u64)(k * WAVES + wave)) * 4096 < lead + len_)
             unit_h[(u64)t * UNITS + (u64)(k * WAVES + wave)] = (u8)h;
     }
@@ -412,7 +418,7 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
         const u64 s = sel[k];
         const u32 lo0 = (u32)s, hi0 = (u32)(s >> 32);
         const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
-        const u32 loc = wave_incl_scan(n) - n;  // offset of this lane's first position inside the unit
+        const u32 loc = upto[k] - n;  // offset of this lane's first position inside the unit
         u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
         __builtin_amdgcn_wave_barrier();  // the window is free: all masks are in registers / already copied out
         // copies the first cnt staged positions to out_pos[gd ...] (and their kinds to kind_out)
@@ -445,10 +451,25 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *s_unit, u32 pre_
             }
         };
         if (C <= CAP) {
-            u32 *p = stage + loc;
-            for (u32 lo = lo0; lo != 0; lo &= lo - 1) *p++ = pos0 + (u32)__builtin_ctz(lo);
+            // two positions per iteration, the lowest and the highest set bit of the word (an odd last bit is
+            // simply written twice to the same slot)
+            const u32 nlo = (u32)__builtin_popcount(lo0);
+            u32 *p = stage + loc, *q = p + nlo - 1;
+            for (u32 x = lo0; x != 0;) {
+                const u32 top = 31u - (u32)__builtin_clz(x);
+                *p++ = pos0 + (u32)__builtin_ctz(x);
+                *q-- = pos0 + top;
+                x = bitop3<(TA & TB & ~TC)>(x, x - 1u, 1u << top);
+            }
             pos0 += 32;
-            for (u32 hi = hi0; hi != 0; hi &= hi - 1) *p++ = pos0 + (u32)__builtin_ctz(hi);
+            p = stage + loc + nlo;
+            q = p + (n - nlo) - 1;
+            for (u32 x = hi0; x != 0;) {
+                const u32 top = 31u - (u32)__builtin_clz(x);
+                *p++ = pos0 + (u32)__builtin_ctz(x);
+                *q-- = pos0 + top;
+                x = bitop3<(TA & TB & ~TC)>(x, x - 1u, 1u << top);
+            }
             __builtin_amdgcn_wave_barrier();
             copy_out(C, g);
         } else {
@@ -486,6 +507,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_unit[3][UNITS];
     __shared__ u32 s_res[4];  // look-back result of the current tile: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
+    __shared__ u32 s_pre[2][WAVES][CH * 64];  // per chunk: inclusive structural counts of its unit, both hypotheses
     __shared__ u8 s_klut[AUX ? 256 : 4];
 
     const int tid = threadIdx.x;
@@ -518,7 +540,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_unit[0], aux);
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+                                    aux);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
         if (has_next)
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                       s_unit[us_n], aux);
+                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux);
         // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
         // waits for the other waves (the predecessors published their aggregates about a phase ago)
         LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
+        err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
@@ -604,13 +627,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 // ---- launcher --------------------------------------------------------------------------
 // Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
 // allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
-static constexpr int S1_DEFAULT_VARIANT = 4;
+static constexpr int S1_DEFAULT_VARIANT = 2;
 
 struct S1Variant {
     int block, ch, wpe;
 };
-static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {512, 2, 6}, {256, 2, 5}, {256, 2, 6},
-                                        {1024, 2, 4}, {256, 4, 4}, {512, 4, 4}};
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {256, 2, 5}, {1024, 2, 4}};
 static S1Variant s1_variant() {
     static int v = -1;
     if (v < 0) {
@@ -689,12 +711,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         else                          \
             S1_LAUNCH2(B, C, W, false); \
     } while (0)
-    if (v.block == 512 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(512, 2, 6);
-    else if (v.block == 256 && v.ch == 2 && v.wpe == 5) S1_LAUNCH(256, 2, 5);
-    else if (v.block == 256 && v.ch == 2 && v.wpe == 6) S1_LAUNCH(256, 2, 6);
+    if (v.block == 256) S1_LAUNCH(256, 2, 5);
     else if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
-    else if (v.block == 256 && v.ch == 4) S1_LAUNCH(256, 4, 4);
-    else if (v.block == 512 && v.ch == 4) S1_LAUNCH(512, 4, 4);
     else S1_LAUNCH(512, 2, 4);
 #undef S1_LAUNCH2
 #undef S1_LAUNCH3
