@@ -91,6 +91,10 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
     HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+    if (hs->err & 8u) {  // a bounded spin loop of a scan kernel ran out: internal error, never a verdict
+        ctx_set_error(ctx, "stage-2 scan aborted (internal synchronisation timeout)");
+        return SJHIP_ERR_HIP;
+    }
     if (hs->err & 4u) {
         ctx_set_error(ctx, "tape longer than 2^32 words");
         return SJHIP_ERR_TOOBIG;

@@ -19,7 +19,7 @@ static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line
 
 // stage-2 totals and flags (zeroed before every launch)
 struct S2State {
-    uint32_t err;            // bit0: stage-2 failure, bit2: tape would exceed 2^32 words
+    uint32_t err;            // bit0: stage-2 failure, bit2: tape would exceed 2^32 words, bit3: internal scan timeout
     uint32_t bignum_count;   // numbers queued for the big-integer tie-break
     int32_t final_depth;
     uint32_t records;        // record-separating newline runs (ND)

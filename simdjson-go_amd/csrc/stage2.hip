@@ -37,6 +37,20 @@ static constexpr u32 DLEN_COPY = 0x80000000u;
 
 __constant__ ElementLut c_elut = make_element_lut();
 
+// The two device-wide scans that run over small arrays (unit byte counts, tile aggregates) are split over
+// SCAN_SEGS blocks, because one CU moves only ~60 GB/s: a block reduces its contiguous segment, publishes the
+// aggregate (payload words, fence, flag), adds up the aggregates of the segments in front of it (one lane per
+// predecessor; all blocks are resident, so the wait is bounded) and then writes its prefixes.
+static constexpr int SCAN_SEGS = 32;
+struct alignas(64) SegSlot {
+    u32 flag;
+    u32 am;
+    i32 d;
+    u32 nb, bc, pad;
+    unsigned long long w, s;  // 64-bit sums: tape words / Strings.B bytes (unit scan: bytes in s)
+};
+static_assert(sizeof(SegSlot) == 64, "one line per segment");
+
 struct alignas(32) TileAgg {
     Agg a;
     u32 pad[2];
@@ -67,6 +81,7 @@ struct S2Dev {
     u64 lev_size[MinTree::MAXLEV];
     int nlev;
     S2State *st;
+    SegSlot *seg_units, *seg_tiles;  // [SCAN_SEGS] segment aggregates of the two multi-block scans (zeroed with st)
     u64 *tape;
     u8 *strings;
     u64 tape_cap, strings_cap;
@@ -99,34 +114,156 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
-// one block of 1024 threads: exclusive scan of u32 data[n] in place (n padded to a multiple of 4 by the caller's
-// allocation), 4096 elements per round with 16-byte coalesced accesses; returns the total (valid in every thread)
-__device__ u64 block_exclusive_scan_u32(u32 *data, u64 n) {
-    __shared__ u32 s_wave[2][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u64 carry = 0;  // the same in every thread
-    int buf = 0;
-    for (u64 start = 0; start < n; start += 16384, buf ^= 1) {
-        const u64 i = start + (u64)threadIdx.x * 16;
-        u32 v[16];
-        if (i + 15 < n) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(data + i + 4 * q);
-                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+// ---- wave scans of full-width aggregates (DPP) ------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Agg agg_dpp(const Agg &v) {  // lanes without a source read the identity
+    return Agg{__builtin_amdgcn_update_dpp(0, v.d, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.nb, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp(0, (int)v.bc, CTRL, ROW_MASK, 0xf, false),
+               (u32)__builtin_amdgcn_update_dpp((int)AM_ALL, (int)v.am, CTRL, ROW_MASK, 0xf, false)};
+}
+__device__ __forceinline__ Agg agg_readlane(const Agg &v, int l) {
+    return Agg{__builtin_amdgcn_readlane(v.d, l),
+               (u32)__builtin_amdgcn_readlane((int)v.w, l),
+               (u32)__builtin_amdgcn_readlane((int)v.s, l),
+               (u32)__builtin_amdgcn_readlane((int)v.nb, l),
+               (u32)__builtin_amdgcn_readlane((int)v.bc, l),
+               (u32)__builtin_amdgcn_readlane((int)v.am, l)};
+}
+__device__ __forceinline__ Agg agg_row_scan(Agg v) {  // inclusive inside rows of 16 lanes
+    v = agg_combine(agg_dpp<0x111, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x112, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x114, 0xf>(v), v);
+    v = agg_combine(agg_dpp<0x118, 0xf>(v), v);
+    return v;
+}
+__device__ __forceinline__ Agg agg_wave_inclusive(Agg v) {
+    v = agg_row_scan(v);
+    v = agg_combine(agg_dpp<0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
+    v = agg_combine(agg_dpp<0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// ---- segment publish / look-back shared by the two multi-block scans -------------------------------------------
+struct SegSum {
+    Agg a;                    // 32-bit fields (wrap like the scan itself)
+    unsigned long long w, s;  // true 64-bit sums
+};
+__device__ __forceinline__ void seg_publish(SegSlot *slot, const SegSum &v) {
+    __hip_atomic_store(&slot->am, v.a.am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->d, v.a.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->nb, v.a.nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->bc, v.a.bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->w, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->s, v.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// called by one whole wave of block `seg`: the ordered sum of segments 0 .. seg-1 (identity for seg 0)
+__device__ __forceinline__ SegSum seg_lookback(SegSlot *slots, int seg, int lane, S2State *st) {
+    SegSum r;
+    r.a = agg_identity();
+    r.w = r.s = 0;
+    static_assert(SCAN_SEGS <= 64, "one lane per predecessor");
+    if (lane < seg) {
+        u32 spins = 0;
+        while (__hip_atomic_load(&slots[lane].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+                atomicOr(&st->err, 8u);
+                break;
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; q++) v[q] = i + q < n ? data[i + q] : 0u;
         }
+        r.a.am = __hip_atomic_load(&slots[lane].am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.a.d = __hip_atomic_load(&slots[lane].d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.a.nb = __hip_atomic_load(&slots[lane].nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.a.bc = __hip_atomic_load(&slots[lane].bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.w = __hip_atomic_load(&slots[lane].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.s = __hip_atomic_load(&slots[lane].s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.a.w = (u32)r.w;
+        r.a.s = (u32)r.s;
+    }
+    r.a = agg_readlane(agg_wave_inclusive(r.a), 63);  // lanes >= seg hold the identity
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        r.w += (unsigned long long)__shfl_xor((long long)r.w, sh, 64);
+        r.s += (unsigned long long)__shfl_xor((long long)r.s, sh, 64);
+    }
+    return r;
+}
+// contiguous share of `n` items for segment `seg`, in whole multiples of `quantum`
+__device__ __forceinline__ void seg_range(u64 n, u64 quantum, int seg, u64 &lo, u64 &hi) {
+    const u64 per = ((n + SCAN_SEGS - 1) / SCAN_SEGS + quantum - 1) / quantum * quantum;
+    lo = (u64)seg * per;
+    hi = lo + per;
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+}
+
+// ---- exclusive scan of the unit byte counts (in place) + Strings.B length: SCAN_SEGS blocks of 1024 threads ------
+// 16 units per thread and round with 16-byte accesses.
+__device__ __forceinline__ void unit_round_load(const u32 *data, u64 i, u64 hi, u32 (&v)[16]) {
+    if (i + 15 < hi) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(data + i + 4 * q);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = i + q < hi ? data[i + q] : 0u;
+    }
+}
+__global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
+    __shared__ u32 s_wave[2][16];
+    __shared__ unsigned long long s_sum[16], s_prefix;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seg = blockIdx.x;
+    u32 *data = p.unit_cnt;
+    u64 lo, hi;
+    seg_range(p.units, 1024, seg, lo, hi);
+    // pass 1: the segment's byte count
+    unsigned long long mine = 0;
+    for (u64 start = lo; start < hi; start += 16384) {
+        u32 v[16];
+        unit_round_load(data, start + (u64)tid * 16, hi, v);
+#pragma unroll
+        for (int q = 0; q < 16; q++) mine += v[q];
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) mine += (unsigned long long)__shfl_xor((long long)mine, sh, 64);
+    if (lane == 0) s_sum[wave] = mine;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < 16; w++) tot += s_sum[w];
+        SegSum own;
+        own.a = agg_identity();
+        own.w = 0;
+        own.s = tot;
+        if (lane == 0) seg_publish(&p.seg_units[seg], own);
+        const SegSum before = seg_lookback(p.seg_units, seg, lane, p.st);
+        if (lane == 0) {
+            s_prefix = before.s;
+            if (seg == SCAN_SEGS - 1) p.st->strings_len_masks = before.s + tot;
+        }
+    }
+    __syncthreads();
+    // pass 2: exclusive prefixes in place
+    u64 carry = s_prefix;  // the same in every thread
+    int buf = 0;
+    for (u64 start = lo; start < hi; start += 16384, buf ^= 1) {
+        const u64 i = start + (u64)tid * 16;
+        u32 v[16];
+        unit_round_load(data, i, hi, v);
         u32 t = 0;
 #pragma unroll
         for (int q = 0; q < 16; q++) t += v[q];
         u32 incl = t;
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const u32 o = __shfl_up(incl, s, 64);
-            if (lane >= s) incl += o;
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const u32 o = __shfl_up(incl, sft, 64);
+            if (lane >= sft) incl += o;
         }
         if (lane == 63) s_wave[buf][wave] = incl;
         __syncthreads();  // one barrier per round: the wave totals alternate between two buffers
@@ -138,7 +275,7 @@ __device__ u64 block_exclusive_scan_u32(u32 *data, u64 n) {
             total += x;
         }
         u32 run = (u32)carry + before + incl - t;  // positions are < 2^32
-        if (i + 15 < n) {
+        if (i + 15 < hi) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint4 o;
@@ -151,19 +288,12 @@ __device__ u64 block_exclusive_scan_u32(u32 *data, u64 n) {
         } else {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                if (i + q < n) data[i + q] = run;
+                if (i + q < hi) data[i + q] = run;
                 run += v[q];
             }
         }
         carry += total;
     }
-    return carry;
-}
-
-// one block: exclusive scan of the unit counts (in place) + Strings.B length
-__global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
-    const u64 total = block_exclusive_scan_u32(p.unit_cnt, p.units);
-    if (threadIdx.x == 0) p.st->strings_len_masks = total;
 }
 
 // selector of v_perm_b32 that moves the bytes named by the 4-bit mask `nib` to the low end of a dword (zeros above)
@@ -304,38 +434,6 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
     return pagg_comb<S>(before, pagg_dpp<S, 0x138, 0xf>(incl));  // wave_shr:1: the lane in front, identity in lane 0
 }
 
-// the full-width scan of the tile aggregates (one block, k_s2_scan_tiles)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ Agg agg_dpp(const Agg &v) {  // lanes without a source read the identity
-    return Agg{__builtin_amdgcn_update_dpp(0, v.d, CTRL, ROW_MASK, 0xf, false),
-               (u32)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, ROW_MASK, 0xf, false),
-               (u32)__builtin_amdgcn_update_dpp(0, (int)v.s, CTRL, ROW_MASK, 0xf, false),
-               (u32)__builtin_amdgcn_update_dpp(0, (int)v.nb, CTRL, ROW_MASK, 0xf, false),
-               (u32)__builtin_amdgcn_update_dpp(0, (int)v.bc, CTRL, ROW_MASK, 0xf, false),
-               (u32)__builtin_amdgcn_update_dpp((int)AM_ALL, (int)v.am, CTRL, ROW_MASK, 0xf, false)};
-}
-__device__ __forceinline__ Agg agg_readlane(const Agg &v, int l) {
-    return Agg{__builtin_amdgcn_readlane(v.d, l),
-               (u32)__builtin_amdgcn_readlane((int)v.w, l),
-               (u32)__builtin_amdgcn_readlane((int)v.s, l),
-               (u32)__builtin_amdgcn_readlane((int)v.nb, l),
-               (u32)__builtin_amdgcn_readlane((int)v.bc, l),
-               (u32)__builtin_amdgcn_readlane((int)v.am, l)};
-}
-__device__ __forceinline__ Agg agg_row_scan(Agg v) {  // inclusive inside rows of 16 lanes
-    v = agg_combine(agg_dpp<0x111, 0xf>(v), v);
-    v = agg_combine(agg_dpp<0x112, 0xf>(v), v);
-    v = agg_combine(agg_dpp<0x114, 0xf>(v), v);
-    v = agg_combine(agg_dpp<0x118, 0xf>(v), v);
-    return v;
-}
-__device__ __forceinline__ Agg agg_wave_inclusive(Agg v) {
-    v = agg_row_scan(v);
-    v = agg_combine(agg_dpp<0x142, 0xa>(v), v);  // row_bcast:15 -> rows 1, 3
-    v = agg_combine(agg_dpp<0x143, 0xc>(v), v);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 // LDS image of a tile's kinds: s_kind[4 + j] = kind of token t0 + j (K_BAD beyond the end), [2] [3] the two
 // tokens in front of the tile, [4 + S2_TILE] the one behind it
 static constexpr int KIND_LDS = S2_TILE + 8;
@@ -420,47 +518,91 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
     }
 }
 
-// ---- pass 2: one block, exclusive scan over the tile aggregates (in place) + totals ---------------------------
-// Every thread owns K consecutive tiles (K <= 32 per round; one round up to 134 M tokens), so the block scans
-// once per round and the aggregates are read with four independent loads in flight per thread.
+// ---- pass 2: exclusive scan over the tile aggregates (in place) + totals: SCAN_SEGS blocks ---------------------
+// Inside a segment every thread owns K consecutive tiles (K <= 32 per round), so a block scans once per round
+// and the aggregates are read with four independent loads in flight per thread.
+__device__ __forceinline__ Agg tile_chunk_sum(const S2Dev &p, u32 first, u32 K, u32 hi) {
+    Agg acc = agg_identity();
+    for (u32 j = 0; j < K; j += 4) {
+        Agg a[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 t = first + j + q;
+            a[q] = (j + q < K && t < hi) ? p.agg[t].a : agg_identity();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = agg_combine(acc, a[q]);
+    }
+    return acc;
+}
 __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
     __shared__ Agg s_w[16];
-    __shared__ unsigned long long words64, bytes64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) {
-        words64 = 0;
-        bytes64 = 0;
+    __shared__ unsigned long long s_w64[16], s_s64[16];
+    __shared__ SegSum s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), seg = blockIdx.x;
+    u64 lo64, hi64;
+    seg_range(p.tiles, 64, seg, lo64, hi64);
+    const u32 lo = (u32)lo64, hi = (u32)hi64;
+    // pass 1: the segment's aggregate (32-bit fields wrap; the two sizes are also summed in 64 bits)
+    Agg seg_acc = agg_identity();  // meaningful in every thread after the loop
+    unsigned long long w64 = 0, s64 = 0;
+    for (u32 start = lo; start < hi; start += 1024u * 32u) {
+        const u32 left = hi - start;
+        const u32 K = left >= 1024u * 32u ? 32u : (left + 1023u) / 1024u;
+        const Agg acc = tile_chunk_sum(p, start + (u32)tid * K, K, hi);
+        unsigned long long ws = acc.w, bs = acc.s;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            ws += (unsigned long long)__shfl_xor((long long)ws, sh, 64);
+            bs += (unsigned long long)__shfl_xor((long long)bs, sh, 64);
+        }
+        const Agg incl = agg_wave_inclusive(acc);
+        if (lane == 63) {
+            s_w[wave] = incl;
+            s_w64[wave] = ws;
+            s_s64[wave] = bs;
+        }
+        __syncthreads();
+        Agg t = lane < 16 ? s_w[lane] : agg_identity();
+        seg_acc = agg_combine(seg_acc, agg_readlane(agg_row_scan(t), 15));
+        for (int w = 0; w < 16; w++) {
+            w64 += s_w64[w];
+            s64 += s_s64[w];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        SegSum own;
+        own.a = seg_acc;
+        own.w = w64;
+        own.s = s64;
+        if (lane == 0) seg_publish(&p.seg_tiles[seg], own);
+        const SegSum before = seg_lookback(p.seg_tiles, seg, lane, p.st);
+        if (lane == 0) {
+            s_before = before;
+            if (seg == SCAN_SEGS - 1) {
+                const Agg tot = agg_combine(before.a, seg_acc);
+                const unsigned long long words64 = before.w + w64, bytes64 = before.s + s64;
+                p.st->final_depth = tot.d;
+                p.st->tape_len = words64 + 2ull;  // + opening root + closing root
+                p.st->strings_len = p.sv.qm ? p.st->strings_len_masks : bytes64;
+                p.st->records = tot.nb;
+                p.st->n_br = tot.bc;
+                // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
+                p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am);
+                if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
+                if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
+            }
+        }
     }
     __syncthreads();
-    Agg carry = agg_identity();  // everything in front of the round
-    for (u32 start = 0; start < p.tiles; start += 1024u * 32u) {
-        const u32 left = p.tiles - start;
+    // pass 2: exclusive prefixes in place
+    Agg carry = s_before.a;
+    for (u32 start = lo; start < hi; start += 1024u * 32u) {
+        const u32 left = hi - start;
         const u32 K = left >= 1024u * 32u ? 32u : (left + 1023u) / 1024u;
         const u32 first = start + (u32)tid * K;
-        Agg acc = agg_identity();
-        for (u32 j = 0; j < K; j += 4) {
-            Agg a[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32 t = first + j + q;
-                a[q] = (j + q < K && t < p.tiles) ? p.agg[t].a : agg_identity();
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc = agg_combine(acc, a[q]);
-        }
-        // 64-bit totals of the round (the 32-bit fields of the scan wrap; a failed size check needs the true sums)
-        {
-            unsigned long long ws = acc.w, bs = acc.s;
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) {
-                ws += (unsigned long long)__shfl_xor((long long)ws, sh, 64);
-                bs += (unsigned long long)__shfl_xor((long long)bs, sh, 64);
-            }
-            if (lane == 0) {
-                atomicAdd(&words64, ws);
-                atomicAdd(&bytes64, bs);
-            }
-        }
+        const Agg acc = tile_chunk_sum(p, first, K, hi);
         const Agg incl = agg_wave_inclusive(acc);
         if (lane == 63) s_w[wave] = incl;
         __syncthreads();
@@ -475,29 +617,17 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 t2 = first + j + q;
-                a[q] = (j + q < K && t2 < p.tiles) ? p.agg[t2].a : agg_identity();
+                a[q] = (j + q < K && t2 < hi) ? p.agg[t2].a : agg_identity();
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 t2 = first + j + q;
-                if (j + q < K && t2 < p.tiles) p.agg[t2].a = run;
+                if (j + q < K && t2 < hi) p.agg[t2].a = run;
                 run = agg_combine(run, a[q]);
             }
         }
         carry = agg_combine(carry, round_total);
         __syncthreads();
-    }
-    if (tid == 0) {
-        const Agg tot = carry;
-        p.st->final_depth = tot.d;
-        p.st->tape_len = words64 + 2ull;  // + opening root + closing root
-        p.st->strings_len = p.sv.qm ? p.st->strings_len_masks : bytes64;
-        p.st->records = tot.nb;
-        p.st->n_br = tot.bc;
-        // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
-        p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am);
-        if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
-        if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
     }
 }
 
@@ -888,7 +1018,7 @@ __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t stage2_workspace_bytes(size_t n) {
-    size_t b = sizeof(S2State) + 256;
+    size_t b = sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot) + 256;
     b += align_up(n + 16, 256) * 2;                 // br_info br_pctx
     b += align_up(n * 4, 256) * 10;                 // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off br_match
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
@@ -911,7 +1041,9 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
         w += align_up(bytes, 256);
         return r;
     };
-    p.st = reinterpret_cast<S2State *>(carve(sizeof(S2State)));
+    p.st = reinterpret_cast<S2State *>(carve(sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot)));  // zeroed together
+    p.seg_units = reinterpret_cast<SegSlot *>(reinterpret_cast<char *>(p.st) + sizeof(S2State));
+    p.seg_tiles = p.seg_units + SCAN_SEGS;
     p.msg = reinterpret_cast<const u8 *>(d_msg);
     p.len = len;
     p.pos = d_pos;
@@ -978,15 +1110,15 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
 hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,
                                  void *ws, hipStream_t stream, void *str_aux) {
     const S2Dev p = stage2_view(d_msg, len, d_pos, d_kind, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
-    hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State), stream);
+    hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot), stream);
     if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     if (p.sv.qm) {
         hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(k_str_scan, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(k_str_scan, dim3(SCAN_SEGS), dim3(1024), 0, stream, p);
     }
     hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, stream, p);
-    hipLaunchKernelGGL(k_s2_scan_tiles, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(k_s2_scan_tiles, dim3(SCAN_SEGS), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 
