@@ -12,7 +12,7 @@
 //                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
 //                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
 //                    separate records leave their tape offset
-//   k_min_level*, k_br_match, k_br_check   previous-smaller-value over the compact bracket view: partners' tape
+//   k_min_level, k_min_upper, k_br_match, k_br_check   previous-smaller-value over the compact bracket view: partners' tape
 //                    words, container contexts, and the grammar check of every gap against its context
 //   k_roots          root words
 // plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
@@ -838,11 +838,8 @@ __device__ __forceinline__ MinTree make_tree(const S2Dev &p) {
     }
     return mt;
 }
-__global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
-    const MinTree mt = make_tree(p);
-    if (l >= mt.nlev) return;
-    const int lane = threadIdx.x & 63;
-    for (u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); g < mt.size[l]; g += (u64)gridDim.x * 4) {
+__device__ __forceinline__ void min_level_groups(const S2Dev &p, const MinTree &mt, int l, u64 first, u64 stride, int lane) {
+    for (u64 g = first; g < mt.size[l]; g += stride) {  // one wave per group of 64 entries of the level below
         const u64 k = g * 64 + lane;
         i32 v = k < mt.size[l - 1] ? mt.lev[l - 1][k] : 0x7fffffff;
 #pragma unroll
@@ -853,7 +850,21 @@ __global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
         if (lane == 0) p.lev[l][g] = v;
     }
 }
-
+// levels 1 and 2 (n_br / 64 and n_br / 4096 entries): grid-stride
+__global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
+    const MinTree mt = make_tree(p);
+    if (l >= mt.nlev) return;
+    min_level_groups(p, mt, l, (u64)blockIdx.x * 4 + (threadIdx.x >> 6), (u64)gridDim.x * 4, threadIdx.x & 63);
+}
+// levels 3.. (n_br / 262144 entries and fewer): one block, level after level
+__global__ __launch_bounds__(1024) void k_min_upper(S2Dev p) {
+    const MinTree mt = make_tree(p);
+    for (int l = 3; l < mt.nlev; l++) {
+        min_level_groups(p, mt, l, (u64)(threadIdx.x >> 6), 16, threadIdx.x & 63);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 
 // ---- bracket partners, contexts and the grammar check of every gap ----------------------------------------------
 // Every bracket asks one previous-smaller-value question over the compact view (sj_stage2.h: bracket_resolve is the
@@ -1137,13 +1148,14 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, c
     if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_numbers, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    for (int l = 1; l < p.nlev; l++) {  // grid-stride: the kernels use the real bracket count
+    for (int l = 1; l < p.nlev && l <= 2; l++) {  // grid-stride: the kernels use the real bracket count
         const u64 want = (p.lev_size[l] + 3) / 4;
         hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
     }
+    if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_br_check, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_roots, dim3(256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_roots, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
