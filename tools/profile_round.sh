@@ -16,3 +16,4 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o s1 -- $S1 > $OUT/pmc_sq2.log 2>&1
 cd $REPO && python tools/summarize_prof.py $OUT $OUT/summary.txt > /dev/null
 grep -h "^{" $OUT/trace.log | tail -1 > $OUT/bench.json
+python tools/make_pmc_json.py $OUT/summary.txt $OUT/stage1_pmc.json "profiles/${1:-prof_round}_bench_rocprofv3_summary.txt (tools/profile_round.sh)" > /dev/null
