@@ -3,18 +3,20 @@
 // The reference builds the tape with a sequential goto state machine over the structural
 // indexes (unifiedMachine, stage2_build_tape_amd64.go:160-446).  Here every structural index
 // ("token") is handled by an independent lane; the state the machine carries is recovered from
-// prefix scans and nearest-smaller-value queries over the token array:
+// one prefix scan over the tokens and previous-smaller-value queries over the brackets:
 //
-//   depth[i]     = (# '{' '[' - # '}' ']') over tokens 0..i            (+ scan)
-//   tape_off[i]  = 1 + sum of tape words of tokens < i                 (+ scan; word 0 is the root)
-//   str_off[i]   = sum of unescaped lengths of copied strings < i      (+ scan) -> Strings.B offsets
-//   last_br[i]   = index+1 of the last bracket token <= i              (max scan)
-//   match / parent of a bracket = "previous smaller value" of depth[]  (64-ary min tree)
+//   depth, tape offset, Strings.B offset, record ordinal, bracket ordinal   sums of per-token elements
+//   allowed contexts of the gap a token lies in                             segmented AND (segments start behind
+//                                                                           brackets), carried as a bit function
+//   partner of a close bracket / parent of an open bracket                  "last bracket in front with depth <= q"
+//                                                                           over the compact bracket view (min tree)
 //
-// and the grammar is checked per token against its predecessor(s) and the type of the innermost
-// open container ("context"); DESIGN.md lists the rule table and why it accepts exactly the
-// documents the machine accepts.  Any violation sets one global error flag; like the reference,
-// a failed parse returns no tape, so only the first-violation-free prefix needs exact bookkeeping.
+// The grammar is a per-token rule over (kind, previous kinds, context of the innermost open container);
+// it is evaluated for all three contexts at once and checked once per bracket against the context the
+// bracket pass derives.  Any violation sets one global error flag; like the
+// reference, a failed parse returns no tape, so only the first-violation-free prefix needs exact bookkeeping.
+// csrc/host_selftest.cpp runs these functions as plain loops (the CPU test-suite checks them against the
+// oracle); csrc/stage2.hip holds the kernels.
 #pragma once
 #include <stdint.h>
 
