@@ -8,7 +8,7 @@
 // Passes over the tokens (one token = one structural index):
 //   k_s2_reduce      scan element per token from the token kinds (written by stage 1), one aggregate per 4096-token tile
 //   k_s2_scan_tiles  exclusive scan of the tile aggregates (one block) + totals: tape length, records, brackets
-//   k_s2_emit        rebuilds the elements, scans inside the tile, and writes every tape word that does not depend
+//   k_s2_emit        (512 threads x 8 tokens) rebuilds the elements, scans inside the tile, and writes every tape word that does not depend
 //                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
 //                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
 //                    separate records leave their tape offset
@@ -28,10 +28,11 @@
 
 namespace sj {
 
-static constexpr int S2_BLOCK = 1024;
-static constexpr int S2_ITEMS = 4;
-static constexpr int S2_TILE = S2_BLOCK * S2_ITEMS;
+static constexpr int S2_TILE = 4096;  // tokens per tile (the packed scan form PAgg is sized for it)
+static constexpr int S2_BLOCK = 512;  // k_s2_emit: 512 threads x 8 tokens
+static constexpr int S2_ITEMS = S2_TILE / S2_BLOCK;
 static constexpr int S2_WAVES = S2_BLOCK / 64;
+static_assert(S2_ITEMS == 8, "k_s2_emit reads the 8 kinds of a thread as one u64");
 static constexpr u32 DLEN_INVALID = 0xffffffffu;
 static constexpr u32 DLEN_COPY = 0x80000000u;
 
@@ -438,17 +439,6 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
 // tokens in front of the tile, [4 + S2_TILE] the one behind it
 static constexpr int KIND_LDS = S2_TILE + 8;
 
-// the four elements of a thread: kv = its packed kinds, the neighbours come from the LDS image
-__device__ __forceinline__ void tile_elements(const u32 *s_elut, const u8 *s_kind, u32 n, u32 base, int tid, u32 kv,
-                                              const u32 (&copied)[S2_ITEMS], PAgg (&e)[S2_ITEMS]) {
-    const u32 *k32 = reinterpret_cast<const u32 *>(s_kind);
-    const u32 prev = k32[tid], next = k32[tid + 2];
-    const u64 w = (u64)(prev >> 16) | ((u64)kv << 16) | ((u64)(next & 0xffu) << 48);
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++)
-        e[k] = base + k < n ? token_pelement(s_elut, (u32)(w >> (8 * k)), copied[k]) : pagg_identity();
-}
-
 // ---- pass 1: tile aggregates ------------------------------------------------------------------------------------
 // 256 threads x 16 tokens: a thread reads its 16 kinds with one 16-byte load; the neighbours' kinds come from LDS.
 static constexpr int RD_BLOCK = 256, RD_ITEMS = S2_TILE / RD_BLOCK;
@@ -633,7 +623,7 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
 
 // ---- pass 3: offsets + every tape word that needs no bracket partner ----------------------------------------------
 // Everything a token needs from memory (the 8 bytes of an atom, the emit-mask words of a string) is requested
-// for all four tokens of a thread before the first use: one memory round trip per tile, not one per token.
+// for four tokens of a thread at a time before the first use: two memory round trips per tile, not one per token.
 // Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
 // MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
 // lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
@@ -649,80 +639,71 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    if (tid < (int)LUT_SIZE) s_elut[tid] = c_elut.v[tid];
+    s_elut[tid] = c_elut.v[tid];
     if (tid == 0) s_cnt = 0;
     const u32 endpos = (u32)p.len;
-    uint4 pv = make_uint4(endpos, endpos, endpos, endpos);
-    u32 kv = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
-    if (base + 3 < p.n) {
-        pv = *reinterpret_cast<const uint4 *>(p.pos + base);
-        kv = *reinterpret_cast<const u32 *>(p.kind + base);
+    constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
+    u32 pp[S2_ITEMS];
+    u32 kv[2] = {NL4, NL4};
+    if (base + S2_ITEMS <= p.n) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(p.pos + base), b = *reinterpret_cast<const uint4 *>(p.pos + base + 4);
+        pp[0] = a.x; pp[1] = a.y; pp[2] = a.z; pp[3] = a.w;
+        pp[4] = b.x; pp[5] = b.y; pp[6] = b.z; pp[7] = b.w;
+        const uint2 k2 = *reinterpret_cast<const uint2 *>(p.kind + base);
+        kv[0] = k2.x;
+        kv[1] = k2.y;
     } else {
-        if (base < p.n) { pv.x = p.pos[base]; kv = (kv & 0xffffff00u) | (u32)p.kind[base]; }
-        if (base + 1 < p.n) { pv.y = p.pos[base + 1]; kv = (kv & 0xffff00ffu) | ((u32)p.kind[base + 1] << 8); }
-        if (base + 2 < p.n) { pv.z = p.pos[base + 2]; kv = (kv & 0xff00ffffu) | ((u32)p.kind[base + 2] << 16); }
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++) {
+            pp[k] = endpos;
+            if (base + k < p.n) {
+                pp[k] = p.pos[base + k];
+                kv[k >> 2] = (kv[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((u32)p.kind[base + k] << (8 * (k & 3)));
+            }
+        }
     }
-    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS]) = pv;
-    *reinterpret_cast<u32 *>(&s_kind[4 + tid * S2_ITEMS]) = kv;
+    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS]) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS + 4]) = make_uint4(pp[4], pp[5], pp[6], pp[7]);
+    *reinterpret_cast<uint2 *>(&s_kind[4 + tid * S2_ITEMS]) = make_uint2(kv[0], kv[1]);  // 4-byte aligned
     if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_NONE;
     if (tid == 2) {
         const bool more = (u64)t0 + S2_TILE < p.n;
         s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_NL;
         s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
     }
-    const u32 pp[S2_ITEMS] = {pv.x, pv.y, pv.z, pv.w};
     const MsgView mv{p.msg, p.len};
     // tokens behind the end of the message have kind K_NL and the identity element: they fall through everything
     u8 kd[S2_ITEMS];
     bool is_str[S2_ITEMS], is_atom[S2_ITEMS];
+    u32 dl[S2_ITEMS], copied[S2_ITEMS];  // selective copy: measured lengths
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
-        kd[k] = (u8)((kv >> (8 * k)) & 0xffu);
+        kd[k] = (u8)((kv[k >> 2] >> (8 * (k & 3))) & 0xffu);
         is_str[k] = kd[k] == K_STRING;
         is_atom[k] = (u32)(kd[k] - K_TRUE) < 3u;
-    }
-    // ---- loads that only depend on the token itself
-    u64 aw[S2_ITEMS];                    // atoms: the 8 message bytes at the token
-    u32 dl[S2_ITEMS], copied[S2_ITEMS];  // selective copy: measured lengths
-    u32 uc0[S2_ITEMS], cp0[S2_ITEMS];    // strings (masks): the three words of E(a0)
-    u64 em0[S2_ITEMS];
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        aw[k] = 0;
         dl[k] = copied[k] = 0;
-        uc0[k] = cp0[k] = 0;
-        em0[k] = 0;
-        if (is_atom[k]) aw[k] = load8_guarded(mv, pp[k]);
-        if (is_str[k]) {
-            if (MASKS) {
-                const u64 a0 = (u64)pp[k] + p.sv.lead + 1;
-                uc0[k] = p.unit_cnt[a0 >> 12];
-                cp0[k] = p.chunk_pre[a0 >> 6] & CHUNK_PRE_MASK;
-                em0[k] = p.em[a0 >> 6];
-            } else {
-                dl[k] = p.dlen[base + k];
-                copied[k] = (dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
-            }
+        if (!MASKS && is_str[k]) {
+            dl[k] = p.dlen[base + k];
+            copied[k] = (dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
         }
     }
     __syncthreads();
-    // ---- the second half of the string loads needs the next token's position (LDS)
-    u32 uc1[S2_ITEMS], cp1[S2_ITEMS];
-    u64 em1[S2_ITEMS];
+    // ---- elements and the scan inside the tile
+    PAgg e[S2_ITEMS];
+    {
+        const u32 *k32 = reinterpret_cast<const u32 *>(s_kind);
+        // byte stream: two kinds of the thread in front, the 8 own ones, one of the thread behind
+        const u32 D[4] = {k32[2 * tid], kv[0], kv[1], k32[2 * tid + 3]};
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        uc1[k] = cp1[k] = 0;
-        em1[k] = 0;
-        if (MASKS && is_str[k]) {
-            const u64 a1 = (u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead;
-            uc1[k] = p.unit_cnt[a1 >> 12];
-            cp1[k] = p.chunk_pre[a1 >> 6] & CHUNK_PRE_MASK;
-            em1[k] = p.em[a1 >> 6];
+        for (int k = 0; k < S2_ITEMS; k++) {
+            const int off = 2 + k;  // byte offset of ppk in the stream
+            const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
+            e[k] = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
         }
     }
-    PAgg e[S2_ITEMS];
-    tile_elements(s_elut, s_kind, p.n, base, tid, kv, copied, e);
-    const PAgg mine = pagg_comb<!MASKS>(pagg_comb<!MASKS>(e[0], e[1]), pagg_comb<!MASKS>(e[2], e[3]));
+    PAgg mine = e[0];
+#pragma unroll
+    for (int k = 1; k < S2_ITEMS; k++) mine = pagg_comb<!MASKS>(mine, e[k]);
     PAgg total;
     PAgg lp = pagg_block_exclusive<!MASKS, S2_WAVES>(mine, s_w, lane, wave, total);  // prefix inside the tile
     const Agg tp = p.agg[blockIdx.x].a;                                               // prefix of the tile
@@ -732,44 +713,74 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     for (int k = 0; k < S2_ITEMS; k++) nnum += kd[k] == K_NUM ? 1u : 0u;
     u32 slot = 0;
     if (nnum) slot = atomicAdd(&s_cnt, nnum);
+    // ---- two batches of four tokens: everything a batch needs from memory (the 8 bytes of an atom, the emit-mask
+    // words of a string) is requested before its first use
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-        bad |= am_value(e[k].z) == 0;                // legal in no context at all
-        // strings and atoms: first word under one predicate, computed without control flow
-        u64 w0 = atom_word(kd[k]), w1 = 0;
-        bool two = false;
-        if (MASKS) {
-            const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
-            const u32 b1 = (u32)(((u64)s_pos[tid * S2_ITEMS + k + 1] + p.sv.lead) & 63u);
-            const u64 so = (u64)uc0[k] + cp0[k] + (u64)popc64(em0[k] & ~(~0ull << b0));
-            const u64 se = (u64)uc1[k] + cp1[k] + (u64)popc64(em1[k] & ~(~0ull << b1));
-            if (is_str[k]) w0 = string_word(true, p.strings_base + so, 0);
-            w1 = se - so;
-            two = is_str[k];
-        } else {
-            const bool cp = (dl[k] & DLEN_COPY) != 0;
-            two = is_str[k] & (dl[k] != DLEN_INVALID);
-            if (is_str[k]) w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1);
-            w1 = dl[k] & ~DLEN_COPY;
+    for (int h = 0; h < S2_ITEMS; h += 4) {
+        u64 aw[4];           // atoms: the 8 message bytes at the token
+        u32 uc0[4], cp0[4];  // strings (masks): the three words of E(a0) and of E(a1)
+        u64 em0[4];
+        u32 uc1[4], cp1[4];
+        u64 em1[4];
+        u32 nxt[4];          // position of the next token
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = h + j;
+            aw[j] = 0;
+            uc0[j] = cp0[j] = uc1[j] = cp1[j] = 0;
+            em0[j] = em1[j] = 0;
+            nxt[j] = k + 1 < S2_ITEMS ? pp[k + 1] : s_pos[tid * S2_ITEMS + S2_ITEMS];
+            if (is_atom[k]) aw[j] = load8_guarded(mv, pp[k]);
+            if (MASKS && is_str[k]) {
+                const u64 a0 = (u64)pp[k] + p.sv.lead + 1, a1 = (u64)nxt[j] + p.sv.lead;
+                uc0[j] = p.unit_cnt[a0 >> 12];
+                cp0[j] = p.chunk_pre[a0 >> 6] & CHUNK_PRE_MASK;
+                em0[j] = p.em[a0 >> 6];
+                uc1[j] = p.unit_cnt[a1 >> 12];
+                cp1[j] = p.chunk_pre[a1 >> 6] & CHUNK_PRE_MASK;
+                em1[j] = p.em[a1 >> 6];
+            }
         }
-        if (is_atom[k]) bad |= !atom_valid_word(aw[k], p.len - pp[k], kd[k]);  // skipped by waves without atoms
-        if (two | is_atom[k]) p.tape[o] = w0;
-        if (two) {
-            p.tape[o + 1] = w1;
-            if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = h + j;
+            const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
+            bad |= am_value(e[k].z) == 0;                // legal in no context at all
+            // strings and atoms: first word under one predicate, computed without control flow
+            u64 w0 = atom_word(kd[k]), w1 = 0;
+            bool two = false;
+            if (MASKS) {
+                const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
+                const u32 b1 = (u32)(((u64)nxt[j] + p.sv.lead) & 63u);
+                const u64 so = (u64)uc0[j] + cp0[j] + (u64)popc64(em0[j] & ~(~0ull << b0));
+                const u64 se = (u64)uc1[j] + cp1[j] + (u64)popc64(em1[j] & ~(~0ull << b1));
+                if (is_str[k]) w0 = string_word(true, p.strings_base + so, 0);
+                w1 = se - so;
+                two = is_str[k];
+            } else {
+                const bool cp = (dl[k] & DLEN_COPY) != 0;
+                two = is_str[k] & (dl[k] != DLEN_INVALID);
+                if (is_str[k]) w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1);
+                w1 = dl[k] & ~DLEN_COPY;
+            }
+            if (is_atom[k]) bad |= !atom_valid_word(aw[j], p.len - pp[k], kd[k]);  // skipped by waves without atoms
+            if (two | is_atom[k]) p.tape[o] = w0;
+            if (two) {
+                p.tape[o + 1] = w1;
+                if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
+            }
+            if ((u32)(kd[k] - K_OPEN_OBJ) < 4u) {
+                const u32 lbc = lp.x >> 14;
+                const u32 c = tp.bc + lbc;  // brackets in front of this one
+                const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
+                p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
+                p.br_off[c] = o;
+                p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
+            }
+            if (kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
+            if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
+            lp = pagg_comb<!MASKS>(lp, e[k]);
         }
-        if ((u32)(kd[k] - K_OPEN_OBJ) < 4u) {
-            const u32 lbc = lp.x >> 14;
-            const u32 c = tp.bc + lbc;  // brackets in front of this one
-            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
-            p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
-            p.br_off[c] = o;
-            p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
-        }
-        if (kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
-        if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
-        lp = pagg_comb<!MASKS>(lp, e[k]);
     }
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
     // the tile's numbers move to the global queue (coalesced; the order of the queue does not matter)
