@@ -375,17 +375,18 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 }
 
 // ---- flatten (flatten_bits_amd64.s:26-60, absolute positions instead of deltas) ------------
-// Each wave expands its own units: lanes scatter their positions into the wave's LDS window (which
-// held the masks: they are read into registers first), then the wave copies the window out with
-// coalesced 256-byte stores.  A unit with more than CAP positions takes several rounds.
-template <int BLOCK, int CH>
-__device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
+// Each wave expands its own units: lanes scatter their positions into the wave's LDS staging buffer, then the
+// wave copies the buffer out with coalesced 256-byte stores.  A unit with more positions than the buffer holds
+// (512: the window that held the masks; 1024 in the whole-parse kernel) takes several rounds.
+static constexpr u32 S1_STAGE_CAP = 1024;
+template <int BLOCK, int CH, bool BIG>
+__device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
                                              u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
                                              const u8 *s_klut) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
-    constexpr u32 CAP = CH * 256;  // u32 slots in the wave's window (CH * 2 * 64 u64)
+    constexpr u32 CAP = BIG ? S1_STAGE_CAP : (u32)CH * 256u;
     static_assert(UNITS <= 64, "one unit per lane in the prefix");
     // per-unit counts under the now known state, prefix over the units (lane u <-> unit u)
     const u32 v = lane < UNITS ? s_unit[lane] : 0u;
@@ -408,7 +409,6 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *pre, const u32 *
         if (unit_h && lane == 0 && ((u64)t * UNITS + (u64)(k * WAVES + wave)) * 4096 < lead + len_)
             unit_h[(u64)t * UNITS + (u64)(k * WAVES + wave)] = (u8)h;
     }
-    u32 *stage = reinterpret_cast<u32 *>(m);
     const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
 #pragma unroll
     for (int k = 0; k < CH; k++) {
@@ -420,7 +420,10 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, const u32 *pre, const u32 *
         const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
         const u32 loc = upto[k] - n;  // offset of this lane's first position inside the unit
         u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
-        __builtin_amdgcn_wave_barrier();  // the window is free: all masks are in registers / already copied out
+        __builtin_amdgcn_wave_barrier();  // the staging buffers are free: all masks are in registers / already copied out
+        // up to 512 positions fit the window that held the masks; the whole-parse kernel has a larger buffer for
+        // denser units (its copy-out is the expensive one: it also writes the token kinds)
+        u32 *stage = (!BIG || C <= (u32)CH * 256u) ? reinterpret_cast<u32 *>(m) : stage_big;
         // copies the first cnt staged positions to out_pos[gd ...] (and their kinds to kind_out)
         auto copy_out = [&](u32 cnt, u64 gd) {
             if (kind_out) {  // whole parse: the kind of every token next to its position (sj_stage2.h)
@@ -508,6 +511,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_res[4];  // look-back result of the current tile: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[2][WAVES][CH * 64];  // per chunk: inclusive structural counts of its unit, both hypotheses
+    __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];  // whole parse: positions of one dense unit
     __shared__ u8 s_klut[AUX ? 256 : 4];
 
     const int tid = threadIdx.x;
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH>(s_mask[ms][wave], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
+        err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         if (!has_next) break;
@@ -627,12 +631,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 // ---- launcher --------------------------------------------------------------------------
 // Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
 // allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
-static constexpr int S1_DEFAULT_VARIANT = 2;
+static constexpr int S1_DEFAULT_VARIANT = 1;
 
 struct S1Variant {
     int block, ch, wpe;
 };
-static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {256, 2, 5}, {1024, 2, 4}};
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {1024, 2, 4}};
 static S1Variant s1_variant() {
     static int v = -1;
     if (v < 0) {
@@ -711,8 +715,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         else                          \
             S1_LAUNCH2(B, C, W, false); \
     } while (0)
-    if (v.block == 256) S1_LAUNCH(256, 2, 5);
-    else if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
+    if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
     else S1_LAUNCH(512, 2, 4);
 #undef S1_LAUNCH2
 #undef S1_LAUNCH3

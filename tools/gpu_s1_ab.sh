@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the stage-1 block shapes on the GPU box: parity tests + kernel time per variant.
-# usage: tools/gpu_s1_ab.sh "0 1 2"   (0: 512x2, 1: 256x2, 2: 1024x2 = default)
+# usage: tools/gpu_s1_ab.sh "0 1"   (0: 512x2, 1: 1024x2 = default)
 mkdir -p gpurun_out
 for v in ${1:-0}; do
   echo "== variant $v"
