@@ -90,14 +90,13 @@ SJ_HDC u32 tape_words(u8 k, u8 next_kind, bool is_last) {
 
 // ---- strings: parse_string_amd64.s restated byte-serially (one string per lane) ----------------
 // digittoval with the DATA-section hole (bytes < 0x30 -> 0), see oracle/sjo_parse_string.c (Q3).
-SJ_HD i32 hex_digit(u8 b) {
-    if (b < 0x30) return 0;
-    if (b <= '9') return b - '0';
-    if (b >= 'A' && b <= 'F') return b - 'A' + 10;
-    if (b >= 'a' && b <= 'f') return b - 'a' + 10;
-    return -1;
+SJ_HDC i32 hex_digit(u8 b) {  // selects, no control flow: the string kernels call it under divergence
+    const u32 l = ((u32)b | 0x20u) - 'a', d = (u32)b - '0';
+    i32 v = l < 6u ? (i32)l + 10 : -1;
+    v = d < 10u ? (i32)d : v;
+    return b < 0x30 ? 0 : v;
 }
-SJ_HD u8 escape_value(u8 b) {  // escape_map, parse_string_amd64.s:38-69
+SJ_HDC u8 escape_value_of(u8 b) {  // escape_map, parse_string_amd64.s:38-69
     switch (b) {
     case '"': return 0x22;
     case '/': return 0x2f;
@@ -110,6 +109,20 @@ SJ_HD u8 escape_value(u8 b) {  // escape_map, parse_string_amd64.s:38-69
     default: return 0;
     }
 }
+struct EscapeLut {
+    u8 v[256];
+};
+constexpr EscapeLut make_escape_lut() {
+    EscapeLut t{};
+    for (u32 c = 0; c < 256; c++) t.v[c] = escape_value_of((u8)c);
+    return t;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ static const EscapeLut ESCAPE_LUT = make_escape_lut();
+#else
+static constexpr EscapeLut ESCAPE_LUT = make_escape_lut();
+#endif
+SJ_HD u8 escape_value(u8 b) { return ESCAPE_LUT.v[b]; }  // one load instead of a compare chain
 
 struct MsgView {
     const u8 *p;

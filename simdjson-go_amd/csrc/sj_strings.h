@@ -33,6 +33,19 @@ struct StrView {
     const u64 *qm, *q, *st;
     const u8 *unit_h;
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
+    // the 16 bytes at a .. a+15 as two little-endian words (two unaligned 8-byte loads away from the message ends)
+    SJ_HD void window16(u64 a, u64 &w0, u64 &w1) const {
+        if (a >= lead && a + 16 <= end) {
+            w0 = load_u64(base + a);
+            w1 = load_u64(base + a + 8);
+        } else {
+            w0 = w1 = 0;
+            for (u32 k = 0; k < 8; k++) {
+                w0 |= (u64)at(a + k) << (8 * k);
+                w1 |= (u64)at(a + 8 + k) << (8 * k);
+            }
+        }
+    }
     SJ_HD u64 sm(u64 c) const {
         const u64 m = qm[c];
         return (unit_h[c >> 6] ? ~m : m) & ~q[c];
@@ -49,20 +62,22 @@ struct UEscape {
     bool ok;
 };
 
-SJ_HD u32 hex4_at(const StrView &m, u64 p) {
-    const u32 d0 = (u32)hex_digit(m.at(p)), d1 = (u32)hex_digit(m.at(p + 1)), d2 = (u32)hex_digit(m.at(p + 2)),
-              d3 = (u32)hex_digit(m.at(p + 3));
+SJ_HD u32 hex4_of(u32 four) {  // four bytes, first digit in the low byte
+    const u32 d0 = (u32)hex_digit((u8)four), d1 = (u32)hex_digit((u8)(four >> 8)), d2 = (u32)hex_digit((u8)(four >> 16)),
+              d3 = (u32)hex_digit((u8)(four >> 24));
     return (d0 << 12) | (d1 << 8) | (d2 << 4) | d3;  // sign-extended -1 poisons the high bits
 }
 
 // is the unicode escape whose backslash is at `pos` a high surrogate (cp in D800..DBFF)?
 SJ_HD bool is_high_surrogate_escape(const StrView &m, u64 pos) {
-    return m.at(pos + 1) == 'u' && (hex4_at(m, pos + 2) & 0xfffffc00u) == 0xd800u;
+    u64 w0, w1;
+    m.window16(pos, w0, w1);
+    return (u8)(w0 >> 8) == 'u' && (hex4_of((u32)(w0 >> 16)) & 0xfffffc00u) == 0xd800u;
 }
 
 // The escape whose 'u' sits at aligned offset au (its starter at au - 1), restating the \u branch of
 // string_walk / parse_string_amd64.s: quote distance rule, the hex table quirk, surrogate pairs with an
-// unchecked low half, code points above 0x10ffff rejected.
+// unchecked low half, code points above 0x10ffff rejected.  Works on the 16 bytes from the backslash on.
 SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
     UEscape r;
     r.n = 0;
@@ -78,23 +93,23 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
         highs++;
     }
     if (highs & 1u) return r;  // validated (as far as the reference validates it) by the high half
-    u32 d = 12;
-    for (u32 j = 1; j < 12; j++)
-        if (m.at(pos + j) == '"') {
-            d = j;
-            break;
-        }
+    u64 w0, w1;
+    m.window16(pos, w0, w1);
+    // distance to the next raw quote among bytes 1..11 (12: none)
+    const u64 Q8 = 0x2222222222222222ull;
+    const u64 z0 = zero_bytes(w0 ^ Q8) & ~0xffull, z1 = zero_bytes(w1 ^ Q8) & 0x00000000ffffffffull;
+    const u32 d = z0 ? (u32)ctz64(z0) >> 3 : (z1 ? 8u + ((u32)ctz64(z1) >> 3) : 12u);
     if (d < 6) {
         r.ok = false;
         return r;
     }
-    u32 cp = hex4_at(m, pos + 2);
+    u32 cp = hex4_of((u32)(w0 >> 16));  // bytes 2..5
     if ((cp & 0xfffffc00u) == 0xd800u) {
-        if (d < 12 || m.at(pos + 6) != '\\' || m.at(pos + 7) != 'u') {
+        if (d < 12 || (u8)(w0 >> 48) != '\\' || (u8)(w0 >> 56) != 'u') {
             r.ok = false;
             return r;
         }
-        const u32 cp2 = hex4_at(m, pos + 8);
+        const u32 cp2 = hex4_of((u32)w1);  // bytes 8..11
         if ((cp | cp2) > 0xffffu) {
             r.ok = false;
             return r;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of experimental library builds: per-kernel times of the whole-parse legs.  usage: tools/exp_s2.sh name...
+# A/B of library builds (simdjson-go_amd/exp_<name>.so): per-kernel times of the whole-parse legs under rocprofv3.
+# usage: tools/ab_parse.sh name...
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for n in "$@"; do
