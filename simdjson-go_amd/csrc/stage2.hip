@@ -321,11 +321,13 @@ __constant__ SelLut c_sel = make_sel_lut();
 // Pass 2 of the string path: one 4 KiB unit per wave, one 64-byte chunk per lane.  A chunk is compacted four
 // bytes at a time: v_perm_b32 squeezes the emitted bytes of a dword together and one unaligned LDS store
 // appends them; the up to four stale bytes such a store leaves behind the lane's data are repaired after a wave
-// barrier, when every lane rewrites the first four bytes of its own region.  Chunks with escapes (flagged by
+// barrier, when every lane rewrites the first four bytes of its own region (kept in a register).  Chunks with escapes (flagged by
 // k_str_masks) first patch the translated bytes into their LDS copy of the chunk (sj_strings.h).
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
-    __shared__ u32 s_in[4][16][64];                                  // chunks with escapes, dword-major (bank = lane)
-    __shared__ __attribute__((aligned(16))) u8 s_out[4][4096 + 16];  // the unit's unescaped bytes
+    // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
+    // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
+    // unit's unescaped bytes.
+    __shared__ __attribute__((aligned(16))) u8 s_io[4][4096 + 16];
     __shared__ u32 s_sel[16];
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
     __syncthreads();
@@ -340,12 +342,15 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const u32 n = (u32)popc64(em);
     const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
     if (total == 0) return;  // wave-uniform
-    u8 *out = &s_out[wave][pre];
-    u8 *in8 = reinterpret_cast<u8 *>(&s_in[wave][0][0]);
+    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit (needed at the very end)
+    u8 *out = &s_io[wave][pre];
+    u32 head = 0;
+    u8 *in8 = &s_io[wave][0];
+    u32 *in32 = reinterpret_cast<u32 *>(in8);
     auto byte_ix = [&](u32 q) { return ((q >> 2) * 64 + lane) * 4 + (q & 3); };
+    u32 w[16];
     if (em != 0) {  // the chunk holds message bytes: its 64-byte line is readable
         const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + c * 64);
-        u32 w[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 v = src[q];
@@ -353,39 +358,44 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         }
         if (patched) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) s_in[wave][q][lane] = w[q];
+            for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
             str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
 #pragma unroll
-            for (int q = 0; q < 16; q++) w[q] = s_in[wave][q][lane];
+            for (int q = 0; q < 16; q++) w[q] = in32[q * 64 + lane];
         }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // every lane has its chunk in registers: the window turns into the output
+    if (em != 0) {
         u32 o = 0;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const u32 nib = (u32)(em >> (4 * q)) & 15u;
-            *reinterpret_cast<u32 *>(out + o) = __builtin_amdgcn_perm(0u, w[q], s_sel[nib]);
+            const u32 cd = __builtin_amdgcn_perm(0u, w[q], s_sel[nib]);
+            *reinterpret_cast<u32 *>(out + o) = cd;
+            head |= (u32)((u64)cd << (8u * (o < 4u ? o : 4u)));  // the lane's first four bytes, kept for the repair
             o += (u32)__builtin_popcount(nib);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (em != 0) {  // the first four bytes again: the lane in front may have left stale bytes there
-        u32 j = 0;
-        if (patched) {
-            for (u64 r = em; r != 0 && j < 4; r &= r - 1, j++) out[j] = in8[byte_ix((u32)ctz64(r))];
-        } else {
-            for (u64 r = em; r != 0 && j < 4; r &= r - 1, j++) out[j] = p.sv.base[c * 64 + (u32)ctz64(r)];
-        }
+    // the first four bytes again: the lane in front may have left stale bytes there
+    if (n >= 4) {
+        *reinterpret_cast<u32 *>(out) = head;
+    } else {
+        if (n > 0) out[0] = (u8)head;
+        if (n > 1) out[1] = (u8)(head >> 8);
+        if (n > 2) out[2] = (u8)(head >> 16);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
     if (g + total > p.strings_cap) return;
     u8 *dst = p.strings + g;
     const u32 words = total >> 2;
     for (u32 i = lane; i < words; i += 64)  // unaligned 4-byte global stores are fine on gfx950
-        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&s_out[wave][4 * i]);
+        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&s_io[wave][4 * i]);
     const u32 tail = words * 4 + lane;
-    if (tail < total) dst[tail] = s_out[wave][tail];
+    if (tail < total) dst[tail] = s_io[wave][tail];
 }
 
 // ---- the token scan ----------------------------------------------------------------------------------------
