@@ -651,6 +651,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
     s_elut[tid] = c_elut.v[tid];
     if (tid == 0) s_cnt = 0;
+    const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     u32 pp[S2_ITEMS];
@@ -716,7 +717,6 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     for (int k = 1; k < S2_ITEMS; k++) mine = pagg_comb<!MASKS>(mine, e[k]);
     PAgg total;
     PAgg lp = pagg_block_exclusive<!MASKS, S2_WAVES>(mine, s_w, lane, wave, total);  // prefix inside the tile
-    const Agg tp = p.agg[blockIdx.x].a;                                               // prefix of the tile
     bool bad = false;
     u32 nnum = 0;  // numbers of this thread
 #pragma unroll

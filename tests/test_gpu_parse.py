@@ -181,6 +181,37 @@ def test_multi_tile_documents(ctx):
     check(ctx, b"[" + b",".join([fixtures.load("canada").strip()] * 4) + b"]", False, "canada x4")
 
 
+def test_concurrent_contexts():
+    """One context per concurrent parse (the reference's goroutine-per-parse model, benchmarks_test.go:60-75):
+    four host threads parse different documents on the same GPU at the same time; every result must be the oracle's."""
+    import threading
+    import sjhip
+    docs = [(workloads.c2_twitter_array(3), False), (fixtures.load("parking-citations") * 3, True),
+            (b"[" + b",".join([fixtures.load("canada").strip()] * 2) + b"]", False),
+            (b"[" + b",".join(b'{"k":[%d,{"z":"v%d"}]}' % (i, i) for i in range(40000)) + b"]", False)]
+    refs = [O.parse(d, ndjson=nd, copy_strings=True) for d, nd in docs]
+    errors = []
+
+    def worker(k):
+        try:
+            c = sjhip.Context(0)
+            d, nd = docs[k]
+            for _ in range(6):
+                pj = c.parse(d, ndjson=nd, copy_strings=True)
+                if not (np.array_equal(pj.Tape, refs[k].tape) and np.array_equal(pj.Strings, refs[k].strings)):
+                    errors.append((k, "mismatch"))
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(docs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_full_size_properties(ctx):
     """BASELINE sizes: lengths are checked against the closed forms of SURVEY.md §8d and the tape
     of every copy must be copy 0's tape rebased (a checksum of the structure, not of the data)."""
