@@ -105,7 +105,9 @@ extern "C" uint64_t sj_selftest_finalize(uint64_t st, uint64_t ws, uint64_t qm, 
 extern "C" int sj_selftest_parse_number(const uint8_t *buf, size_t len, uint64_t *tag, uint64_t *val, int *used_bignum) {
     u32 numlen = 0;
     *used_bignum = 0;
-    int st = parse_number(buf, (u32)len, tag, val, &numlen);
+    u8 head[32] = {0};  // like k_numbers: the first 32 bytes are parsed from a copy
+    for (size_t k = 0; k < 32 && k < len; k++) head[k] = buf[k];
+    int st = parse_number_head32(head, buf, len, tag, val, &numlen);
     if (st == NUM_NEEDS_BIGNUM) {
         static Big X, Y;
         *used_bignum = 1;

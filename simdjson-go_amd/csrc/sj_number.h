@@ -309,4 +309,16 @@ SJ_HD int parse_number(const u8 *buf, u32 avail, u64 *tag, u64 *val, u32 *numlen
     return st;
 }
 
+// The kernels parse from a 32-byte copy of the head of the number (LDS: no dependent global byte loads); `full`
+// points at the number in the message, `rest` = bytes from there to the end of the message.  The copy may cut a
+// longer number anywhere -- behind a sign or a '.', where the pre-validation fails -- so both "used all 32 bytes"
+// and "failed" send a longer text to the message itself.
+SJ_HD int parse_number_head32(const u8 *head, const u8 *full, u64 rest, u64 *tag, u64 *val, u32 *numlen) {
+    const u32 avail = rest < 32 ? (u32)rest : 32u;
+    *numlen = 0;
+    int st = parse_number(head, avail, tag, val, numlen);
+    if (rest > 32 && (st == NUM_FAIL || *numlen == 32)) st = parse_number(full, (u32)rest, tag, val, numlen);
+    return st;
+}
+
 }  // namespace sj

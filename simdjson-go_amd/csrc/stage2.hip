@@ -824,9 +824,7 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p) {
         }
         u64 tag = 0, val = 0;
         u32 numlen = 0;
-        const u32 avail = rest < 32 ? (u32)rest : 32u;
-        int st = parse_number(reinterpret_cast<const u8 *>(w), avail, &tag, &val, &numlen);
-        if (numlen == 32 && rest > 32) st = parse_number(p.msg + at, (u32)rest, &tag, &val, &numlen);
+        const int st = parse_number_head32(reinterpret_cast<const u8 *>(w), p.msg + at, rest, &tag, &val, &numlen);
         if (st == NUM_FAIL) {
             bad = true;
         } else {

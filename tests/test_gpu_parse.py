@@ -118,6 +118,16 @@ def test_float_rounding_torture(ctx):
         check(ctx, ("[" + ",".join(docs[i:i + 500]) + "]").encode(), False, "floats")
 
 
+def test_numbers_cut_by_the_32_byte_window(ctx):
+    nums = workloads.window_cut_numbers()
+    for n in nums[-7:]:  # malformed ones: each alone
+        check(ctx, ("[" + n + "]").encode(), False, "cut-bad")
+    good = nums[:-7]
+    for i in range(0, len(good), 200):
+        check(ctx, ("[" + ",".join(good[i:i + 200]) + "]").encode(), False, "cut")
+        check(ctx, ("[ " + " , ".join(good[i:i + 200]) + " ]").encode(), False, "cut-spaced")
+
+
 def test_random_documents(ctx):
     rnd = random.Random(5)
     rng = np.random.default_rng(7)
@@ -179,6 +189,104 @@ def test_multi_tile_documents(ctx):
     check(ctx, workloads.c2_twitter_array(12), False, "twitter x12")
     check(ctx, fixtures.load("parking-citations") * 12, True, "parking x12")
     check(ctx, b"[" + b",".join([fixtures.load("canada").strip()] * 4) + b"]", False, "canada x4")
+
+
+def _random_value(rnd, depth):
+    r = rnd.random()
+    if depth > 7 or r < 0.35:
+        k = rnd.randrange(12)
+        if k == 0:
+            return rnd.choice(["true", "false", "null"])
+        if k == 1:
+            return str(rnd.randrange(-10**18, 10**18))
+        if k == 2:
+            return repr(rnd.uniform(-1e6, 1e6))
+        if k == 3:
+            return "%d.%de%+d" % (rnd.randrange(10**rnd.randrange(1, 25)), rnd.randrange(10**6), rnd.randrange(-330, 310))
+        if k == 4:
+            return str(rnd.randrange(2**63 - 5, 2**64 + 5))
+        # strings: plain runs of every length around the 64-byte / 4 KiB boundaries, escapes, unicode, surrogates
+        parts = []
+        for _ in range(rnd.randrange(0, 6)):
+            c = rnd.randrange(9)
+            if c < 4:
+                parts.append("abcdefghijklmnopqrstuvwxyz0123456789 ,:{}[]"[rnd.randrange(43)] * rnd.choice([1, 3, 7, 31, 63, 64, 65, 200]))
+            elif c == 4:
+                parts.append(rnd.choice(['\\n', '\\t', '\\"', '\\\\', '\\/', '\\b', '\\f', '\\r']))
+            elif c == 5:
+                parts.append("\\u%04x" % rnd.choice([0x41, 0xe9, 0x20ac, 0x7ff, 0x800, 0xffff, 0x0]))
+            elif c == 6:
+                parts.append("\\ud83d\\ude00" if rnd.random() < 0.8 else "\\ud800\\u0041")
+            elif c == 7:
+                parts.append("\u00e9\u4e16\U0001f600")
+            else:
+                parts.append("\\" * (2 * rnd.randrange(1, 40)))
+        return '"' + "".join(parts) + '"'
+    if r < 0.65:
+        return "[" + ",".join(_random_value(rnd, depth + 1) for _ in range(rnd.randrange(0, 6))) + "]"
+    return "{" + ",".join('"k%d":%s' % (i, _random_value(rnd, depth + 1)) for i in range(rnd.randrange(0, 6))) + "}"
+
+
+def _random_records(seed, nbytes):
+    rnd = random.Random(seed)
+    lines = []
+    size = 0
+    while size < nbytes:
+        v = _random_value(rnd, 0)
+        if v[0] not in "[{":
+            v = "[" + v + "]"
+        v = v.replace(",", "," + rnd.choice(["", " ", "\t", "  "]))
+        if O.parse(v.encode("utf-8"), ndjson=False, copy_strings=True).rc != 0:
+            continue  # e.g. a float that overflows: the document must be one the reference accepts
+        lines.append(v)
+        size += len(v) + 1
+    return rnd, lines
+
+
+def test_large_random_ndjson(ctx):
+    """~20 MB of generated records in one ParseND: every tile / unit / chunk boundary falls somewhere inside
+    strings, escapes, numbers and nested containers; whole and sharded parses must equal the oracle's."""
+    from sjhip import ndshard
+    rnd, lines = _random_records(20260922, 20 << 20)
+    doc = ("\n".join(lines) + rnd.choice(["", "\n", "\n\n "])).encode("utf-8")
+    check(ctx, doc, True, "random-nd")
+    for copy_strings in (True, False):
+        ref = O.parse(doc, ndjson=True, copy_strings=copy_strings)
+        assert ref.rc == 0
+        trim, begin, finish = ndshard.device_callbacks(ctx, copy_strings)
+        world = 5
+        sizes = []
+        for a, b in ndshard.record_cuts(doc, world):
+            off, ln = trim(doc[a:b])
+            sizes.append((0, 0) if ln == 0 else begin(doc[a + off:a + off + ln]))
+        tapes, strs = [], []
+        for r in range(world):
+            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes, copy_strings)
+            tapes.append(t)
+            strs.append(s)
+        assert np.array_equal(np.concatenate(tapes), ref.tape)
+        assert np.array_equal(np.concatenate(strs), ref.strings)
+    # one corrupted byte somewhere in the middle: same verdict as the oracle
+    for _ in range(12):
+        b = bytearray(doc)
+        b[rnd.randrange(len(b))] = rnd.choice(b'{}[]:,"\\ 1tx\n')
+        check(ctx, bytes(b), True, "random-nd-mut")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_documents_at_scale(ctx, seed):
+    """the same generator, other seeds: one JSON document (records as the members of an array nested a few
+    hundred levels deep) and the records as NDJSON with blank lines"""
+    rnd, lines = _random_records(seed, 6 << 20)
+    depth = rnd.randrange(1, 300)
+    doc = ('{"r":' * depth + "[" + ",\n".join(lines) + "]" + "}" * depth).encode("utf-8")
+    check(ctx, doc, False, "random-array")
+    nd = ("\n\n".join(lines) + "\n").encode("utf-8")
+    check(ctx, nd, True, "random-nd-blank-lines")
+    for _ in range(6):
+        b = bytearray(doc)
+        b[rnd.randrange(len(b))] = rnd.choice(b'{}[]:,"\\ 1tx\n')
+        check(ctx, bytes(b), False, "random-array-mut")
 
 
 def test_concurrent_contexts():

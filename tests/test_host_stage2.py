@@ -145,6 +145,16 @@ def test_number_parsing_against_strtod(L):
     assert nbig > 1000  # the big-integer tie-break path was exercised
 
 
+def test_numbers_cut_by_the_32_byte_window(L):
+    import workloads
+    nums = workloads.window_cut_numbers()
+    for n in nums[-7:]:
+        check(L, ("[" + n + "]").encode(), False, "cut-bad")
+    good = nums[:-7]
+    for i in range(0, len(good), 200):
+        check(L, ("[" + ",".join(good[i:i + 200]) + "]").encode(), False, "cut")
+
+
 def test_trim_space(L):
     OL = O.lib()
     samples = [b"", b"  x ", b"\x0b\x0cx\x0b", "  x　".encode(), b"\xc2\x85x\xc2\xa0", b"\xe2\x80\xa8{}\xe2\x80\xa9",

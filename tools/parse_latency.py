@@ -1,0 +1,14 @@
+import sys, os, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+for p in (os.path.join(ROOT, "simdjson-go_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import sjhip, fixtures
+c = sjhip.Context(0)
+for name in ("twitter", "canada", "twitterescaped", "parking-citations"):
+    d = fixtures.load(name)
+    nd = name.startswith("parking")
+    for _ in range(5): c.parse(d, ndjson=nd)
+    t0 = time.perf_counter(); N = 100
+    for _ in range(N): c.parse(d, ndjson=nd)
+    dt = (time.perf_counter() - t0) / N
+    print(f"{name:20s} {len(d):9d} B  {dt*1e6:8.1f} us/parse  {len(d)/dt/1e9:6.2f} GB/s (host buffer -> tape on host)")
