@@ -118,6 +118,17 @@ def test_float_rounding_torture(ctx):
         check(ctx, ("[" + ",".join(docs[i:i + 500]) + "]").encode(), False, "floats")
 
 
+def test_byte_soup_with_controls_and_high_bytes(ctx):
+    """short random byte strings over an alphabet that includes control characters, DEL, bytes >= 0x80, unicode
+    escape material and number characters: every verdict and every accepted tape must be the oracle's"""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b'{}[]:,""\\\\u00dD8aAfF19 \n\t-+.eE0tn\x00\x1f\x7f\x80\xc3\xa9\xff', dtype=np.uint8)
+    for trial in range(2500):
+        body = bytes(alpha[rng.integers(0, alpha.size, int(rng.integers(1, 60)))])
+        check(ctx, body, bool(trial & 1), "soup2")
+        check(ctx, b'["' + body.replace(b'"', b"") + b'"]', False, "soup2-in-string")
+
+
 def test_numbers_cut_by_the_32_byte_window(ctx):
     nums = workloads.window_cut_numbers()
     for n in nums[-7:]:  # malformed ones: each alone
