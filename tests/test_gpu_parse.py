@@ -300,6 +300,37 @@ def test_random_documents_at_scale(ctx, seed):
         check(ctx, bytes(b), False, "random-array-mut")
 
 
+def test_parse_nd_stream():
+    """ParseNDStream (simdjson_amd64.go:101-216): blocks cut at record ends, parsed concurrently, delivered in
+    order; every block's ParsedJson is the oracle's ParseND of that block; the first bad block ends the stream."""
+    import io
+    import sjhip
+    park = fixtures.load("parking-citations")
+    stream = park * 24  # ~9 MB
+    bs = 1 << 20
+    blocks = list(sjhip.cut_blocks(io.BytesIO(stream), bs))
+    assert b"".join(blocks) == stream and all(b.endswith(b"\n") and len(b) >= bs for b in blocks[:-1])
+    for inflight in (1, 3):
+        got = list(sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=inflight))
+        assert len(got) == len(blocks)
+        for pj, blk in zip(got, blocks):
+            ref = O.parse(blk, ndjson=True, copy_strings=True)
+            assert ref.rc == 0
+            assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
+            assert pj.Message == bytes(blk[ref.msg_off:ref.msg_off + ref.msg_len])
+    # a broken record in the fourth block: three results, then the error
+    bad = bytearray(stream)
+    at = sum(len(b) for b in blocks[:3]) + 5000
+    bad[at:at + 1] = b"\x01" if bad[at:at + 1] != b"\x01" else b"\x02"
+    it = sjhip.parse_nd_stream(io.BytesIO(bytes(bad)), block_size=bs, inflight=2)
+    n_ok = 0
+    with pytest.raises(sjhip.ParseError):
+        for _ in it:
+            n_ok += 1
+    ref_bad = O.parse(bytes(bad), ndjson=True, copy_strings=True)
+    assert ref_bad.rc != 0 and n_ok == 3
+
+
 def test_concurrent_contexts():
     """One context per concurrent parse (the reference's goroutine-per-parse model, benchmarks_test.go:60-75):
     four host threads parse different documents on the same GPU at the same time; every result must be the oracle's."""

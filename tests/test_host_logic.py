@@ -79,3 +79,36 @@ def test_chunk_math_adversarial(built):
         got, err, inq = _st1(L, data, 0)
         if ok:
             assert np.array_equal(got, pos), k
+
+
+def test_stream_block_cutter():
+    """cut_blocks = the block cutter of ParseNDStream (simdjson_amd64.go:155-176); pure host logic"""
+    import io
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simdjson-go_amd"))
+    from sjhip.stream import cut_blocks
+    import random
+    rnd = random.Random(4)
+    for trial in range(50):
+        lines = [b"x" * rnd.randrange(0, 300) for _ in range(rnd.randrange(1, 200))]
+        data = b"\n".join(lines) + (b"\n" if trial & 1 else b"")
+        bs = rnd.choice([1, 7, 64, 1000, 1 << 20])
+        blocks = list(cut_blocks(io.BytesIO(data), bs))
+        assert b"".join(blocks) == data
+        assert all(len(b) >= bs and b.endswith(b"\n") for b in blocks[:-1])
+        assert all(len(b) > 0 for b in blocks)
+
+        class Raw(io.RawIOBase):  # a reader without readline and with short reads
+            def __init__(self, d):
+                self.d, self.p = d, 0
+
+            def readable(self):
+                return True
+
+            def readinto(self, b):
+                n = min(len(b), 13, len(self.d) - self.p)
+                b[:n] = self.d[self.p:self.p + n]
+                self.p += n
+                return n
+        assert b"".join(cut_blocks(Raw(data), bs)) == data
