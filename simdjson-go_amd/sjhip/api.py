@@ -100,20 +100,24 @@ class Context:
         return ms.value
 
     # ---- whole parse -----------------------------------------------------------------------
-    def parse(self, data, ndjson=False, copy_strings=True):
-        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    def parse(self, data, ndjson=False, copy_strings=True, reuse=None):
+        """Parse / ParseND.  `reuse`: a ParsedJson whose Tape / Strings capacity is recycled (the reference's
+        `reuse *ParsedJson`, simdjson_amd64.go:46-51): its arrays are overwritten."""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
         L = _lib.lib()
         rc = L.sjhip_parse(self._h, a.ctypes.data if a.size else None, a.size, flags, C.byref(tl), C.byref(sl),
                            C.byref(mo), C.byref(ml))
         self._check(rc)
-        tape = np.empty(tl.value, dtype=np.uint64)
-        strings = np.empty(sl.value, dtype=np.uint8)
-        rc = L.sjhip_fetch(self._h, tape.ctypes.data, strings.ctypes.data)
+        tape_buf = reuse._tape_buf if reuse is not None and reuse._tape_buf.size >= tl.value else \
+            np.empty(tl.value, dtype=np.uint64)
+        str_buf = reuse._str_buf if reuse is not None and reuse._str_buf.size >= sl.value else \
+            np.empty(sl.value, dtype=np.uint8)
+        rc = L.sjhip_fetch(self._h, tape_buf.ctypes.data, str_buf.ctypes.data)
         self._check(rc)
-        msg = bytes(a[mo.value: mo.value + ml.value])
-        return ParsedJson(msg, tape, strings)
+        msg = a[mo.value: mo.value + ml.value].tobytes()
+        return ParsedJson(msg, tape_buf[:tl.value], str_buf[:sl.value], tape_buf, str_buf)
 
     def parse_device(self, d_msg_ptr, length, ndjson=False, copy_strings=True):
         tl, sl = C.c_size_t(0), C.c_size_t(0)
@@ -132,12 +136,14 @@ class Context:
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 
-    __slots__ = ("Message", "Tape", "Strings")
+    __slots__ = ("Message", "Tape", "Strings", "_tape_buf", "_str_buf")
 
-    def __init__(self, message, tape, strings):
+    def __init__(self, message, tape, strings, tape_buf=None, str_buf=None):
         self.Message = message
         self.Tape = tape
         self.Strings = strings
+        self._tape_buf = tape if tape_buf is None else tape_buf  # capacity behind Tape / Strings (reuse)
+        self._str_buf = strings if str_buf is None else str_buf
 
 
 _DEFAULT = {}
@@ -152,12 +158,12 @@ def _default_ctx(device=0):
 
 def parse(b, reuse=None, copy_strings=True, ctx=None):
     """Parse(b, reuse, WithCopyStrings(copy_strings)) -- simdjson_amd64.go:66."""
-    return (ctx or _default_ctx()).parse(b, ndjson=False, copy_strings=copy_strings)
+    return (ctx or _default_ctx()).parse(b, ndjson=False, copy_strings=copy_strings, reuse=reuse)
 
 
 def parse_nd(b, reuse=None, copy_strings=True, ctx=None):
     """ParseND(b, reuse, ...) -- simdjson_amd64.go:82."""
-    return (ctx or _default_ctx()).parse(b, ndjson=True, copy_strings=copy_strings)
+    return (ctx or _default_ctx()).parse(b, ndjson=True, copy_strings=copy_strings, reuse=reuse)
 
 
 def stage1(b, ndjson=False, ctx=None):

@@ -18,31 +18,42 @@ from .api import Context, ParseError
 BLOCK_SIZE = 10 << 20  # tmpSize, simdjson_amd64.go:127
 
 
-def cut_blocks(reader, block_size=BLOCK_SIZE):
+def cut_blocks(reader, block_size=BLOCK_SIZE, pool=None):
     """The block cutter of ParseNDStream (simdjson_amd64.go:155-176): `block_size` bytes, then on to the end of the
-    current line; the last block is whatever is left.  Yields non-empty bytes objects whose concatenation is the
-    stream."""
-    if isinstance(reader, io.RawIOBase) or not hasattr(reader, "readline"):
+    current line; the last block is whatever is left.  Yields non-empty blocks whose concatenation is the stream:
+    bytes objects, or -- with `pool`, a queue of recycled bytearrays like the reference's tmpPool -- bytearrays
+    the consumer puts back into the pool when it is done with them."""
+    if isinstance(reader, io.RawIOBase) or not hasattr(reader, "readline") or not hasattr(reader, "readinto"):
         reader = io.BufferedReader(reader, buffer_size=max(block_size, 1 << 16))
 
-    def read_full(n):  # like bufio: short reads of the underlying stream are not the end of it
-        parts = []
-        while n > 0:
-            c = reader.read(n)
-            if not c:
-                break
-            parts.append(c)
-            n -= len(c)
-        return b"".join(parts)
-
     while True:
-        block = read_full(block_size)
-        if not block:
+        buf = None
+        if pool is not None:
+            try:
+                buf = pool.get_nowait()
+            except queue.Empty:
+                buf = None
+        if buf is None:
+            buf = bytearray(block_size)
+        elif len(buf) != block_size:
+            del buf[block_size:]
+            buf.extend(bytes(block_size - len(buf)))
+        view = memoryview(buf)
+        got = 0
+        while got < block_size:  # like bufio: short reads of the underlying stream are not the end of it
+            n = reader.readinto(view[got:])
+            if not n:
+                break
+            got += n
+        view.release()
+        if got == 0:
             return
-        if len(block) == block_size:  # a full block: finish the record it ends in
-            block += reader.readline()
-        yield block
-        if len(block) < block_size:
+        if got == block_size:  # a full block: finish the record it ends in
+            buf.extend(reader.readline())
+        else:
+            del buf[got:]
+        yield buf if pool is not None else bytes(buf)
+        if got < block_size:
             return
 
 
@@ -51,10 +62,10 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=2, device=0, reuse=N
 
     Mirrors `ParseNDStream(r, res, reuse)`: a block that fails to parse raises `ParseError` after all earlier
     blocks have been delivered and ends the stream (the reference sends `Stream{Error: ...}` and closes `res`);
-    normal exhaustion of the generator stands for the final `Stream{Error: io.EOF}`.  `reuse` is accepted for
-    signature parity: the device arenas of the contexts are what is recycled here.
+    normal exhaustion of the generator stands for the final `Stream{Error: io.EOF}`.  `reuse`: an optional
+    `queue.Queue`-like object the consumer puts finished ParsedJson values into; like the reference's `reuse`
+    channel it is polled without blocking and the Tape / Strings capacity of what it returns is recycled.
     """
-    del reuse
     inflight = max(1, int(inflight))
     contexts = queue.SimpleQueue()
     made = []
@@ -63,17 +74,26 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=2, device=0, reuse=N
         made.append(c)
         contexts.put(c)
 
+    blocks = queue.SimpleQueue()  # recycled input buffers (tmpPool, simdjson_amd64.go:129-131)
+
     def work(block):
         c = contexts.get()
+        old = None
+        if reuse is not None:
+            try:
+                old = reuse.get_nowait()  # `select { case v := <-reuse: ... default: }`, simdjson_amd64.go:181-190
+            except queue.Empty:
+                old = None
         try:
-            return c.parse(block, ndjson=True, copy_strings=True)  # pj.copyStrings = true, simdjson_amd64.go:180
+            return c.parse(block, ndjson=True, copy_strings=True, reuse=old)  # pj.copyStrings = true, :180
         finally:
             contexts.put(c)
+            blocks.put(block)  # Message was copied out of it
 
     pending = collections.deque()
     try:
         with concurrent.futures.ThreadPoolExecutor(max_workers=inflight) as pool:
-            for block in cut_blocks(reader, block_size):
+            for block in cut_blocks(reader, block_size, pool=blocks):
                 pending.append(pool.submit(work, block))
                 while len(pending) >= inflight + 1:  # one block cut ahead of the ones being parsed
                     yield pending.popleft().result()

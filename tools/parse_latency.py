@@ -23,3 +23,11 @@ for inflight in (1, 2, 4):
     nblk = sum(1 for _ in sjhip.parse_nd_stream(io.BytesIO(big), inflight=inflight))
     dt = time.perf_counter() - t0
     print(f"parse_nd_stream inflight={inflight}: {len(big)} B in {nblk} blocks, {dt*1e3:7.1f} ms, {len(big)/dt/1e9:5.2f} GB/s")
+    import queue
+    back = queue.Queue()
+    for rep in range(2):  # results handed back through `reuse` (second pass: every buffer recycled)
+        t0 = time.perf_counter()
+        for pj in sjhip.parse_nd_stream(io.BytesIO(big), inflight=inflight, reuse=back):
+            back.put(pj)
+        dt = time.perf_counter() - t0
+    print(f"   ... with reuse:          {dt*1e3:7.1f} ms, {len(big)/dt/1e9:5.2f} GB/s")
