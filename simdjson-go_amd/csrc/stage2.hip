@@ -774,10 +774,11 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
                 w1 = dl[k] & ~DLEN_COPY;
             }
             if (is_atom[k]) bad |= !atom_valid_word(aw[j], p.len - pp[k], kd[k]);  // skipped by waves without atoms
-            if (two | is_atom[k]) p.tape[o] = w0;
-            if (two) {
-                p.tape[o + 1] = w1;
+            if (two) {  // both words of a string with one 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
+                *reinterpret_cast<uint4 *>(p.tape + o) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
                 if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
+            } else if (is_atom[k]) {
+                p.tape[o] = w0;
             }
             if ((u32)(kd[k] - K_OPEN_OBJ) < 4u) {
                 const u32 lbc = lp.x >> 14;
