@@ -169,6 +169,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     std::vector<u64> v_qm(chunks, 0), v_q(chunks, 0), v_st(chunks, 0), v_em(chunks, 0), v_um(chunks, 0);
     std::vector<u8> v_h(units, 0);
     std::vector<uint16_t> v_pre(chunks, 0);
+    std::vector<ChunkRec> v_rec(chunks);
     std::vector<u32> v_ucnt(units, 0);
     g_qm = v_qm.data();
     g_q = v_q.data();
@@ -196,6 +197,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
                 v_pre[c] = (uint16_t)run;
+                v_rec[c] = ChunkRec{v_em[c], run | (str_chunk_has_escapes(sv, c) ? CHUNK_SLOW : 0u), 0u};
                 run += (u32)popc64(v_em[c]);
             }
             v_ucnt[u] = (u32)masks_total;
@@ -266,8 +268,8 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             if (!atom_valid(mv, pos[i], k)) bad = 1;
         } else if (k == K_STRING && copy) {
             const u64 a0 = (u64)pos[i] + 1, a1 = i + 1 < n ? pos[i + 1] : len;
-            const u64 so = emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a0);
-            const u64 se = emitted_before(v_ucnt.data(), v_pre.data(), v_em.data(), a1);
+            const u64 so = emitted_before(v_ucnt.data(), v_rec.data(), a0);
+            const u64 se = emitted_before(v_ucnt.data(), v_rec.data(), a1);
             tape[toff[i]] = string_word(true, strings_base + so, 0);
             tape[toff[i] + 1] = se - so;
         } else if (k == K_STRING && !strbad[i]) {

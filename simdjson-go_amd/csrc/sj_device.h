@@ -45,12 +45,12 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_p
 size_t stage1_workspace_bytes(size_t len);
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
 // String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / q / st / unit_h, the string
-// kernels of stage 2 add em / chunk_pre / unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
+// kernels of stage 2 add one 16-byte record per chunk (sj_strings.h ChunkRec) and unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
 // base of the message); everything is sized in whole 4 KiB units.
 struct StrAux {
     size_t units, chunks, bytes;
-    uint64_t *qm, *q, *st, *em;
-    uint16_t *chunk_pre;
+    uint64_t *qm, *q, *st;
+    void *rec;  // ChunkRec[chunks]
     uint32_t *unit_cnt;
     uint8_t *unit_h;
 };
@@ -67,8 +67,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.qm = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
     a.q = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
     a.st = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
-    a.em = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
-    a.chunk_pre = reinterpret_cast<uint16_t *>(carve(a.chunks * 2));
+    a.rec = carve(a.chunks * 16);
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
     a.bytes = (size_t)(w - reinterpret_cast<char *>(buf));

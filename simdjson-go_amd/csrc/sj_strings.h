@@ -140,8 +140,15 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
     return r;
 }
 
-// chunk_pre[] entries: bits 0-14 the emitted bytes of the unit in front of the chunk, bit 15 "the chunk takes
-// the byte-serial pass 2" (it holds an escape, or a unicode escape of the previous chunk reaches into it)
+// What pass 1 leaves per 64-byte chunk, one 16-byte record (one load for everything a consumer needs):
+//   em   emit mask
+//   pre  bits 0-14 the emitted bytes of the unit in front of the chunk, bit 15 "the chunk needs patching in
+//        pass 2" (it holds an escape, or a unicode escape of the previous chunk reaches into it)
+struct alignas(16) ChunkRec {
+    u64 em;
+    u32 pre;
+    u32 pad;
+};
 static constexpr u32 CHUNK_PRE_MASK = 0x7fffu, CHUNK_SLOW = 0x8000u;
 SJ_HD bool str_chunk_has_escapes(const StrView &m, u64 c) {
     if ((m.esc(c) & m.sm(c)) != 0) return true;
@@ -236,11 +243,11 @@ SJ_HD void str_chunk_patch(const StrView &m, u64 c, Put put) {
 }
 
 // E(a): emitted bytes in front of aligned offset a
-SJ_HD u64 emitted_before(const u32 *unit_base, const uint16_t *chunk_pre, const u64 *em, u64 a) {
-    const u64 c = a >> 6;
+SJ_HD u64 emitted_before(const u32 *unit_base, const ChunkRec *rec, u64 a) {
+    const ChunkRec r = rec[a >> 6];
     const u32 bit = (u32)(a & 63);
-    const u64 below = bit ? (em[c] & (~0ull >> (64 - bit))) : 0ull;
-    return (u64)unit_base[a >> 12] + (chunk_pre[c] & CHUNK_PRE_MASK) + (u64)popc64(below);
+    const u64 below = bit ? (r.em & (~0ull >> (64 - bit))) : 0ull;
+    return (u64)unit_base[a >> 12] + (r.pre & CHUNK_PRE_MASK) + (u64)popc64(below);
 }
 
 }  // namespace sj

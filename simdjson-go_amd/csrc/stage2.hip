@@ -89,8 +89,7 @@ struct S2Dev {
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
     // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
-    u64 *em;              // [chunks] emit mask
-    uint16_t *chunk_pre;  // [chunks] emitted bytes of the unit in front of the chunk
+    ChunkRec *rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
     u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
     u64 units;
 };
@@ -103,7 +102,6 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     u64 em, um;
     bool escapes;
     if (!str_chunk_masks(p.sv, c, &em, &um, &escapes)) atomicOr(&p.st->err, 1u);
-    p.em[c] = em;  // (the 'u' mask is only an intermediate: pass 2 re-derives the escapes of flagged chunks)
     const u32 n = (u32)popc64(em);
     u32 incl = n;
 #pragma unroll
@@ -111,7 +109,8 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
         const u32 o = __shfl_up(incl, s, 64);
         if (lane >= s) incl += o;
     }
-    p.chunk_pre[c] = (uint16_t)((incl - n) | (escapes ? CHUNK_SLOW : 0u));
+    // (the 'u' mask is only an intermediate: pass 2 re-derives the escapes of flagged chunks)
+    p.rec[c] = ChunkRec{em, (incl - n) | (escapes ? CHUNK_SLOW : 0u), 0u};
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
@@ -335,8 +334,9 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (c >= p.units * 64) return;
     const u64 unit = c >> 6;
-    const u64 em = p.em[c];
-    const u32 pre_raw = p.chunk_pre[c];
+    const ChunkRec rec = p.rec[c];
+    const u64 em = rec.em;
+    const u32 pre_raw = rec.pre;
     const u32 pre = pre_raw & CHUNK_PRE_MASK;
     const bool patched = (pre_raw & CHUNK_SLOW) != 0;
     const u32 n = (u32)popc64(em);
@@ -743,12 +743,13 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             if (is_atom[k]) aw[j] = load8_guarded(mv, pp[k]);
             if (MASKS && is_str[k]) {
                 const u64 a0 = (u64)pp[k] + p.sv.lead + 1, a1 = (u64)nxt[j] + p.sv.lead;
+                const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
                 uc0[j] = p.unit_cnt[a0 >> 12];
-                cp0[j] = p.chunk_pre[a0 >> 6] & CHUNK_PRE_MASK;
-                em0[j] = p.em[a0 >> 6];
+                cp0[j] = r0.pre & CHUNK_PRE_MASK;
+                em0[j] = r0.em;
                 uc1[j] = p.unit_cnt[a1 >> 12];
-                cp1[j] = p.chunk_pre[a1 >> 6] & CHUNK_PRE_MASK;
-                em1[j] = p.em[a1 >> 6];
+                cp1[j] = r1.pre & CHUNK_PRE_MASK;
+                em1[j] = r1.em;
             }
         }
 #pragma unroll
@@ -1118,8 +1119,7 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
     p.sv.end = p.sv.lead + len;
     p.sv.qm = p.sv.q = p.sv.st = nullptr;
     p.sv.unit_h = nullptr;
-    p.em = nullptr;
-    p.chunk_pre = nullptr;
+    p.rec = nullptr;
     p.unit_cnt = nullptr;
     p.units = 0;
     if (str_aux && p.copy_strings) {
@@ -1128,8 +1128,7 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
         p.sv.q = a.q;
         p.sv.st = a.st;
         p.sv.unit_h = a.unit_h;
-        p.em = a.em;
-        p.chunk_pre = a.chunk_pre;
+        p.rec = reinterpret_cast<ChunkRec *>(a.rec);
         p.unit_cnt = a.unit_cnt;
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
