@@ -30,7 +30,7 @@ static const u64 POW5_128[(POW5_MAX_Q - POW5_MIN_Q + 1) * 2] = SJ_POW5_TABLE_INI
 // parse_number.go:27-34
 enum : u8 { NF_PART = 1, NF_FLOATONLY = 2, NF_MINUS = 4, NF_EOV = 8, NF_DIGIT = 16, NF_MUSTDIGIT = 32 };
 
-SJ_HD u8 number_rune(u8 c) {  // isNumberRune, parse_number.go:36-60
+SJ_HDC u8 number_rune_of(u8 c) {  // isNumberRune, parse_number.go:36-60
     if (c >= '0' && c <= '9') return NF_PART | NF_DIGIT;
     switch (c) {
     case '.': return NF_PART | NF_FLOATONLY | NF_MUSTDIGIT;
@@ -49,6 +49,21 @@ SJ_HD u8 number_rune(u8 c) {  // isNumberRune, parse_number.go:36-60
     default: return 0;
     }
 }
+// the same as a table: one load instead of a compare chain under divergence (the reference uses a table too)
+struct NumberRuneLut {
+    u8 v[256];
+};
+constexpr NumberRuneLut make_number_rune_lut() {
+    NumberRuneLut t{};
+    for (u32 c = 0; c < 256; c++) t.v[c] = number_rune_of((u8)c);
+    return t;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ static const NumberRuneLut NUMBER_RUNE_LUT = make_number_rune_lut();
+#else
+static constexpr NumberRuneLut NUMBER_RUNE_LUT = make_number_rune_lut();
+#endif
+SJ_HD u8 number_rune(u8 c) { return NUMBER_RUNE_LUT.v[c]; }
 
 // ---- 64x64 -> 128 multiply ---------------------------------------------------------------------
 struct U128 {
