@@ -158,7 +158,11 @@ __device__ __forceinline__ void seg_publish(SegSlot *slot, const SegSum &v) {
     __hip_atomic_store(&slot->bc, v.a.bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&slot->w, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&slot->s, v.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&slot->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // every word above is an agent-scope atomic (performed at L2): it is enough to wait for their completion.  An
+    // agent-scope release would also write the whole L2 of this XCD back (measured: ~100 us when every block of a
+    // large kernel does it) and an acquire on the reader's side would invalidate it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&slot->flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // called by one whole wave of block `seg`: the ordered sum of segments 0 .. seg-1 (identity for seg 0)
 __device__ __forceinline__ SegSum seg_lookback(SegSlot *slots, int seg, int lane, S2State *st) {
@@ -168,9 +172,9 @@ __device__ __forceinline__ SegSum seg_lookback(SegSlot *slots, int seg, int lane
     static_assert(SCAN_SEGS <= 64, "one lane per predecessor");
     if (lane < seg) {
         u32 spins = 0;
-        while (__hip_atomic_load(&slots[lane].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+        while (__hip_atomic_load(&slots[lane].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(16);  // ~0.4 us between polls: the line is also the target of the publishers' stores
+            if (++spins > (1u << 20)) {  // bounded: a bug must not hang the device
                 atomicOr(&st->err, 8u);
                 break;
             }
