@@ -5,6 +5,7 @@
 // the oracle without a GPU.  The chunk loop below plays the role of the lanes; every
 // cross-chunk input is derived exactly the way the kernel derives it (memory peeks and a
 // running parity / count), never from the reference-style carried scalars.
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -83,6 +84,13 @@ extern "C" void sj_selftest_classify(const uint8_t *in64, uint64_t *out6) {
     u32 w[16];
     memcpy(w, in64, 64);
     const Classes c = classify(w);
+    // the butterfly transposition classify() uses against the one-plane-at-a-time dot4 form
+    u64 pl[8];
+    transpose_planes(w, pl);
+    const u64 ref[8] = {plane_of<0>(w), plane_of<1>(w), plane_of<2>(w), plane_of<3>(w),
+                        plane_of<4>(w), plane_of<5>(w), plane_of<6>(w), plane_of<7>(w)};
+    for (int k = 0; k < 8; k++)
+        if (pl[k] != ref[k]) abort();
     out6[0] = c.bs;
     out6[1] = c.quote;
     out6[2] = c.structs;

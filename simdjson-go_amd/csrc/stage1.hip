@@ -15,9 +15,9 @@
 //     about the in-string state at the start of its wave unit (lane-local, cheap next to the
 //     bit-plane transposition), so a tile can publish (parity, count|outside, count|inside)
 //     before it knows its own incoming state.  One decoupled look-back over 64-bit tile
-//     descriptors then resolves parity and offset together; the look-back window is BLOCK
-//     descriptors wide (every wave of the block reads 64 of them), so even with ~1000 tiles
-//     in flight it finishes in one or two memory round trips.
+//     descriptors then resolves parity and offset together; it is done by wave 0 of the block
+//     over a window of 256 descriptors (4 per lane), so even with one tile per CU in flight it
+//     finishes in one or two memory round trips.
 // The input is fetched from HBM exactly once.
 // Output: ABSOLUTE uint32 byte positions (the running sum of the reference's deltas).
 #include <hip/hip_runtime.h>
@@ -123,15 +123,6 @@ __device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base,
     const u64 x = (prev8 ^ BS8) << 8;
     if (x == 0) return peek_backslash_parity(base, lead, off - 1) ^ 1u;
     return ((((u32)__builtin_clzll(x | 0xffu) >> 3) & 1u)) ^ 1u;
-}
-// slow path for lanes > 0 (only taken when a wave holds a chunk made of 64 backslashes)
-__device__ __forceinline__ u32 peek_pseudo_pred(const u8 *base, u64 lead, u64 p) {
-    if (p <= lead) return 1;  // stage1_find_marks_amd64.go:56: starts as 1
-    const u8 b = base[p - 1];
-    if (b == ' ' || b == '\t' || b == '\n' || b == '\r') return 1;
-    if (b == '{' || b == '}' || b == '[' || b == ']' || b == ':' || b == ',') return 1;
-    if (b == '"') return peek_backslash_parity(base, lead, p - 1) ^ 1u;
-    return 0;
 }
 
 // ---- chunk load ------------------------------------------------------------------------
@@ -248,9 +239,9 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 
 // ---- phase A: everything that does not need the state in front of the tile ----------------
 // One pass = one 64-byte chunk per lane.  The two candidate structural masks of every chunk go to
-// the wave's private LDS window m[pass][outside|inside][lane]; registers only carry the chunk
-// itself, so the kernel runs at high occupancy.  While pass k is being computed the loads of pass
-// k+1 are in flight (issued as soon as the chunk registers are dead).
+// the wave's private LDS window m[pass][outside|inside][lane], the lane's inclusive structural counts
+// to pre[pass][lane].  While pass k is being computed the loads of pass k+1 are in flight (issued as
+// soon as the chunk registers are dead).
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
