@@ -71,6 +71,24 @@ def test_fixture_tapes_equal_oracle(ctx, name):
         check(ctx, data, nd=True, what=name + "/nd")
 
 
+@pytest.mark.parametrize("name", ["twitter", "twitterescaped", "canada", "parking-citations"])
+def test_fixture_mutations(ctx, name):
+    """single-byte corruptions of the real documents (positions spread over the file, replacement bytes that
+    matter to the grammar, the string scanner and the number parser): same verdict and tape as the oracle"""
+    import os
+    data = fixtures.load(name)
+    nd = name == "parking-citations"
+    import zlib
+    rnd = random.Random(zlib.crc32(name.encode()))
+    for _ in range(int(os.environ.get("SJ_MUTATIONS", "40"))):
+        b = bytearray(data)
+        at = rnd.randrange(len(b))
+        b[at] = rnd.choice(b'{}[]:,"\\ \n\t0179-+.eEtfnu\x00\x1f\x80')
+        if rnd.random() < 0.3:  # a second corruption nearby
+            b[min(len(b) - 1, at + rnd.randrange(1, 70))] = rnd.choice(b'{}[]:,"\\ u')
+        check(ctx, bytes(b), nd, "mutation@%d" % at)
+
+
 def test_reference_corpora(ctx):  # simdjson_amd64_test.go fail / pass / ND tables
     for key in ("fail_cases", "pass_cases"):
         for c in CORP[key]:
