@@ -627,7 +627,7 @@ static constexpr int S1_DEFAULT_VARIANT = 1;
 struct S1Variant {
     int block, ch, wpe;
 };
-static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {1024, 2, 4}};
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {1024, 2, 4}, {768, 2, 3}};
 static S1Variant s1_variant() {
     static int v = -1;
     if (v < 0) {
@@ -707,6 +707,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
             S1_LAUNCH2(B, C, W, false); \
     } while (0)
     if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
+    else if (v.block == 768) S1_LAUNCH(768, 2, 3);
     else S1_LAUNCH(512, 2, 4);
 #undef S1_LAUNCH2
 #undef S1_LAUNCH3
