@@ -380,6 +380,28 @@ def test_concurrent_contexts():
     assert not errors, errors
 
 
+@pytest.mark.parametrize("lead", [1, 17, 63])
+def test_parse_device_unaligned_pointer(ctx, lead):
+    """sjhip_parse_device takes any device pointer: the kernels work from the 64-byte aligned base and the string
+    masks, token kinds and Strings.B offsets are all relative to it"""
+    import sjhip
+    import torch
+    docs = [(workloads.c2_twitter_array(3), False), (fixtures.load("twitterescaped"), False),
+            (fixtures.load("parking-citations") * 5, True), (b'["a\\u00e9b","' + b"x" * 200 + b'",-1.5e3,{"k":[true,null]}]', False)]
+    for doc, nd in docs:
+        doc = doc.strip()  # parse_device takes the TrimSpace'd message
+        dev = torch.zeros(len(doc) + 512, dtype=torch.uint8, device="cuda:0")
+        dev[lead:lead + len(doc)].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        for copy in (True, False):
+            ref = O.parse(doc, ndjson=nd, copy_strings=copy)
+            assert ref.rc == 0 and ref.msg_off == 0 and ref.msg_len == len(doc)
+            tl, sl = ctx.parse_device(dev.data_ptr() + lead, len(doc), ndjson=nd, copy_strings=copy)
+            tape, strings = ctx.fetch(tl, sl)
+            assert np.array_equal(tape, ref.tape), (lead, nd, copy)
+            assert np.array_equal(strings, ref.strings), (lead, nd, copy)
+
+
 def test_full_size_properties(ctx):
     """BASELINE sizes: lengths are checked against the closed forms of SURVEY.md §8d and the tape
     of every copy must be copy 0's tape rebased (a checksum of the structure, not of the data)."""
