@@ -160,7 +160,9 @@ extern "C" int sj_selftest_parse_shard(const uint8_t *msg0, size_t len0, uint32_
 static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint64_t tape_base, uint64_t strings_base,
                           uint64_t msg_base, uint64_t **tape_out, size_t *tape_len, uint8_t **strings_out,
                           size_t *strings_len, size_t *msg_off, size_t *msg_len) {
-    const bool ndjson = flags & 1, copy = flags & 2;
+    const bool ndjson = flags & 1;
+    bool copy = flags & 2;      // every string copied through the emit masks (byte-parallel path)
+    bool force_copy = false;    // ... or, after a surrogate-walk overflow, through the per-string walks (parse_api.hip)
     size_t off, len;
     trim_space(msg0, len0, &off, &len);
     *msg_off = off;
@@ -197,10 +199,17 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     if (copy) {
         for (size_t c = 0; c < used_units * 64; c++)
         {
-            bool esc_flag;
-            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c], &esc_flag)) bad = 1;
+            bool esc_flag, overflow;
+            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c], &esc_flag, &overflow)) bad = 1;
             if (esc_flag != str_chunk_has_escapes(sv, c)) return 96;
+            if (overflow) force_copy = true;
         }
+        if (force_copy) {  // S2_ERR_SERIAL_STRINGS: nothing of the mask pass is a verdict
+            copy = false;
+            bad = 0;
+        }
+    }
+    if (copy) {
         for (size_t u = 0; u < used_units; u++) {
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
@@ -228,7 +237,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                 strbad[i] = 1;
             } else {
                 dlen[i] = dl;
-                needcopy[i] = sl != dl;
+                needcopy[i] = force_copy || sl != dl;
                 copied[i] = needcopy[i] ? dl : 0u;
             }
         }

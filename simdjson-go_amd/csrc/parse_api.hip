@@ -69,6 +69,14 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         S2State *hs = (S2State *)(ctx->h_scratch + 256);
         HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
+        if (hs->err & S2_ERR_SERIAL_STRINGS) {  // pathological surrogate run: measure again with the per-string walks
+            ctx->p_aux = nullptr;
+            HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, flags, ctx->d_s2.p,
+                                         ctx->stream, nullptr),
+                   "stage2 launch (measure, per-string)");
+            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
+        }
         if (tape_len) *tape_len = (size_t)hs->tape_len;
         if (strings_len) *strings_len = (size_t)hs->strings_len;
     }
@@ -91,6 +99,20 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
     HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+    if ((hs->err & S2_ERR_SERIAL_STRINGS) && ctx->p_aux) {
+        // a run of > SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string path
+        // gave up, nothing of this run is a verdict.  Stage 2 again with the per-string walks (linear in the run).
+        ctx->p_aux = nullptr;
+        HIPCHK(stage2_launch_measure(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags,
+                                     ctx->d_s2.p, ctx->stream, nullptr),
+               "stage2 launch (measure, per-string)");
+        HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags, ctx->d_s2.p,
+                                  (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
+                                  strings_base, msg_base, ctx->stream, nullptr),
+               "stage2 launch (emit, per-string)");
+        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+    }
     if (hs->err & 8u) {  // a bounded spin loop of a scan kernel ran out: internal error, never a verdict
         ctx_set_error(ctx, "stage-2 scan aborted (internal synchronisation timeout)");
         return SJHIP_ERR_HIP;

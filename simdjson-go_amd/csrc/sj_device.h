@@ -19,7 +19,8 @@ static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line
 
 // stage-2 totals and flags (zeroed before every launch)
 struct S2State {
-    uint32_t err;            // bit0: stage-2 failure, bit2: tape would exceed 2^32 words, bit3: internal scan timeout
+    uint32_t err;            // bit0: stage-2 failure, bit2: tape would exceed 2^32 words, bit3: internal scan timeout,
+                             // bit4: S2_ERR_SERIAL_STRINGS
     uint32_t bignum_count;   // numbers queued for the big-integer tie-break
     int32_t final_depth;
     uint32_t records;        // record-separating newline runs (ND)
@@ -32,6 +33,9 @@ struct S2State {
     uint32_t pad[3];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
+// a run of more than SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string
+// path gives up and the host repeats stage 2 with the per-string walks (no verdict is taken from the first run)
+static constexpr uint32_t S2_ERR_SERIAL_STRINGS = 16u;
 
 size_t stage2_workspace_bytes(size_t n_tokens);
 // d_kind: the token kinds stage 1 wrote next to the positions

@@ -60,7 +60,12 @@ struct UEscape {
     u32 n;     // bytes emitted at the positions of 'u' and the hex digits (0: consumed as the low half of a pair)
     u8 b[4];
     bool ok;
+    bool overflow;  // the run of high-surrogate escapes in front is longer than SURROGATE_WALK_CAP: not decided here
 };
+// Bound of the backward walk over adjacent high-surrogate escapes (each escape of such a run walks to the start of
+// the run: quadratic in the run length).  Real text stops after one or two steps; a document with a longer run is
+// handed to the per-string path (string_walk: linear), see S2_ERR_SERIAL_STRINGS.
+static constexpr u32 SURROGATE_WALK_CAP = 4096;
 
 SJ_HD u32 hex4_of(u32 four) {  // four bytes, first digit in the low byte
     const u32 d0 = (u32)hex_digit((u8)four), d1 = (u32)hex_digit((u8)(four >> 8)), d2 = (u32)hex_digit((u8)(four >> 16)),
@@ -82,6 +87,7 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
     UEscape r;
     r.n = 0;
     r.ok = true;
+    r.overflow = false;
     r.b[0] = r.b[1] = r.b[2] = r.b[3] = 0;
     const u64 pos = au - 1;
     // consumed as the low half of a pair?  count the unconsumed high-surrogate escapes directly in front
@@ -90,7 +96,10 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
     for (u64 p = pos; p >= m.lead + 6; p -= 6) {
         const u64 pp = p - 6;
         if (!(m.is_starter(pp) && m.in_string(pp + 1) && is_high_surrogate_escape(m, pp))) break;
-        highs++;
+        if (++highs > SURROGATE_WALK_CAP) {
+            r.overflow = true;
+            return r;
+        }
     }
     if (highs & 1u) return r;  // validated (as far as the reference validates it) by the high half
     u64 w0, w1;
@@ -155,14 +164,17 @@ SJ_HD bool str_chunk_has_escapes(const StrView &m, u64 c) {
     return c > 0 && ((m.esc(c - 1) & m.sm(c - 1)) >> 60) != 0;
 }
 
-// Pass 1, one chunk: the emit mask and the 'u' mask of chunk c; returns false on an invalid escape.
-SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bool *escapes_out = nullptr) {
+// Pass 1, one chunk: the emit mask and the 'u' mask of chunk c; returns false on an invalid escape.  *overflow_out
+// is set when a surrogate run exceeds SURROGATE_WALK_CAP (the masks are then not valid).
+SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bool *escapes_out = nullptr,
+                           bool *overflow_out = nullptr) {
     const u64 sm = m.sm(c);
     const u64 e = m.esc(c) & sm;  // escaped characters inside strings
     u64 em = sm & ~m.st[c];
     u64 um = 0;
     bool ok = true;
     bool escapes = e != 0;  // == str_chunk_has_escapes(m, c)
+    bool overflow = false;
     // escapes whose 'u' lies in the last four bytes of the previous chunk reach into this one
     if (c > 0) {
         u64 pe = (m.esc(c - 1) & m.sm(c - 1)) >> 60;
@@ -172,6 +184,7 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bo
             const u64 au = (c - 1) * 64 + 60 + k;
             if (m.at(au) != 'u') continue;
             const UEscape u = unicode_escape(m, au);  // errors are reported by the owner of the 'u'
+            overflow |= u.overflow;
             for (u32 j = 1; j <= 4; j++) {
                 const u64 a = au + j;
                 if ((a >> 6) == c) {
@@ -192,6 +205,7 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bo
         um |= 1ull << p;
         const UEscape u = unicode_escape(m, a);
         if (!u.ok) ok = false;
+        overflow |= u.overflow;
         for (u32 j = 0; j <= 4; j++) {
             const u64 aj = a + j;
             if ((aj >> 6) == c) {
@@ -203,6 +217,7 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bo
     *em_out = em;
     *um_out = um;
     if (escapes_out) *escapes_out = escapes;
+    if (overflow_out) *overflow_out = overflow;
     return ok;
 }
 

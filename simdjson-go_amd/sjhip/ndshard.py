@@ -6,7 +6,8 @@ simdjson_amd64.go:156-192); the merged ParsedJson is the concatenation of the sh
 Strings.B once every index stored in a shard's tape is rebased by where the shard begins in the
 merged Tape / Strings.B / Message.  These three offsets are exclusive prefix sums over the preceding
 shards: the only data exchanged is one (tape_len, strings_len) pair per rank (an all_gather of 16
-bytes, RCCL over xGMI on the GPUs, gloo in the CPU tests).
+bytes, RCCL over xGMI on the GPUs, gloo in the CPU tests) plus each rank's return code, so that an invalid
+shard fails the parse on every rank instead of leaving the others in a collective.
 
 The functions here are pure host logic (no device code) and are exercised on the CPU by
 tests/test_ndshard_gloo.py with the host replay standing in for the kernels.
@@ -44,14 +45,47 @@ def bases_from_sizes(sizes: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
     return out
 
 
+class ShardError(Exception):
+    """Raised on EVERY rank when any shard of a sharded ParseND fails.  `code` follows the C ABI (1 = stage 1,
+    2 = stage 2, ...); `ranks` lists the failing ranks.  Stage 1 takes precedence over stage 2 like in
+    parseMessage (parse_json_amd64.go:97-105,123-126)."""
+
+    def __init__(self, code, ranks):
+        from .api import ERR_STAGE1, ERR_STAGE2
+        msg = {1: ERR_STAGE1, 2: ERR_STAGE2}.get(code, f"sjhip error {code}")
+        super().__init__(f"{msg} (shard(s) {ranks})")
+        self.code = code
+        self.ranks = ranks
+
+
+def _agree(codes):
+    """The verdict all ranks reach from the gathered per-rank return codes (0 = ok)."""
+    bad = [r for r, c in enumerate(codes) if c != 0]
+    if not bad:
+        return
+    code = 1 if 1 in codes else codes[bad[0]]
+    raise ShardError(code, bad)
+
+
+def _code_of(exc):
+    c = getattr(exc, "code", None)
+    return c if isinstance(c, int) and c != 0 else -1
+
+
 def parse_shard(data: bytes, rank: int, world: int, trim: Callable, begin: Callable, finish: Callable,
-                all_gather_sizes: Callable, copy_strings: bool = True):
+                all_gather: Callable, copy_strings: bool = True):
     """Runs one rank's part of a sharded ParseND.
 
     trim(bytes) -> (off, len)                              bytes.TrimSpace
     begin(shard_bytes) -> (tape_len, strings_len)          stage 1 + measure (0, 0 for an empty shard)
-    all_gather_sizes((tape_len, strings_len)) -> list     one pair per rank, in rank order
+    all_gather(tuple of ints) -> list of tuples            one per rank, in rank order (called TWICE per parse,
+                                                           by every rank, whatever happens locally)
     finish(tape_base, strings_base, msg_base) -> (tape, strings)
+
+    A failure of `begin` or `finish` on one rank (ParseError: invalid shard, too big, HIP error) never leaves
+    the other ranks blocked in a collective: the local return code travels with the sizes (first exchange) and
+    alone (second exchange), and every rank raises the same ShardError after the exchange.
+
     Returns (tape, strings, tape_base, strings_base); concatenating the ranks' tapes / strings in rank
     order gives the merged ParsedJson, whose Message is TrimSpace(data)."""
     g_off, _ = trim(data)
@@ -60,13 +94,23 @@ def parse_shard(data: bytes, rank: int, world: int, trim: Callable, begin: Calla
     off, ln = trim(shard)
     empty = ln == 0
     window = shard[off:off + ln]
-    sizes = (0, 0) if empty else begin(window)
-    allsizes = all_gather_sizes(sizes)
-    tape_base, strings_base = bases_from_sizes(allsizes)[rank]
-    if empty:
-        return np.empty(0, np.uint64), np.empty(0, np.uint8), tape_base, strings_base
-    msg_base = start + off - g_off
-    tape, strings = finish(tape_base, strings_base, msg_base)
+    sizes, rc = (0, 0), 0
+    if not empty:
+        try:
+            sizes = begin(window)
+        except Exception as e:  # noqa: BLE001 -- the code is exchanged, the error re-raised on all ranks
+            rc = _code_of(e)
+    gathered = [tuple(g) for g in all_gather((int(sizes[0]), int(sizes[1]), int(rc)))]
+    _agree([g[2] if len(g) > 2 else 0 for g in gathered])
+    tape_base, strings_base = bases_from_sizes([g[:2] for g in gathered])[rank]
+    tape, strings, rc2 = np.empty(0, np.uint64), np.empty(0, np.uint8), 0
+    if not empty:
+        msg_base = start + off - g_off
+        try:
+            tape, strings = finish(tape_base, strings_base, msg_base)
+        except Exception as e:  # noqa: BLE001
+            rc2 = _code_of(e)
+    _agree([(tuple(g) + (0,))[0] for g in all_gather((int(rc2),))])
     return tape, strings, tape_base, strings_base
 
 

@@ -290,7 +290,7 @@ def test_large_random_ndjson(ctx):
             sizes.append((0, 0) if ln == 0 else begin(doc[a + off:a + off + ln]))
         tapes, strs = [], []
         for r in range(world):
-            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes, copy_strings)
+            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes if len(s) == 3 else [(0,)] * world, copy_strings)
             tapes.append(t)
             strs.append(s)
         assert np.array_equal(np.concatenate(tapes), ref.tape)
@@ -476,7 +476,7 @@ def test_sharded_parse_nd_equals_oracle(ctx, world, copy_strings):
         # pass 2: every rank parses its shard with the gathered sizes
         tapes, strs = [], []
         for r in range(world):
-            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes, copy_strings)
+            t, s, _, _ = ndshard.parse_shard(doc, r, world, trim, begin, finish, lambda s: sizes if len(s) == 3 else [(0,)] * world, copy_strings)
             tapes.append(t)
             strs.append(s)
         ref = O.parse(doc, ndjson=True, copy_strings=copy_strings)

@@ -164,3 +164,19 @@ def test_trim_space(L):
         L.sj_selftest_trim(s, len(s), C.byref(a), C.byref(b))
         OL.sjo_trim_space(s, len(s), C.byref(c), C.byref(d))
         assert (b.value == d.value) and (b.value == 0 or a.value == c.value), s
+
+
+def surrogate_run_docs():
+    """Runs of adjacent high-surrogate escapes: the byte-parallel string path pairs them by walking back to the start
+    of the run; beyond SURROGATE_WALK_CAP (4096) escapes it hands the document to the per-string walks."""
+    hi, lo = b"\\ud800", b"\\udc00"
+    for n in (1, 2, 3, 7, 64, 4095, 4096, 4097, 4098, 9001):
+        yield b'["' + hi * n + b'"]', f"highs{n}"                   # odd n: the last one is a lone high surrogate -> fail
+        yield b'["' + hi * n + lo + b'"]', f"highs{n}+low"
+        yield b'{"k":"x' + hi * n + b'","after":"\\u00e9' + hi * 2 + b'"}', f"highs{n}-then-more"
+    yield b'["' + (b"\\ud800" * 5000 + b"x") * 3 + b'"]', "three-long-runs"
+
+
+def test_long_surrogate_runs(L):
+    for doc, what in surrogate_run_docs():
+        check(L, doc, False, what)

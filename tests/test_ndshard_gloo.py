@@ -43,7 +43,9 @@ def _host_callbacks(lib, copy_strings):
         tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         rc = lib.sj_selftest_parse_shard(window, len(window), flags, tb, sb, mb, C.byref(tape), C.byref(tl), C.byref(strs),
                                          C.byref(sl), C.byref(mo), C.byref(ml))
-        assert rc == 0, rc
+        if rc != 0:
+            from sjhip.api import ParseError
+            raise ParseError(f"host replay rc {rc}", rc)
         t = np.ctypeslib.as_array(tape, shape=(tl.value,)).copy()
         s = np.ctypeslib.as_array(strs, shape=(max(sl.value, 1),))[: sl.value].copy()
         lib.sj_selftest_free(tape)
@@ -70,6 +72,15 @@ def _nd_docs():
     yield b'{"only":"one record"}'
 
 
+def _bad_docs():
+    """(document, expected code): one shard of two is invalid; the other rank must not hang in the collective."""
+    good = b'{"a":[1,2,{"b":"c"}]}\n' * 6
+    yield good + b'{"a":"unterminated\n' + good[:-1], 1       # stage 1 (rank 1: the cut falls behind the 3rd record)
+    yield b'{"x":"ctrl \x01 char"}\n' + good * 2, 1           # stage 1 on rank 0
+    yield good + b'{"a":[1,2}\n{"b":}\n' + good, 2            # stage 2
+    yield b'{"a":tru}\n' + good * 2 + b'"unterminated', 1     # stage 2 on rank 0 and stage 1 on rank 1: stage 1 wins
+
+
 def _worker(rank, world, port, copy_strings, q):
     import torch.distributed as dist
     from sjhip import ndshard
@@ -77,11 +88,23 @@ def _worker(rank, world, port, copy_strings, q):
     lib = _selftest()
     trim, begin, finish = _host_callbacks(lib, copy_strings)
     out = []
+
+    def gather(vals):
+        box = [None] * world
+        dist.all_gather_object(box, tuple(int(x) for x in vals))
+        return box
+
+    # an invalid shard on one rank: every rank raises the same ShardError, nobody stays behind in a collective
+    for doc, want in _bad_docs():
+        try:
+            ndshard.parse_shard(doc, rank, world, trim, begin, finish, gather, copy_strings)
+            got = 0
+        except ndshard.ShardError as e:
+            got = e.code
+        codes = [None] * world
+        dist.all_gather_object(codes, got)
+        assert codes == [want] * world, (doc[:40], codes, want)
     for doc in _nd_docs():
-        def gather(sizes):
-            box = [None] * world
-            dist.all_gather_object(box, tuple(int(x) for x in sizes))
-            return box
         tape, strings, tb, sb = ndshard.parse_shard(doc, rank, world, trim, begin, finish, gather, copy_strings)
         pieces = [None] * world
         dist.all_gather_object(pieces, (tape.tobytes(), strings.tobytes()))
