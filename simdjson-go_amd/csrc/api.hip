@@ -202,16 +202,22 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-routine KAT kernels: a single lane runs the very same device functions as stage1_kernel
+// per-routine KAT kernels: a single lane runs the lane-local device functions of sj_chunk.h that stage1_kernel is
+// made of (classify, prefix_xor, finalize).  Two routines exist in the kernel in another form than the reference's:
+//   * odd backslashes: stage1_kernel uses escaped_mask() with the carry taken from the neighbour chunk's trailing
+//     run; the KAT evaluates the reference form odd_backslash_ends() AND the kernel form on the device and the entry
+//     point fails if they disagree on any non-backslash byte or on the carry;
+//   * flatten: stage1_kernel writes absolute positions through flatten_tile (LDS staging, coalesced copy-out); the
+//     KAT entry point runs the real kernel on a 64-byte message whose structural mask is the given mask and turns
+//     the absolute positions into the reference's deltas on the host (the carried / position bookkeeping is transport).
 // ---------------------------------------------------------------------------------------------
 struct KatIO {
     uint8_t in[64];
     uint64_t a[8];    // scalar inputs
     uint64_t out[8];  // scalar outputs
-    uint32_t idx[80]; // flatten output
 };
 
-enum { KAT_ODD_BS, KAT_QUOTE, KAT_WS, KAT_FINALIZE, KAT_NEWLINE, KAT_FLATTEN };
+enum { KAT_ODD_BS, KAT_QUOTE, KAT_WS, KAT_FINALIZE, KAT_NEWLINE };
 
 __global__ void kat_kernel(KatIO *io, int op) {
     if (threadIdx.x != 0) return;
@@ -225,6 +231,13 @@ __global__ void kat_kernel(KatIO *io, int op) {
         u32 co;
         io->out[0] = odd_backslash_ends(c.bs, (u32)io->a[0], co);
         io->out[1] = co;
+        // the form stage1_kernel runs (stage1.hip phase_a): escaped characters, carry from the trailing run
+        const u64 escaped = escaped_mask(c.bs, (u32)io->a[0]);
+        io->out[2] = escaped & ~c.bs;                         // must equal out[0]
+        io->out[3] = c.quote & ~escaped;                      // the kernel's quote_bits
+        io->out[4] = c.quote & ~io->out[0];                   // the reference's quote_bits
+        const bool all_bs = c.bs == ~0ull;
+        io->out[5] = all_bs ? io->a[0] : ((u32)__builtin_clzll(~c.bs) & 1u);  // the kernel's carry into the next chunk
         break;
     }
     case KAT_QUOTE: {  // a0 = odd_ends, a1 = prev_inside_quote, a2 = error_mask (accumulated)
@@ -248,22 +261,6 @@ __global__ void kat_kernel(KatIO *io, int op) {
     case KAT_NEWLINE:
         io->out[0] = c.nl & ~io->a[0];
         break;
-    case KAT_FLATTEN: {  // a0 mask, a1 carried, a2 position (absolute of last emitted, ~0 = none)
-        u64 s = io->a[0];
-        u64 position = io->a[2];
-        const u64 start = position + io->a[1] + 1;  // absolute position of bit 0 of this mask
-        u32 n = 0;
-        while (s) {
-            const u64 abs = start + (u64)ctz64(s);
-            io->idx[n++] = (u32)(abs - position);  // the reference hands deltas to stage 2
-            position = abs;
-            s &= s - 1;
-        }
-        io->out[0] = n;
-        io->out[1] = (start + 63) - position;  // carried
-        io->out[2] = position;
-        break;
-    }
     }
 }
 
@@ -287,6 +284,10 @@ int sjhip_find_odd_backslash_sequences(sjhip_ctx *ctx, const uint8_t in[64], uin
     h.a[0] = *prev;
     int rc = kat_run(ctx, h, KAT_ODD_BS);
     if (rc) return rc;
+    if (h.out[2] != h.out[0] || h.out[3] != h.out[4] || h.out[5] != h.out[1]) {
+        ctx_set_error(ctx, "escaped_mask (kernel form) disagrees with odd_backslash_ends (reference form)");
+        return SJHIP_ERR_HIP;
+    }
     *odd_ends = h.out[0];
     *prev = h.out[1];
     return SJHIP_OK;
@@ -355,15 +356,29 @@ int sjhip_find_newline_delimiters(sjhip_ctx *ctx, const uint8_t in[64], uint64_t
 int sjhip_flatten_bits_incremental(sjhip_ctx *ctx, uint32_t *base, int *base_index, uint64_t mask, uint64_t *carried,
                                    uint64_t *position) {
     if (!ctx) return SJHIP_ERR_ARG;
-    KatIO h;
-    memset(&h, 0, sizeof h);
-    h.a[0] = mask;
-    h.a[1] = *carried;
-    h.a[2] = *position;
-    int rc = kat_run(ctx, h, KAT_FLATTEN);
+    // ':' at every set bit, blanks elsewhere: the structural mask of this 64-byte message is `mask` (the reference's
+    // own whitespace-padding test builds its inputs the same way, find_subroutines_amd64_test.go:381-421)
+    uint8_t msg[64];
+    for (int j = 0; j < 64; j++) msg[j] = ((mask >> j) & 1u) ? ':' : ' ';
+    uint32_t pos[64];
+    size_t n = 0;
+    int ok = 0;
+    int rc = sjhip_stage1(ctx, msg, 64, 0, pos, 64, &n, &ok);  // stage1_kernel -> flatten_tile
     if (rc) return rc;
-    for (uint64_t i = 0; i < h.out[0]; i++) base[(*base_index)++] = h.idx[i];
-    *carried = h.out[1];
-    *position = h.out[2];
+    if (n != (size_t)__builtin_popcountll(mask)) {
+        ctx_set_error(ctx, "flatten: %zu positions for a mask with %d bits", n, __builtin_popcountll(mask));
+        return SJHIP_ERR_HIP;
+    }
+    // flatten_bits_amd64.s:26-60: deltas relative to the last index, `carried` = distance from it to the end of
+    // the previous mask
+    uint64_t last = *position;
+    const uint64_t start = last + *carried + 1;  // absolute position of bit 0 of this mask
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t abs = start + pos[i];
+        base[(*base_index)++] = (uint32_t)(abs - last);
+        last = abs;
+    }
+    *carried = (start + 63) - last;
+    *position = last;
     return SJHIP_OK;
 }

@@ -102,6 +102,27 @@ def test_kat_flatten(ctx, L):
         assert list(base[: idx.value]) == r["expected"]
 
 
+def test_kat_odd_backslash_random_chunks(ctx, L):
+    """Chunks dense in backslashes and quotes, both carries: the entry point evaluates the reference form
+    (odd_backslash_ends) and the form the kernel runs (escaped_mask + trailing-run carry) on the device and fails
+    if they disagree; the result is compared with the oracle."""
+    OL = O.lib()
+    rng = np.random.default_rng(20260922)
+    alphabets = [b'\\\\"a', b'\\"', b'\\', b'\\a"  ']
+    for trial in range(400):
+        al = np.frombuffer(alphabets[trial % 4], dtype=np.uint8)
+        chunk = bytes(al[rng.integers(0, al.size, 64)])
+        if trial % 50 == 0:
+            chunk = b"\\" * 64
+        for carry in (0, 1):
+            prev, out = u64(carry), u64(0)
+            rc = L.sjhip_find_odd_backslash_sequences(ctx._h, chunk, C.byref(prev), C.byref(out))
+            assert rc == 0, (rc, L.sjhip_last_error(ctx._h), chunk)
+            rprev = u64(carry)
+            want = OL.sjo_find_odd_backslash_sequences(chunk, C.byref(rprev))
+            assert out.value == want and prev.value == rprev.value, (chunk, carry)
+
+
 # ---- whole stage 1 ----
 def test_demo_json_positions(ctx):
     ok, pos = ctx.stage1(bytes.fromhex(S1["demo_json_hex"]))
