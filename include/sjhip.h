@@ -97,6 +97,18 @@ int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjso
 int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,
                       size_t pos_cap, int iters, float *ms_per_launch);
 
+/* ---- profiling aids (not needed by a binding) -------------------------------------------------------------------
+ * sjhip_stage1_set_variant: kernel variant used by this process for stage 1 (A/B runs on hardware): 0 512-thread
+ *   blocks with barriers, 1 1024 with barriers, 2 768 with barriers, 3 1024 barrier-free, 4 512 barrier-free;
+ *   -1 = the SJHIP_S1_VARIANT environment variable or the default.  Returns the variant in effect.
+ * sjhip_stage1_trace: one stage-1 launch of a profiling build of the current variant that stamps s_memtime at the
+ *   phase boundaries of every (tile, wave): trace_out[(tile * waves + wave) * words + k], k = 0 phase A begins,
+ *   1 phase A done, 2 serial section done (only the wave that ran it), 3 state of the tile known, 4 flatten done,
+ *   5 HW_ID | XCC_ID << 32.  Plain (non-ND) stage 1 of a device-resident message. */
+int sjhip_stage1_set_variant(int variant);
+int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_pos, size_t pos_cap, uint64_t *trace_out,
+                       size_t trace_cap_words, unsigned *tiles, int *waves, int *words);
+
 /* ---- per-routine known-answer entry points (one 64-byte chunk, executed on the GPU) ----------
  * Same signatures as the Go wrappers in find_subroutines_amd64.go so that the reference's
  * per-routine tests (find_subroutines_amd64_test.go) can be replayed against the device code. */

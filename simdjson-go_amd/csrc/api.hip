@@ -201,6 +201,33 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
     return SJHIP_OK;
 }
 
+int sjhip_stage1_set_variant(int variant) { return stage1_set_variant(variant); }
+
+int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_pos, size_t pos_cap, uint64_t *trace_out,
+                       size_t trace_cap_words, unsigned *tiles, int *waves, int *words) {
+    if (!ctx || !trace_out || !tiles || !waves || !words) return SJHIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t lead = (size_t)(reinterpret_cast<uintptr_t>(d_msg) & 63);
+    const size_t nw = stage1_trace_words(len, lead, tiles, waves);
+    *words = 8;
+    if (nw > trace_cap_words) {
+        ctx_set_error(ctx, "trace needs %zu words", nw);
+        return SJHIP_ERR_ARG;
+    }
+    int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
+    if (rc) return rc;
+    rc = arena_reserve(ctx, ctx->d_kat, nw * sizeof(uint64_t));
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, nw * sizeof(uint64_t), ctx->stream), "trace memset");
+    HIPCHK(stage1_prepare(len, lead, ctx->d_ws.p, ctx->stream), "stage1 memset");
+    HIPCHK(stage1_launch_prepared(d_msg, len, 0, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, nullptr, nullptr,
+                                  (unsigned long long *)ctx->d_kat.p),
+           "stage1 launch (trace)");
+    HIPCHK(hipMemcpyAsync(trace_out, ctx->d_kat.p, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "D2H trace");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "trace sync");
+    return SJHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-routine KAT kernels: a single lane runs the lane-local device functions of sj_chunk.h that stage1_kernel is
 // made of (classify, prefix_xor, finalize).  Two routines exist in the kernel in another form than the reference's:

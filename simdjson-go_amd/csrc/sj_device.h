@@ -80,7 +80,11 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
 inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).bytes + 256; }
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
-                                  void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr);
+                                  void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
+                                  unsigned long long *d_trace = nullptr);
+// kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
+int stage1_set_variant(int v);
+size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr);
 

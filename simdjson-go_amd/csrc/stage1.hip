@@ -36,7 +36,16 @@ struct S1Aux {
     u64 *qm, *q, *st;  // null unless every string is copied (byte-parallel unescape)
     u8 *unit_h;
     u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
+    u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
 };
+// per-phase timeline of a tile for every wave (profiling builds of the kernels, sjhip_stage1_trace):
+//   0 phase A begins   1 phase A done (arrival)   2 serial section done (the wave that ran it; 0 otherwise)
+//   3 state of the tile known (past the second barrier / the result flag)   4 flatten done   5 HW_ID
+static constexpr int TRACE_WORDS = 8;
+template <bool TRACE>
+__device__ __forceinline__ void trace_put(u64 *trace, u32 tile, int waves, int wave, int lane, int k) {
+    if (TRACE && lane == 0) trace[((u64)tile * waves + wave) * TRACE_WORDS + k] = __builtin_readcyclecounter();
+}
 __constant__ KindLut c_s1_klut = make_kind_lut();
 
 // ---- tile descriptors ------------------------------------------------------------------
@@ -489,7 +498,7 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *
 // Persistent blocks draw tiles from a ticket counter: tiles are started in id order, so every
 // predecessor in the look-back chain is resident or finished (forward progress without any
 // dispatch-order assumption), and no block ever waits for the dispatcher.
-template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX>
+template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
@@ -535,8 +544,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
+    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
                                     aux);
+    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
@@ -557,9 +568,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const int us_n = us == 2 ? 0 : us + 1;
         u32 tk = 0;  // the ticket after t_nn: drawn now, it returns while phase A runs
         if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
-        if (has_next)
+        if (has_next) {
+            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
                                             s_pre[ms ^ 1][wave], s_unit[us_n], aux);
+            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
+        }
         // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
         // waits for the other waves (the predecessors published their aggregates about a phase ago)
         LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
@@ -598,14 +612,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                 s_res[3] = (u32)(BASE >> 32);
                 if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
             }
+            trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
         }
         __syncthreads();
+        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
         const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
+        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
         if (!has_next) break;
         P0 = P1;
         T00 = T10;
@@ -619,23 +636,208 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }
 
+// ---- the same tile pipeline without block barriers ------------------------------------------------------------
+// The barrier kernel above stalls the whole CU twice per tile while wave 0 runs the serial section (aggregate,
+// ticket, look-back).  Here the waves of a block only meet through LDS words:
+//   * a wave that has finished phase A of tile T(i+1) adds 1 to an arrival counter; the wave that finds WAVES-1
+//     there is the last one and runs the serial section S(i) itself: aggregate + AGG descriptor of T(i+1), ticket
+//     T(i+3), look-back of T(i), PREFIX descriptor, then the result record res(i) = {state, unit parities, output
+//     base, ticket} behind a sequence word (workgroup-scope release);
+//   * every wave then waits for res(i) (acquire poll), flattens its units of T(i) and goes on to phase A of T(i+2).
+// res(i) is asked for a whole phase A after the last wave of A(T(i+1)) started producing it, so in the steady state
+// nobody waits: the other 15 waves of the block and the CU's issue slots keep working while one wave is in the
+// look-back.  A wave can run at most one tile ahead of the slowest one (slot reuse: s_unit 3, masks 2, res 4).
+template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
+__global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
+                                                               u32 *__restrict__ out_pos, u64 pos_cap,
+                                                               Stage1State *__restrict__ st, u64 *__restrict__ desc,
+                                                               u32 num_tiles, S1Aux aux) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int UNITS = WAVES * CH;
+    static_assert(UNITS <= 32, "pre_mask is a u32");
+    __shared__ u32 s_ticket[3];
+    __shared__ u32 s_unit[3][UNITS];
+    __shared__ u32 s_arrive[3];   // waves that have finished phase A of the tile in unit slot k
+    __shared__ u32 s_agg[3][4];   // P, T0, T1, pre_mask of the tile in unit slot k (written by the serial section)
+    __shared__ u32 s_res[4][8];   // res(i) in slot i & 3: G, pre_mask, BASE lo, BASE hi, ticket T(i+3), sequence i+1
+    __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
+    __shared__ u32 s_pre[2][WAVES][CH * 64];
+    __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];
+    __shared__ u8 s_klut[AUX ? 256 : 4];
+
+    const int tid = threadIdx.x;
+    if (AUX && tid < 256) {  // '\n' is a token only in NDJSON
+        const u8 k = c_s1_klut.v[tid];
+        s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
+    }
+    if (tid < 3) s_arrive[tid] = 0;
+    if (tid < 4) s_res[tid][5] = 0;
+    const int lane = tid & 63;
+    const int wave = (int)uniform((u32)tid >> 6);
+    const u64 end = lead + len;
+    auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
+
+    // prologue (two block barriers, once per block): first ticket alone, the next two while phase A of the first
+    // tile runs
+    if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
+    __syncthreads();
+    u32 t_cur = uniform(s_ticket[0]);
+    if (t_cur >= num_tiles) return;
+    uint4 pf[4];
+    {
+        const u64 un = (u64)t_cur * UNITS + (u64)wave;
+        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+    }
+    if (tid == 0) {
+        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
+        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
+    }
+    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+                                    aux);
+    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
+    __syncthreads();
+    u32 t_nxt = uniform(s_ticket[1]), t_nn = uniform(s_ticket[2]);
+    if (t_nxt < num_tiles) {
+        const u64 un = (u64)t_nxt * UNITS + (u64)wave;
+        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+    }
+    if (wave == 0) {
+        u32 P0, T00, T01, pm0;
+        tile_aggregate<UNITS>(s_unit[0], lane, P0, T00, T01, pm0);
+        if (lane == 0) {
+            desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
+            s_agg[0][0] = P0;
+            s_agg[0][1] = T00;
+            s_agg[0][2] = T01;
+            s_agg[0][3] = pm0;
+        }
+    }  // wave 0's arrival below (release) makes s_agg[0] visible to whoever runs S(0)
+
+    int ms = 0, us = 0;
+    u32 iter = 0;
+    bool err = false;
+    for (;; iter++) {
+        const bool has_next = t_nxt < num_tiles;
+        const int us_n = us == 2 ? 0 : us + 1;
+        if (has_next) {
+            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
+                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux);
+            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
+        }
+        // ---- arrival; the last wave runs the serial section
+        u32 arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[us_n], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = uniform(arrived);
+        u32 *res = s_res[iter & 3u];
+        if (arrived == (u32)WAVES - 1u) {
+            if (lane == 0) s_arrive[us_n] = 0;  // next used three tiles from now, behind two result hand-offs
+            u32 tk = 0xffffffffu;
+            if (has_next && lane == 0) tk = atomicAdd(&st->tile_counter, 1u);  // T(i+3): returns during the look-back
+            LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
+            u64 win[4] = {0, 0, 0, 0};
+            if (t_cur != 0) lookback_load(desc, lb.j, lane, win);
+            if (has_next) {
+                u32 P1, T10, T11, pm1;
+                tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
+                if (lane == 0) {
+                    desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+                    s_agg[us_n][0] = P1;
+                    s_agg[us_n][1] = T10;
+                    s_agg[us_n][2] = T11;
+                    s_agg[us_n][3] = pm1;
+                }
+            }
+            const u32 P0 = uniform(s_agg[us][0]), T00 = uniform(s_agg[us][1]), T01 = uniform(s_agg[us][2]),
+                      pm0 = uniform(s_agg[us][3]);
+            u32 G = 0;
+            u64 BASE = 0;
+            if (t_cur != 0) {
+                u32 spins = 0;
+                for (;;) {
+                    const int r = lookback_eval(win, lb, lane, G, BASE);
+                    if (r == 1) break;
+                    if (r == 0) __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                        break;
+                    }
+                    lookback_load(desc, lb.j, lane, win);
+                }
+                if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
+            }
+            if (lane == 0) {
+                res[0] = G;
+                res[1] = pm0;
+                res[2] = (u32)BASE;
+                res[3] = (u32)(BASE >> 32);
+                res[4] = tk;
+                if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
+                __hip_atomic_store(&res[5], iter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
+        }
+        // ---- the state in front of the current tile
+        {
+            u32 spins = 0;
+            while (__hip_atomic_load(&res[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != iter + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) {
+                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    break;
+                }
+            }
+        }
+        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
+        const u32 G = uniform(res[0]), pm = uniform(res[1]);
+        const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
+        const u32 t_3 = uniform(res[4]);
+        u64 tile_end = 0;
+        err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
+                                       tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
+        if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
+        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
+        if (TRACE && lane == 0)
+            aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
+                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        if (!has_next) break;
+        t_cur = t_nxt;
+        t_nxt = t_nn;
+        t_nn = t_3;
+        ms ^= 1;
+        us = us_n;
+    }
+    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+}
+
 // ---- launcher --------------------------------------------------------------------------
-// Tile shape (BLOCK lanes x CH passes) and register budget (WPE = waves per SIMD the allocation must
-// allow).  SJHIP_S1_VARIANT selects alternatives for A/B runs on hardware.
+// Tile shape (BLOCK lanes x CH passes), register budget (WPE = waves per SIMD the allocation must allow) and
+// synchronisation scheme (nb: the barrier-free kernel).  SJHIP_S1_VARIANT selects alternatives for A/B runs on
+// hardware; the variant can also be set per call (stage1_set_variant, used by the trace entry point).
 static constexpr int S1_DEFAULT_VARIANT = 1;
 
 struct S1Variant {
     int block, ch, wpe;
+    bool nb;
 };
-static const S1Variant S1_VARIANTS[] = {{512, 2, 4}, {1024, 2, 4}, {768, 2, 3}};
-static S1Variant s1_variant() {
-    static int v = -1;
-    if (v < 0) {
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4, false}, {1024, 2, 4, false}, {768, 2, 3, false},
+                                        {1024, 2, 4, true}, {512, 2, 4, true}};
+static constexpr int S1_NVARIANTS = (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0]);
+static int g_s1_variant = -1;
+int stage1_set_variant(int v) {  // -1: back to SJHIP_S1_VARIANT / the default; returns the variant in effect
+    if (v >= 0 && v < S1_NVARIANTS) {
+        g_s1_variant = v;
+    } else {
         const char *e = getenv("SJHIP_S1_VARIANT");
-        v = e ? atoi(e) : S1_DEFAULT_VARIANT;
-        if (v < 0 || v >= (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0])) v = S1_DEFAULT_VARIANT;
+        g_s1_variant = e ? atoi(e) : S1_DEFAULT_VARIANT;
+        if (g_s1_variant < 0 || g_s1_variant >= S1_NVARIANTS) g_s1_variant = S1_DEFAULT_VARIANT;
     }
-    return S1_VARIANTS[v];
+    return g_s1_variant;
+}
+static S1Variant s1_variant() {
+    if (g_s1_variant < 0) stage1_set_variant(-1);
+    return S1_VARIANTS[g_s1_variant];
 }
 
 // persistent grid: as many blocks as fit on the device at once (more would only queue)
@@ -669,9 +871,19 @@ hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream)
     return hipMemsetAsync(ws, 0, sizeof(Stage1State) + (size_t)tiles * sizeof(u64), stream);
 }
 
+// words of trace a launch of the current variant writes (sjhip_stage1_trace): tiles x waves x TRACE_WORDS
+size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out) {
+    const S1Variant v = s1_variant();
+    const u32 tiles = stage1_tiles(len, lead);
+    if (tiles_out) *tiles_out = tiles;
+    if (waves_out) *waves_out = v.block / 64;
+    return (size_t)tiles * (size_t)(v.block / 64) * TRACE_WORDS;
+}
+
 // d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
+// d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                                  hipStream_t stream, void *aux_buf, u8 *d_kind) {
+                                  hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -681,7 +893,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind};
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace)};
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = a.qm;
@@ -689,29 +901,33 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.st = a.st;
         aux.unit_h = a.unit_h;
     }
-#define S1_LAUNCH3(B, C, W, ND, AX)                                                                                  \
-    hipLaunchKernelGGL((stage1_kernel<B, C, W, ND, AX>), dim3(grid_for(stage1_kernel<B, C, W, ND, AX>, B, tiles)), dim3(B), \
-                       0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, st, desc, tiles, aux)
-#define S1_LAUNCH2(B, C, W, ND)           \
-    do {                                  \
-        if (aux_buf || d_kind)            \
-            S1_LAUNCH3(B, C, W, ND, true);  \
-        else                              \
-            S1_LAUNCH3(B, C, W, ND, false); \
+#define S1_LAUNCHK(K, B)                                                                                            \
+    hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
+                       st, desc, tiles, aux)
+#define S1_LAUNCH(KERNEL, B, C, W)                                                    \
+    do {                                                                              \
+        const bool ax = aux_buf || d_kind;                                            \
+        if (d_trace) {                                                                \
+            if (nd || ax) return hipErrorInvalidValue;                                \
+            S1_LAUNCHK((KERNEL<B, C, W, false, false, true>), B);                     \
+        } else if (nd) {                                                              \
+            if (ax) S1_LAUNCHK((KERNEL<B, C, W, true, true>), B);                     \
+            else S1_LAUNCHK((KERNEL<B, C, W, true, false>), B);                       \
+        } else {                                                                      \
+            if (ax) S1_LAUNCHK((KERNEL<B, C, W, false, true>), B);                    \
+            else S1_LAUNCHK((KERNEL<B, C, W, false, false>), B);                      \
+        }                                                                             \
     } while (0)
-#define S1_LAUNCH(B, C, W)            \
-    do {                              \
-        if (nd)                       \
-            S1_LAUNCH2(B, C, W, true);  \
-        else                          \
-            S1_LAUNCH2(B, C, W, false); \
-    } while (0)
-    if (v.block == 1024) S1_LAUNCH(1024, 2, 4);
-    else if (v.block == 768) S1_LAUNCH(768, 2, 3);
-    else S1_LAUNCH(512, 2, 4);
-#undef S1_LAUNCH2
-#undef S1_LAUNCH3
+    if (v.nb) {
+        if (v.block == 1024) S1_LAUNCH(stage1_kernel_nb, 1024, 2, 4);
+        else S1_LAUNCH(stage1_kernel_nb, 512, 2, 4);
+    } else {
+        if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
+        else if (v.block == 768) S1_LAUNCH(stage1_kernel, 768, 2, 3);
+        else S1_LAUNCH(stage1_kernel, 512, 2, 4);
+    }
 #undef S1_LAUNCH
+#undef S1_LAUNCHK
     return hipGetLastError();
 }
 
@@ -719,7 +935,7 @@ hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, 
                          hipStream_t stream, void *aux_buf, u8 *d_kind) {
     hipError_t e = stage1_prepare(len, reinterpret_cast<uintptr_t>(d_msg) & 63, ws, stream);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr);
 }
 
 }  // namespace sj

@@ -32,6 +32,9 @@ SYMBOLS = {
                                       intp]),
     "sjhip_stage1_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_float)]),
+    "sjhip_stage1_set_variant": (C.c_int, [C.c_int]),
+    "sjhip_stage1_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_uint), intp, intp]),
     "sjhip_find_odd_backslash_sequences": (C.c_int, [C.c_void_p, C.c_char_p, u64p, u64p]),
     "sjhip_find_quote_mask_and_bits": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "sjhip_find_whitespace_and_structurals": (C.c_int, [C.c_void_p, C.c_char_p, u64p, u64p]),
