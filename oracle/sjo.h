@@ -97,6 +97,21 @@ int sjo_parse(const uint8_t *msg, size_t len, uint32_t flags, uint64_t **tape, s
               uint8_t **strings, size_t *strings_len, size_t *msg_off, size_t *msg_len);
 void sjo_free(void *p);
 
+/* ---- sjo_fast.c: the same routines with the reference's AVX2 / PCLMULQDQ instruction shapes, for the CPU baseline
+ * of bench.py (shapes B1 / B2 / B3).  Bit-identical to the scalar functions above. ---- */
+typedef struct sjo_fast sjo_fast;
+int sjo_avx2_available(void);
+int sjo_find_structural_indices_avx2(const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t pos_cap,
+                                     size_t *n_out);
+sjo_fast *sjo_fast_create(void);
+void sjo_fast_destroy(sjo_fast *w);
+int sjo_fast_parse(sjo_fast *w, const uint8_t *msg, size_t len, uint32_t flags, int threads, const uint64_t **tape,
+                   size_t *tape_len, const uint8_t **strings, size_t *strings_len);
+double sjo_bench_stage1(const uint8_t *msg, size_t len, int ndjson, int iters, int avx2, size_t *n_out);
+double sjo_bench_parse(const uint8_t *msg, size_t len, uint32_t flags, int threads, int iters, int *rc_out,
+                       size_t *tape_len_out);
+double sjo_bench_nd_blocks(const uint8_t *msg, size_t len, int threads, size_t block_bytes, int iters, int *failed_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
  * zeroed buffer (stage2_build_tape_amd64.go:75-86).
  */
 #include "sjo.h"
+#include "sjo_internal.h"
 
 #include <string.h>
 
@@ -59,9 +60,9 @@ static uint32_t hex4(const uint8_t *src, size_t avail, size_t p) {
 
 /* Common walk.  If dst != NULL the unescaped bytes are written (the reference copies whole
  * 32-byte YMM words and patches; the visible result is the same byte sequence). */
-static int walk(const uint8_t *src, size_t avail, uint8_t *dst, uint64_t *str_length, uint64_t *dst_length) {
-    size_t pos = 0; /* r13 - rdi */
-    size_t out = 0; /* r14 (validate) / rsi - dst (parse) */
+int sjo_string_walk_from(const uint8_t *src, size_t avail, uint8_t *dst, size_t pos, size_t out, uint64_t *str_length,
+                         uint64_t *dst_length) {
+    /* pos: r13 - rdi; out: r14 (validate) / rsi - dst (parse) */
     for (;;) {
         if (pos > avail + 64) return 0; /* oracle guard: the reference would run off the buffer */
         uint32_t bs_bits = win_mask(src, avail, pos, '\\');
@@ -151,9 +152,9 @@ static int walk(const uint8_t *src, size_t avail, uint8_t *dst, uint64_t *str_le
 }
 
 int sjo_parse_string_validate_only(const uint8_t *src, size_t avail, uint64_t *str_length, uint64_t *dst_length) {
-    return walk(src, avail, NULL, str_length, dst_length);
+    return sjo_string_walk_from(src, avail, NULL, 0, 0, str_length, dst_length);
 }
 
 int sjo_parse_string(const uint8_t *src, size_t avail, uint8_t *dst, uint64_t *dst_length) {
-    return walk(src, avail, dst, NULL, dst_length);
+    return sjo_string_walk_from(src, avail, dst, 0, 0, NULL, dst_length);
 }

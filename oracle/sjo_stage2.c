@@ -4,6 +4,7 @@
  * (parse_json_amd64.go:28-127, simdjson_amd64.go:66-94).
  */
 #include "sjo.h"
+#include "sjo_internal.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -140,21 +141,7 @@ int sjo_is_valid_null_atom(const uint8_t *buf, size_t len) {
     return 0;
 }
 
-/* ---------------- growable outputs ---------------- */
-typedef struct {
-    const uint8_t *msg;
-    size_t len;
-    int copy_strings;
-    uint64_t *tape;
-    size_t tape_len, tape_cap;
-    uint8_t *strs;
-    size_t strs_len, strs_cap;
-    uint64_t *scope; /* containingScopeOffset */
-    size_t scope_len, scope_cap;
-    const uint32_t *pos;
-    size_t npos, ipos;
-} pj_t;
-
+/* ---------------- growable outputs: pj_t lives in sjo_internal.h ---------------- */
 static void tape_push(pj_t *pj, uint64_t w) {
     if (pj->tape_len == pj->tape_cap) {
         pj->tape_cap = pj->tape_cap ? pj->tape_cap * 2 : 1024;
@@ -176,7 +163,7 @@ static int parse_string(pj_t *pj, uint64_t idx) {
     const uint8_t *src = pj->msg + idx + 1;
     size_t avail = pj->len - (size_t)idx - 1;
     uint64_t src_len = 0, size = 0;
-    if (!sjo_parse_string_validate_only(src, avail, &src_len, &size)) return 0;
+    if (!(pj->validate_string ? pj->validate_string : sjo_parse_string_validate_only)(src, avail, &src_len, &size)) return 0;
     int need_copy = pj->copy_strings || src_len != size; /* parse_string_amd64.go:40 */
     if (!need_copy) {
         write_tape(pj, idx + 1, '"');
@@ -187,7 +174,7 @@ static int parse_string(pj_t *pj, uint64_t idx) {
             pj->strs = (uint8_t *)realloc(pj->strs, pj->strs_cap);
         }
         uint64_t written = 0;
-        sjo_parse_string(src, avail, pj->strs + pj->strs_len, &written);
+        (pj->copy_string ? pj->copy_string : sjo_parse_string)(src, avail, pj->strs + pj->strs_len, &written);
         write_tape(pj, SJO_STRINGBUFBIT + pj->strs_len, '"');
         pj->strs_len += (size_t)written;
         size = written;
@@ -208,14 +195,27 @@ static int add_number(pj_t *pj, uint64_t idx) { /* stage2_build_tape_amd64.go:11
 enum { RET_START = 1, RET_OBJECT = 2, RET_ARRAY = 3 }; /* :27-32 */
 
 /* updateChar (:34-46): the delta stream is pre-summed into absolute positions */
-#define UPDATE_CHAR()                                   \
-    do {                                                \
-        if (pj->ipos >= pj->npos) goto succeed;         \
-        idx = pj->pos[pj->ipos++];                      \
+#define UPDATE_CHAR()                                                   \
+    do {                                                                \
+        if (pj->ipos >= pj->npos && !more_indexes(pj)) goto succeed;    \
+        idx = pj->pos[pj->ipos++];                                      \
     } while (0)
 
+/* Two-thread shape (parse_json_amd64.go:75-95): stage 1 keeps appending to pos[] on another thread and publishes
+ * its count; the consumer refreshes its view when it runs dry (the role of `<-pj.indexChans`, :48-61). */
+static int more_indexes(pj_t *pj) {
+    if (!pj->live_npos) return 0;
+    for (;;) {
+        const int done = __atomic_load_n(pj->live_done, __ATOMIC_ACQUIRE);
+        pj->npos = __atomic_load_n(pj->live_npos, __ATOMIC_ACQUIRE);
+        if (pj->ipos < pj->npos) return 1;
+        if (done) return 0;
+        __builtin_ia32_pause();
+    }
+}
+
 /* unifiedMachine: stage2_build_tape_amd64.go:160-446 */
-static int unified_machine(pj_t *pj) {
+int sjo_unified_machine(pj_t *pj) {
     const uint8_t *buf = pj->msg;
     uint64_t idx = 0;
     uint64_t offset;
@@ -417,7 +417,7 @@ int sjo_parse(const uint8_t *msg, size_t len, uint32_t flags, uint64_t **tape, s
     pj.npos = npos;
     pj.strs_cap = 128;
     pj.strs = (uint8_t *)malloc(pj.strs_cap);
-    int ok2 = unified_machine(&pj);
+    int ok2 = sjo_unified_machine(&pj);
     free(pos);
     free(pj.scope);
     if (!ok2) {

@@ -623,6 +623,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
+        if (TRACE && lane == 0)
+            aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
+                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
         if (!has_next) break;
         P0 = P1;
         T00 = T10;
@@ -637,16 +640,21 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 }
 
 // ---- the same tile pipeline without block barriers ------------------------------------------------------------
-// The barrier kernel above stalls the whole CU twice per tile while wave 0 runs the serial section (aggregate,
-// ticket, look-back).  Here the waves of a block only meet through LDS words:
-//   * a wave that has finished phase A of tile T(i+1) adds 1 to an arrival counter; the wave that finds WAVES-1
-//     there is the last one and runs the serial section S(i) itself: aggregate + AGG descriptor of T(i+1), ticket
-//     T(i+3), look-back of T(i), PREFIX descriptor, then the result record res(i) = {state, unit parities, output
-//     base, ticket} behind a sequence word (workgroup-scope release);
-//   * every wave then waits for res(i) (acquire poll), flattens its units of T(i) and goes on to phase A of T(i+2).
-// res(i) is asked for a whole phase A after the last wave of A(T(i+1)) started producing it, so in the steady state
-// nobody waits: the other 15 waves of the block and the CU's issue slots keep working while one wave is in the
-// look-back.  A wave can run at most one tile ahead of the slowest one (slot reuse: s_unit 3, masks 2, res 4).
+// The barrier kernel above stalls the whole CU twice per tile: at the first barrier the waves that finished phase A
+// early wait for the slowest one (the four waves of a SIMD finish one after the other), then everybody waits while
+// wave 0 runs the serial section, whose look-back costs one cross-CU hand-off (~3 us behind the CU's own streaming
+// loads).  The s_memtime timelines (profiles/) show ~18 of the ~36 k cycles of a tile round spent that way.
+// Here the waves of a block only meet through LDS words and nobody waits for a look-back that somebody else could
+// be running:
+//   * a wave that has finished phase A of tile T(j) adds 1 to an arrival counter; the wave that finds WAVES-1 there
+//     aggregates the tile, publishes its AGG descriptor and marks the tile ready -- a few hundred cycles;
+//   * the serial duty S(j) -- ticket T(j+3), look-back of T(j), PREFIX descriptor, result record res(j) = {state,
+//     unit parities, output base, ticket} -- is CLAIMED (LDS compare-and-swap) by whichever wave gets to it first:
+//     a wave that has just flattened T(j-1) (it is ahead of the others: the duty slows it down, so the role
+//     rotates), or, at the latest, the first wave that needs res(j) and finds it neither done nor claimed;
+//   * a wave needs res(j) only after it has flattened T(j-1) AND run phase A of T(j+1), a whole round after the
+//     tile became ready: in the steady state the hand-off latency is off every wave's critical path.
+// Slot reuse (a wave is at most one tile ahead of the slowest): s_unit / s_agg / s_arrive / s_ready 3, masks 2, res 4.
 template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
@@ -658,8 +666,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     __shared__ u32 s_ticket[3];
     __shared__ u32 s_unit[3][UNITS];
     __shared__ u32 s_arrive[3];   // waves that have finished phase A of the tile in unit slot k
-    __shared__ u32 s_agg[3][4];   // P, T0, T1, pre_mask of the tile in unit slot k (written by the serial section)
-    __shared__ u32 s_res[4][8];   // res(i) in slot i & 3: G, pre_mask, BASE lo, BASE hi, ticket T(i+3), sequence i+1
+    __shared__ u32 s_ready[3];    // j + 1 once tile T(j) (unit slot j % 3) is aggregated and its AGG published
+    __shared__ u32 s_agg[3][4];   // P, T0, T1, pre_mask of that tile
+    __shared__ u32 s_claim[4];    // j + 1 once the serial duty S(j) has been taken (slot j & 3)
+    __shared__ u32 s_res[4][8];   // res(j) in slot j & 3: G, pre_mask, BASE lo, BASE hi, ticket T(j+3), sequence j + 1
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[2][WAVES][CH * 64];
     __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];
@@ -670,8 +680,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u8 k = c_s1_klut.v[tid];
         s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
     }
-    if (tid < 3) s_arrive[tid] = 0;
-    if (tid < 4) s_res[tid][5] = 0;
+    if (tid < 3) {
+        s_arrive[tid] = 0;
+        s_ready[tid] = 0;
+    }
+    if (tid < 4) {
+        s_res[tid][5] = 0;
+        s_claim[tid] = (u32)tid - 3u;  // the value the claim of S(tid) expects: (j + 1) - 4
+    }
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
@@ -711,8 +727,59 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             s_agg[0][1] = T00;
             s_agg[0][2] = T01;
             s_agg[0][3] = pm0;
+            __hip_atomic_store(&s_ready[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    }  // wave 0's arrival below (release) makes s_agg[0] visible to whoever runs S(0)
+    }
+
+    // The serial duty S(j) for tile tj = T(j) in unit slot uj; tj1 = T(j+1) (a ticket T(j+3) is drawn only if it is a
+    // tile).  Returns false without doing anything if the tile is not ready yet or another wave has the duty.
+    auto serial_duty = [&](u32 j, u32 tj, u32 tj1, int uj) -> bool {
+        if (__hip_atomic_load(&s_ready[uj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1u) return false;
+        u32 won = 0;
+        if (lane == 0) {
+            u32 expect = j - 3u;
+            won = __hip_atomic_compare_exchange_strong(&s_claim[j & 3u], &expect, j + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP)
+                      ? 1u
+                      : 0u;
+        }
+        if (!uniform(won)) return false;
+        u32 *res = s_res[j & 3u];
+        u32 tk = 0xffffffffu;
+        if (tj1 < num_tiles && lane == 0) tk = atomicAdd(&st->tile_counter, 1u);  // returns during the look-back
+        const u32 P0 = uniform(s_agg[uj][0]), T00 = uniform(s_agg[uj][1]), T01 = uniform(s_agg[uj][2]),
+                  pm0 = uniform(s_agg[uj][3]);
+        u32 G = 0;
+        u64 BASE = 0;
+        if (tj != 0) {
+            LookBack lb = {(long long)tj - 1, 0, 0, 0};
+            u64 win[4];
+            lookback_load(desc, lb.j, lane, win);
+            u32 spins = 0;
+            for (;;) {
+                const int r = lookback_eval(win, lb, lane, G, BASE);
+                if (r == 1) break;
+                if (r == 0) __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    break;
+                }
+                lookback_load(desc, lb.j, lane, win);
+            }
+            if (lane == 0) desc_store(&desc[tj], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
+        }
+        if (lane == 0) {
+            res[0] = G;
+            res[1] = pm0;
+            res[2] = (u32)BASE;
+            res[3] = (u32)(BASE >> 32);
+            res[4] = tk;
+            if (tj == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
+            __hip_atomic_store(&res[5], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        trace_put<TRACE>(aux.trace, tj, WAVES, wave, lane, 2);
+        return true;
+    };
 
     int ms = 0, us = 0;
     u32 iter = 0;
@@ -725,63 +792,29 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
                                             s_pre[ms ^ 1][wave], s_unit[us_n], aux);
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
-        }
-        // ---- arrival; the last wave runs the serial section
-        u32 arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[us_n], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        arrived = uniform(arrived);
-        u32 *res = s_res[iter & 3u];
-        if (arrived == (u32)WAVES - 1u) {
-            if (lane == 0) s_arrive[us_n] = 0;  // next used three tiles from now, behind two result hand-offs
-            u32 tk = 0xffffffffu;
-            if (has_next && lane == 0) tk = atomicAdd(&st->tile_counter, 1u);  // T(i+3): returns during the look-back
-            LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
-            u64 win[4] = {0, 0, 0, 0};
-            if (t_cur != 0) lookback_load(desc, lb.j, lane, win);
-            if (has_next) {
+            // ---- arrival; the last wave aggregates the tile and publishes its AGG descriptor
+            u32 arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[us_n], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (uniform(arrived) == (u32)WAVES - 1u) {
                 u32 P1, T10, T11, pm1;
                 tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
                 if (lane == 0) {
                     desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+                    s_arrive[us_n] = 0;  // next used three tiles from now, behind two result hand-offs
                     s_agg[us_n][0] = P1;
                     s_agg[us_n][1] = T10;
                     s_agg[us_n][2] = T11;
                     s_agg[us_n][3] = pm1;
+                    __hip_atomic_store(&s_ready[us_n], iter + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            const u32 P0 = uniform(s_agg[us][0]), T00 = uniform(s_agg[us][1]), T01 = uniform(s_agg[us][2]),
-                      pm0 = uniform(s_agg[us][3]);
-            u32 G = 0;
-            u64 BASE = 0;
-            if (t_cur != 0) {
-                u32 spins = 0;
-                for (;;) {
-                    const int r = lookback_eval(win, lb, lane, G, BASE);
-                    if (r == 1) break;
-                    if (r == 0) __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
-                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
-                        break;
-                    }
-                    lookback_load(desc, lb.j, lane, win);
-                }
-                if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
-            }
-            if (lane == 0) {
-                res[0] = G;
-                res[1] = pm0;
-                res[2] = (u32)BASE;
-                res[3] = (u32)(BASE >> 32);
-                res[4] = tk;
-                if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
-                __hip_atomic_store(&res[5], iter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
         }
-        // ---- the state in front of the current tile
+        // ---- the state in front of the current tile: done by now in the steady state; otherwise take the duty
+        u32 *res = s_res[iter & 3u];
         {
             u32 spins = 0;
             while (__hip_atomic_load(&res[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != iter + 1u) {
+                if (serial_duty(iter, t_cur, t_nxt, us)) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 24)) {
                     if (lane == 0) atomicOr(&st->error, 0x80000000u);
@@ -802,6 +835,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
                 (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
         if (!has_next) break;
+        // ahead of the others?  Then the look-back of the next tile is ours if it is ready and nobody has it yet.
+        (void)serial_duty(iter + 1u, t_nxt, t_nn, us_n);
         t_cur = t_nxt;
         t_nxt = t_nn;
         t_nn = t_3;
@@ -822,7 +857,7 @@ struct S1Variant {
     bool nb;
 };
 static const S1Variant S1_VARIANTS[] = {{512, 2, 4, false}, {1024, 2, 4, false}, {768, 2, 3, false},
-                                        {1024, 2, 4, true}, {512, 2, 4, true}};
+                                        {1024, 2, 4, true}, {1024, 1, 4, true}};
 static constexpr int S1_NVARIANTS = (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0]);
 static int g_s1_variant = -1;
 int stage1_set_variant(int v) {  // -1: back to SJHIP_S1_VARIANT / the default; returns the variant in effect
@@ -919,8 +954,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         }                                                                             \
     } while (0)
     if (v.nb) {
-        if (v.block == 1024) S1_LAUNCH(stage1_kernel_nb, 1024, 2, 4);
-        else S1_LAUNCH(stage1_kernel_nb, 512, 2, 4);
+        if (v.ch == 2) S1_LAUNCH(stage1_kernel_nb, 1024, 2, 4);
+        else S1_LAUNCH(stage1_kernel_nb, 1024, 1, 4);
     } else {
         if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
         else if (v.block == 768) S1_LAUNCH(stage1_kernel, 768, 2, 3);

@@ -66,6 +66,22 @@ def lib():
                                 C.POINTER(C.c_size_t)]
         L.sjo_free.restype = None
         L.sjo_free.argtypes = [C.c_void_p]
+        # sjo_fast.c: AVX2 / PCLMULQDQ shapes for the CPU baseline
+        szp = C.POINTER(C.c_size_t)
+        L.sjo_avx2_available.restype = C.c_int
+        L.sjo_find_structural_indices_avx2.restype = C.c_int
+        L.sjo_find_structural_indices_avx2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp]
+        L.sjo_fast_create.restype = C.c_void_p
+        L.sjo_fast_destroy.argtypes = [C.c_void_p]
+        L.sjo_fast_parse.restype = C.c_int
+        L.sjo_fast_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(u64p), szp,
+                                     C.POINTER(u8p), szp]
+        L.sjo_bench_stage1.restype = C.c_double
+        L.sjo_bench_stage1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, szp]
+        L.sjo_bench_parse.restype = C.c_double
+        L.sjo_bench_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), szp]
+        L.sjo_bench_nd_blocks.restype = C.c_double
+        L.sjo_bench_nd_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -111,3 +127,39 @@ def parse(data, ndjson=False, copy_strings=True):
         p.tape = np.zeros(0, np.uint64)
         p.strings = np.zeros(0, np.uint8)
     return p
+
+
+def stage1_avx2(data, ndjson=False):
+    """sjo_fast.c: findStructuralIndices with the reference's AVX2 / PCLMULQDQ shapes."""
+    a = _as_np_u8(data)
+    cap = a.size + 64
+    pos = np.empty(cap, dtype=np.uint32)
+    n = C.c_size_t(0)
+    ok = lib().sjo_find_structural_indices_avx2(a.ctypes.data, a.size, int(ndjson), pos.ctypes.data, cap, C.byref(n))
+    return bool(ok), pos[: n.value].copy()
+
+
+class FastParser:
+    """sjo_fast.c: whole parse with recycled buffers, 1 thread or the reference's 2-thread stage1 || stage2 shape."""
+
+    def __init__(self):
+        self._w = lib().sjo_fast_create()
+
+    def close(self):
+        if self._w:
+            lib().sjo_fast_destroy(self._w)
+            self._w = None
+
+    def parse(self, data, ndjson=False, copy_strings=True, threads=1):
+        a = _as_np_u8(data)
+        tape, strs = u64p(), u8p()
+        tl, sl = C.c_size_t(0), C.c_size_t(0)
+        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
+        rc = lib().sjo_fast_parse(self._w, a.ctypes.data, a.size, flags, threads, C.byref(tape), C.byref(tl),
+                                  C.byref(strs), C.byref(sl))
+        p = Parsed()
+        p.rc = rc
+        p.msg_off = p.msg_len = 0
+        p.tape = np.ctypeslib.as_array(tape, shape=(tl.value,)).copy() if rc == 0 and tl.value else np.zeros(0, np.uint64)
+        p.strings = np.ctypeslib.as_array(strs, shape=(sl.value,)).copy() if rc == 0 and sl.value else np.zeros(0, np.uint8)
+        return p

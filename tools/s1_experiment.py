@@ -20,8 +20,8 @@ OUT = os.path.join(ROOT, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
 L = sjhip.lib()
 ctx = sjhip.Context(0)
-VARIANTS = [int(x) for x in os.environ.get("VARIANTS", "1 3 4 0 2").split()]
-NAMES = {0: "512 barrier", 1: "1024 barrier", 2: "768 barrier", 3: "1024 barrier-free", 4: "512 barrier-free"}
+VARIANTS = [int(x) for x in os.environ.get("VARIANTS", "1 3 4").split()]
+NAMES = {0: "512x2 barrier", 1: "1024x2 barrier", 2: "768x2 barrier", 3: "1024x2 claimed serial duty", 4: "1024x1 claimed serial duty"}
 report = {"variants": NAMES, "runs": []}
 
 
@@ -45,26 +45,10 @@ def trace(d_msg, n, d_pos, v):
     return t
 
 
-def summarize(t, kernel_ms):
-    t0 = t[:, :, 0][t[:, :, 0] > 0].min()
-    span = t[:, :, 4].max() - t0
-    a = (t[:, :, 1] - t[:, :, 0])
-    wait = (t[:, :, 3] - t[:, :, 1])          # arrival -> state known (barrier wait + serial section, or the flag poll)
-    fl = (t[:, :, 4] - t[:, :, 3])
-    ser = t[:, :, 2] - t[:, :, 1]
-    ser = ser[t[:, :, 2] > 0]
-    tiles, waves = t.shape[0], t.shape[1]
-    # the wave timeline is covered by A(next) , wait, flatten(cur): busy = A + flatten of all tiles
-    busy = float(a.sum() + fl.sum())
-    wave_time = float(span) * 256 * waves if tiles >= 256 else float(span) * tiles * waves
-    return {"ticks_per_us": round(float(span) / (kernel_ms * 1e3), 2), "span_ticks": int(span),
-            "phaseA_mean": round(float(a.mean()), 1), "phaseA_p95": float(np.percentile(a, 95)),
-            "wait_mean": round(float(wait.mean()), 1), "wait_p50": float(np.percentile(wait, 50)),
-            "wait_p95": float(np.percentile(wait, 95)),
-            "serial_mean": round(float(ser.mean()), 1) if ser.size else None,
-            "serial_p95": float(np.percentile(ser, 95)) if ser.size else None,
-            "flatten_mean": round(float(fl.mean()), 1), "flatten_p95": float(np.percentile(fl, 95)),
-            "busy_fraction_of_resident_wave_time": round(busy / wave_time, 4)}
+def summarize(path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import s1_timeline
+    return s1_timeline.analyse(path)
 
 
 for copies in [int(x) for x in os.environ.get("COPIES", "426 1700").split()]:
@@ -88,8 +72,9 @@ for copies in [int(x) for x in os.environ.get("COPIES", "426 1700").split()]:
                "input_GBps": round(n / min(ms) / 1e6, 1), "algo_GBps": round((n + 4 * expect) / min(ms) / 1e6, 1)}
         if v in (1, 3, 4) and copies == 426:
             t = trace(d_msg, n, d_pos, v)
-            np.savez_compressed(os.path.join(OUT, f"s1_trace_v{v}.npz"), trace=t)
-            run["timeline"] = summarize(t, min(ms))
+            path = os.path.join(OUT, f"s1_trace_v{v}.npz")
+            np.savez_compressed(path, trace=t)
+            run["timeline"] = summarize(path)
         print(json.dumps(run), flush=True)
         report["runs"].append(run)
     del d_msg, d_pos, ref_pos
