@@ -146,6 +146,19 @@ int sjo_find_structural_indices_avx2(const uint8_t *msg, size_t len, int ndjson,
 static const uint8_t ESCAPE_MAP[256] = {['"'] = 0x22, ['/'] = 0x2f, ['\\'] = 0x5c, ['b'] = 0x08, ['f'] = 0x0c,
                                         ['n'] = 0x0a, ['r'] = 0x0d, ['t'] = 0x09};
 
+/* digittoval as the DATA section lays it out (parse_string_amd64.s:12-37, quirk Q3: bytes below 0x30 read as 0) */
+static int8_t DIGIT[256];
+__attribute__((constructor)) static void init_digit(void) {
+    for (int b = 0; b < 256; b++) {
+        int8_t v = -1;
+        if (b < 0x30) v = 0;
+        else if (b >= '0' && b <= '9') v = (int8_t)(b - '0');
+        else if (b >= 'A' && b <= 'F') v = (int8_t)(b - 'A' + 10);
+        else if (b >= 'a' && b <= 'f') v = (int8_t)(b - 'a' + 10);
+        DIGIT[b] = v;
+    }
+}
+
 TGT static int string_avx2(const uint8_t *src, size_t avail, uint8_t *dst, uint64_t *str_length, uint64_t *dst_length) {
     size_t pos = 0, out = 0;
     const __m256i kb = _mm256_set1_epi8('\\'), kq = _mm256_set1_epi8('"');
@@ -167,12 +180,59 @@ TGT static int string_avx2(const uint8_t *src, size_t avail, uint8_t *dst, uint6
         }
         const unsigned b = (unsigned)_tzcnt_u32(bs_bits);
         const uint8_t esc = src[pos + b + 1];
-        if (esc == 'u') break; /* unicode escape: scalar walk from this window */
-        const uint8_t e = ESCAPE_MAP[esc];
-        if (e == 0) return 0;
-        if (dst) dst[out + b] = e;
-        out += b + 1;
-        pos += b + 2;
+        if (esc != 'u') { /* LBB0_26 */
+            const uint8_t e = ESCAPE_MAP[esc];
+            if (e == 0) return 0;
+            if (dst) dst[out + b] = e;
+            out += b + 1;
+            pos += b + 2;
+            continue;
+        }
+        /* \\uXXXX (LBB0_8 .. LBB0_14): needs the distance from the backslash to the next raw quote; when the window
+         * shows no quote and the backslash sits in its last 11 bytes the reference looks at a second window -- that
+         * case, and the last bytes of the message, go to the scalar walk */
+        if (quote_bits == 0 && b >= 21) break;
+        if (pos + b + 12 > avail) break;
+        const uint32_t d = quote_bits ? (uint32_t)_tzcnt_u32(quote_bits) - b : 32u - b;
+        if (d < 6) return 0;
+        const uint8_t *p = src + pos + b;
+        uint32_t cp = ((uint32_t)(int32_t)DIGIT[p[2]] << 12) | ((uint32_t)(int32_t)DIGIT[p[3]] << 8) |
+                      ((uint32_t)(int32_t)DIGIT[p[4]] << 4) | (uint32_t)(int32_t)DIGIT[p[5]];
+        unsigned adv = 6;
+        if ((cp & 0xfffffc00u) == 0xd800u) { /* LBB0_12: surrogate pair, low half unchecked, 32-bit wrap-around */
+            if (d < 12 || p[6] != '\\' || p[7] != 'u') return 0;
+            const uint32_t cp2 = ((uint32_t)(int32_t)DIGIT[p[8]] << 12) | ((uint32_t)(int32_t)DIGIT[p[9]] << 8) |
+                                 ((uint32_t)(int32_t)DIGIT[p[10]] << 4) | (uint32_t)(int32_t)DIGIT[p[11]];
+            if ((cp2 | cp) > 0xffffu) return 0;
+            cp = (((cp << 10) + 0xfca00000u) | (cp2 + 0xffff2400u)) + 0x10000u;
+            adv = 12;
+        }
+        uint8_t enc[4];
+        unsigned n;
+        if (cp < 0x80) {
+            n = 1;
+            enc[0] = (uint8_t)cp;
+        } else if (cp < 0x800) {
+            n = 2;
+            enc[0] = (uint8_t)((cp >> 6) + 192);
+            enc[1] = (uint8_t)((cp & 63) | 128);
+        } else if (cp < 0x10000) {
+            n = 3;
+            enc[0] = (uint8_t)((cp >> 12) + 224);
+            enc[1] = (uint8_t)(((cp >> 6) & 63) | 128);
+            enc[2] = (uint8_t)((cp & 63) | 128);
+        } else if (cp <= 0x10ffff) {
+            n = 4;
+            enc[0] = (uint8_t)((cp >> 18) + 240);
+            enc[1] = (uint8_t)(((cp >> 12) & 63) | 128);
+            enc[2] = (uint8_t)(((cp >> 6) & 63) | 128);
+            enc[3] = (uint8_t)((cp & 63) | 128);
+        } else {
+            return 0;
+        }
+        if (dst) memcpy(dst + out + b, enc, n);
+        out += b + n;
+        pos += b + adv;
     }
     return sjo_string_walk_from(src, avail, dst, pos, out, str_length, dst_length);
 }
@@ -186,22 +246,6 @@ static int copy_avx2(const uint8_t *src, size_t avail, uint8_t *dst, uint64_t *d
 /* ------------------------------------------------------------------------------------------------------------
  * whole parse with recycled buffers (`reuse *ParsedJson`), 1 or 2 threads
  * ---------------------------------------------------------------------------------------------------------- */
-typedef struct sjo_fast {
-    uint32_t *pos;
-    size_t pos_cap;
-    pj_t pj; /* tape / strs / scope capacities are kept across calls */
-} sjo_fast;
-
-sjo_fast *sjo_fast_create(void) { return (sjo_fast *)calloc(1, sizeof(sjo_fast)); }
-void sjo_fast_destroy(sjo_fast *w) {
-    if (!w) return;
-    free(w->pos);
-    free(w->pj.tape);
-    free(w->pj.strs);
-    free(w->pj.scope);
-    free(w);
-}
-
 typedef struct {
     const uint8_t *msg;
     size_t len;
@@ -212,11 +256,58 @@ typedef struct {
     int done, ok;
 } s1_job;
 
-static void *s1_thread(void *arg) {
-    s1_job *j = (s1_job *)arg;
-    j->ok = stage1_avx2(j->msg, j->len, j->ndjson, j->pos, j->pos_cap, &j->n, &j->live);
-    __atomic_store_n(&j->done, 1, __ATOMIC_RELEASE);
+TGT static int stage1_avx2(const uint8_t *msg, size_t len, int ndjson, uint32_t *pos, size_t pos_cap, size_t *n_out,
+                           size_t *live);
+
+typedef struct sjo_fast {
+    uint32_t *pos;
+    size_t pos_cap;
+    pj_t pj; /* tape / strs / scope capacities are kept across calls */
+    /* the stage-1 goroutine of the 2-thread shape: one helper thread per workspace, parked on a condition variable */
+    pthread_t helper;
+    int helper_started, helper_quit, job_pending;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    s1_job job;
+} sjo_fast;
+
+static void *helper_main(void *arg) {
+    sjo_fast *w = (sjo_fast *)arg;
+    pthread_mutex_lock(&w->mu);
+    for (;;) {
+        while (!w->job_pending && !w->helper_quit) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->helper_quit) break;
+        w->job_pending = 0;
+        pthread_mutex_unlock(&w->mu);
+        s1_job *j = &w->job;
+        j->ok = stage1_avx2(j->msg, j->len, j->ndjson, j->pos, j->pos_cap, &j->n, &j->live);
+        __atomic_store_n(&j->done, 1, __ATOMIC_RELEASE);
+        pthread_mutex_lock(&w->mu);
+    }
+    pthread_mutex_unlock(&w->mu);
     return NULL;
+}
+
+sjo_fast *sjo_fast_create(void) {
+    sjo_fast *w = (sjo_fast *)calloc(1, sizeof(sjo_fast));
+    pthread_mutex_init(&w->mu, NULL);
+    pthread_cond_init(&w->cv, NULL);
+    return w;
+}
+void sjo_fast_destroy(sjo_fast *w) {
+    if (!w) return;
+    if (w->helper_started) {
+        pthread_mutex_lock(&w->mu);
+        w->helper_quit = 1;
+        pthread_cond_signal(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pthread_join(w->helper, NULL);
+    }
+    free(w->pos);
+    free(w->pj.tape);
+    free(w->pj.strs);
+    free(w->pj.scope);
+    free(w);
 }
 
 /* parseMessage (parse_json_amd64.go:52-127).  threads = 2: stage 1 on its own thread, stage 2 consumes the
@@ -249,17 +340,24 @@ int sjo_fast_parse(sjo_fast *w, const uint8_t *msg, size_t len, uint32_t flags, 
     }
     int ok1, ok2;
     if (threads >= 2) {
-        s1_job job = {msg + off, mlen, (flags & SJO_FLAG_NDJSON) != 0, w->pos, w->pos_cap, 0, 0, 0, 0};
-        pthread_t th;
+        const s1_job job = {msg + off, mlen, (flags & SJO_FLAG_NDJSON) != 0, w->pos, w->pos_cap, 0, 0, 0, 0};
+        w->job = job;
         pj->npos = 0;
-        pj->live_npos = &job.live;
-        pj->live_done = &job.done;
-        pthread_create(&th, NULL, s1_thread, &job);
+        pj->live_npos = &w->job.live;
+        pj->live_done = &w->job.done;
+        pthread_mutex_lock(&w->mu);
+        if (!w->helper_started) {
+            pthread_create(&w->helper, NULL, helper_main, w);
+            w->helper_started = 1;
+        }
+        w->job_pending = 1;
+        pthread_cond_signal(&w->cv);
+        pthread_mutex_unlock(&w->mu);
         ok2 = sjo_unified_machine(pj);
-        pthread_join(th, NULL);
+        while (!__atomic_load_n(&w->job.done, __ATOMIC_ACQUIRE)) __builtin_ia32_pause(); /* wg.Wait() */
         pj->live_npos = NULL;
         pj->live_done = NULL;
-        ok1 = job.ok;
+        ok1 = w->job.ok;
     } else {
         size_t n = 0;
         pj->live_npos = NULL;

@@ -379,14 +379,14 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 // wave copies the buffer out with coalesced 256-byte stores.  A unit with more positions than the buffer holds
 // (512: the window that held the masks; 1024 in the whole-parse kernel) takes several rounds.
 static constexpr u32 S1_STAGE_CAP = 1024;
-template <int BLOCK, int CH, bool BIG>
+template <int BLOCK, int CH, bool BIG, u32 BIGCAP = S1_STAGE_CAP>
 __device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
                                              u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
                                              const u8 *s_klut) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
-    constexpr u32 CAP = BIG ? S1_STAGE_CAP : (u32)CH * 256u;
+    constexpr u32 CAP = BIG ? BIGCAP : (u32)CH * 256u;
     static_assert(UNITS <= 64, "one unit per lane in the prefix");
     // per-unit counts under the now known state, prefix over the units (lane u <-> unit u)
     const u32 v = lane < UNITS ? s_unit[lane] : 0u;
@@ -639,40 +639,44 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }
 
-// ---- the same tile pipeline without block barriers ------------------------------------------------------------
+// ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
 // The barrier kernel above stalls the whole CU twice per tile: at the first barrier the waves that finished phase A
 // early wait for the slowest one (the four waves of a SIMD finish one after the other), then everybody waits while
 // wave 0 runs the serial section, whose look-back costs one cross-CU hand-off (~3 us behind the CU's own streaming
-// loads).  The s_memtime timelines (profiles/) show ~18 of the ~36 k cycles of a tile round spent that way.
-// Here the waves of a block only meet through LDS words and nobody waits for a look-back that somebody else could
-// be running:
-//   * a wave that has finished phase A of tile T(j) adds 1 to an arrival counter; the wave that finds WAVES-1 there
-//     aggregates the tile, publishes its AGG descriptor and marks the tile ready -- a few hundred cycles;
-//   * the serial duty S(j) -- ticket T(j+3), look-back of T(j), PREFIX descriptor, result record res(j) = {state,
-//     unit parities, output base, ticket} -- is CLAIMED (LDS compare-and-swap) by whichever wave gets to it first:
-//     a wave that has just flattened T(j-1) (it is ahead of the others: the duty slows it down, so the role
-//     rotates), or, at the latest, the first wave that needs res(j) and finds it neither done nor claimed;
-//   * a wave needs res(j) only after it has flattened T(j-1) AND run phase A of T(j+1), a whole round after the
-//     tile became ready: in the steady state the hand-off latency is off every wave's critical path.
-// Slot reuse (a wave is at most one tile ahead of the slowest): s_unit / s_agg / s_arrive / s_ready 3, masks 2, res 4.
-template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
+// loads) plus the wait for the slowest of the ~256 tiles in front (they all run at the same time).  The s_memtime
+// timelines (profiles/) show about a third of every wave's life spent that way.
+// Here the waves of a block only meet through LDS words, a wave never waits for something another wave could be
+// doing, and the result of a look-back is asked for DEPTH-1 phase A's after the tile was aggregated:
+//   iteration k of a wave:   phase A of tile T(k)  ->  arrive  ->  [ need res(k-DEPTH+1) ]  ->  flatten T(k-DEPTH+1)
+//   * arrival: +1 on an LDS counter; the wave that finds WAVES-1 there aggregates the tile, publishes its AGG
+//     descriptor and marks the tile ready (a few hundred cycles);
+//   * the serial duty S(j) -- ticket T(j+DEPTH+1), look-back of T(j), PREFIX descriptor, result record res(j) =
+//     {state, unit parities, output base} -- is CLAIMED (LDS compare-and-swap) by whichever wave gets to it first:
+//     a wave that has just finished a flatten (it is ahead of the others; the duty slows it down, so the role
+//     rotates), or at the latest the first wave that needs res(j) and finds it neither done nor claimed.
+// Ring sizes: tickets and res / claim 8 (k & 7), masks DEPTH (private per wave), unit state 2*DEPTH: a wave can be
+// DEPTH iterations ahead of the slowest one, which may still be flattening the tile DEPTH-1 behind its own phase A.
+template <int BLOCK, int CH, int DEPTH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
                                                                Stage1State *__restrict__ st, u64 *__restrict__ desc,
                                                                u32 num_tiles, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
+    constexpr int NU = 2 * DEPTH;  // unit-state slots
     static_assert(UNITS <= 32, "pre_mask is a u32");
-    __shared__ u32 s_ticket[3];
-    __shared__ u32 s_unit[3][UNITS];
-    __shared__ u32 s_arrive[3];   // waves that have finished phase A of the tile in unit slot k
-    __shared__ u32 s_ready[3];    // j + 1 once tile T(j) (unit slot j % 3) is aggregated and its AGG published
-    __shared__ u32 s_agg[3][4];   // P, T0, T1, pre_mask of that tile
-    __shared__ u32 s_claim[4];    // j + 1 once the serial duty S(j) has been taken (slot j & 3)
-    __shared__ u32 s_res[4][8];   // res(j) in slot j & 3: G, pre_mask, BASE lo, BASE hi, ticket T(j+3), sequence j + 1
-    __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
-    __shared__ u32 s_pre[2][WAVES][CH * 64];
-    __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];
+    static_assert(DEPTH >= 2 && DEPTH <= 3, "ticket ring of 8");
+    constexpr u32 STAGE_CAP = AUX ? (DEPTH == 2 ? S1_STAGE_CAP : 512u) : 4u;
+    __shared__ u32 s_tk[8];         // T(k) in slot k & 7
+    __shared__ u32 s_unit[NU][UNITS];
+    __shared__ u32 s_arrive[NU];    // waves that have finished phase A of the tile in unit slot k % NU
+    __shared__ u32 s_ready[NU];     // k + 1 once tile T(k) is aggregated and its AGG published
+    __shared__ u32 s_agg[NU][4];    // P, T0, T1, pre_mask of that tile
+    __shared__ u32 s_claim[8];      // k + 1 once the serial duty S(k) has been taken (slot k & 7)
+    __shared__ u32 s_res[8][8];     // res(k) in slot k & 7: G, pre_mask, BASE lo, BASE hi, -, sequence k + 1
+    __shared__ u64 s_mask[DEPTH][WAVES][CH * 2 * 64];
+    __shared__ u32 s_pre[DEPTH][WAVES][CH * 64];
+    __shared__ u32 s_stage[AUX ? WAVES : 1][STAGE_CAP];
     __shared__ u8 s_klut[AUX ? 256 : 4];
 
     const int tid = threadIdx.x;
@@ -680,73 +684,73 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u8 k = c_s1_klut.v[tid];
         s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
     }
-    if (tid < 3) {
+    if (tid < NU) {
         s_arrive[tid] = 0;
         s_ready[tid] = 0;
     }
-    if (tid < 4) {
+    if (tid < 8) {
         s_res[tid][5] = 0;
-        s_claim[tid] = (u32)tid - 3u;  // the value the claim of S(tid) expects: (j + 1) - 4
+        s_claim[tid] = (u32)tid - 7u;  // the value the claim of S(tid) expects: (k + 1) - 8
+        s_tk[tid] = 0xffffffffu;
     }
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
     auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
 
-    // prologue (two block barriers, once per block): first ticket alone, the next two while phase A of the first
+    // prologue (two block barriers, once per block): first ticket alone, the next DEPTH while phase A of the first
     // tile runs
-    if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
-    u32 t_cur = uniform(s_ticket[0]);
-    if (t_cur >= num_tiles) return;
+    if (tid == 0) s_tk[0] = atomicAdd(&st->tile_counter, 1u);
+    __syncthreads();
+    const u32 t_first = uniform(s_tk[0]);
+    if (t_first >= num_tiles) return;
     uint4 pf[4];
     {
-        const u64 un = (u64)t_cur * UNITS + (u64)wave;
+        const u64 un = (u64)t_first * UNITS + (u64)wave;
         unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
     if (tid == 0) {
-        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
-        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
-    }
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux);
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
-    __syncthreads();
-    u32 t_nxt = uniform(s_ticket[1]), t_nn = uniform(s_ticket[2]);
-    if (t_nxt < num_tiles) {
-        const u64 un = (u64)t_nxt * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
-    }
-    if (wave == 0) {
-        u32 P0, T00, T01, pm0;
-        tile_aggregate<UNITS>(s_unit[0], lane, P0, T00, T01, pm0);
-        if (lane == 0) {
-            desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
-            s_agg[0][0] = P0;
-            s_agg[0][1] = T00;
-            s_agg[0][2] = T01;
-            s_agg[0][3] = pm0;
-            __hip_atomic_store(&s_ready[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+#pragma unroll
+        for (int k = 1; k <= DEPTH; k++) s_tk[k] = atomicAdd(&st->tile_counter, 1u);
     }
 
-    // The serial duty S(j) for tile tj = T(j) in unit slot uj; tj1 = T(j+1) (a ticket T(j+3) is drawn only if it is a
-    // tile).  Returns false without doing anything if the tile is not ready yet or another wave has the duty.
-    auto serial_duty = [&](u32 j, u32 tj, u32 tj1, int uj) -> bool {
+    // arrival for tile T(k) = tk (unit slot uk); the last wave aggregates it and publishes its descriptor
+    auto arrive = [&](u32 k, u32 tk, int uk) {
+        u32 arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[uk], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (uniform(arrived) == (u32)WAVES - 1u) {
+            u32 P1, T10, T11, pm1;
+            tile_aggregate<UNITS>(s_unit[uk], lane, P1, T10, T11, pm1);
+            if (lane == 0) {
+                desc_store(&desc[tk], tk == 0 ? pack_prefix(P1, T10) : pack_agg(P1, T10, T11));
+                s_arrive[uk] = 0;  // next used NU tiles from now
+                s_agg[uk][0] = P1;
+                s_agg[uk][1] = T10;
+                s_agg[uk][2] = T11;
+                s_agg[uk][3] = pm1;
+                __hip_atomic_store(&s_ready[uk], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    // The serial duty S(j) for tile T(j) in unit slot uj.  Returns false without doing anything if the tile is not
+    // ready yet or another wave has the duty.
+    auto serial_duty = [&](u32 j, int uj) -> bool {
         if (__hip_atomic_load(&s_ready[uj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1u) return false;
         u32 won = 0;
         if (lane == 0) {
-            u32 expect = j - 3u;
-            won = __hip_atomic_compare_exchange_strong(&s_claim[j & 3u], &expect, j + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+            u32 expect = j - 7u;
+            won = __hip_atomic_compare_exchange_strong(&s_claim[j & 7u], &expect, j + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP)
                       ? 1u
                       : 0u;
         }
         if (!uniform(won)) return false;
-        u32 *res = s_res[j & 3u];
+        const u32 tj = uniform(s_tk[j & 7u]);
+        u32 *res = s_res[j & 7u];
+        // ticket T(j+DEPTH+1), drawn only while the newest known ticket is still a tile; it returns during the look-back
         u32 tk = 0xffffffffu;
-        if (tj1 < num_tiles && lane == 0) tk = atomicAdd(&st->tile_counter, 1u);  // returns during the look-back
+        if (lane == 0 && s_tk[(j + DEPTH) & 7u] < num_tiles) tk = atomicAdd(&st->tile_counter, 1u);
         const u32 P0 = uniform(s_agg[uj][0]), T00 = uniform(s_agg[uj][1]), T01 = uniform(s_agg[uj][2]),
                   pm0 = uniform(s_agg[uj][3]);
         u32 G = 0;
@@ -769,11 +773,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             if (lane == 0) desc_store(&desc[tj], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
         }
         if (lane == 0) {
+            s_tk[(j + DEPTH + 1) & 7u] = tk;
             res[0] = G;
             res[1] = pm0;
             res[2] = (u32)BASE;
             res[3] = (u32)(BASE >> 32);
-            res[4] = tk;
             if (tj == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
             __hip_atomic_store(&res[5], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -781,67 +785,77 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         return true;
     };
 
-    int ms = 0, us = 0;
-    u32 iter = 0;
+    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+                                    aux);
+    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
+    __syncthreads();  // the tickets T(1) .. T(DEPTH) are in s_tk
+    {
+        const u32 t1 = uniform(s_tk[1]);
+        if (t1 < num_tiles) {
+            const u64 un = (u64)t1 * UNITS + (u64)wave;
+            unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        }
+    }
+    arrive(0u, t_first, 0);
+
+    // k: the tile phase A runs on in this iteration; f = k - (DEPTH - 1): the tile that is flattened
+    int mk = 1 % DEPTH, uk = 1 % NU;   // mask / unit slot of T(k)
+    int mf = 0, uf = 0;                // of T(f): the first tile flattened is T(0)
+    u32 next_duty = 0;                 // no res(j) below this is missing (wave-local view)
     bool err = false;
-    for (;; iter++) {
-        const bool has_next = t_nxt < num_tiles;
-        const int us_n = us == 2 ? 0 : us + 1;
-        if (has_next) {
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux);
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
-            // ---- arrival; the last wave aggregates the tile and publishes its AGG descriptor
-            u32 arrived = 0;
-            if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[us_n], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (uniform(arrived) == (u32)WAVES - 1u) {
-                u32 P1, T10, T11, pm1;
-                tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
-                if (lane == 0) {
-                    desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
-                    s_arrive[us_n] = 0;  // next used three tiles from now, behind two result hand-offs
-                    s_agg[us_n][0] = P1;
-                    s_agg[us_n][1] = T10;
-                    s_agg[us_n][2] = T11;
-                    s_agg[us_n][3] = pm1;
-                    __hip_atomic_store(&s_ready[us_n], iter + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (u32 k = 1;; k++) {
+        const u32 ta = uniform(s_tk[k & 7u]);
+        if (ta < num_tiles) {
+            const u32 tn = uniform(s_tk[(k + 1u) & 7u]);
+            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
+                                            s_unit[uk], aux);
+            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
+            arrive(k, ta, uk);
+        }
+        if (k + 1u >= (u32)DEPTH) {
+            const u32 f = k + 1u - (u32)DEPTH;
+            const u32 tf = uniform(s_tk[f & 7u]);
+            if (tf >= num_tiles) break;  // tickets are monotonic: nothing left in flight
+            // ---- the state in front of T(f): done by now in the steady state; otherwise take the duty
+            u32 *res = s_res[f & 7u];
+            {
+                u32 spins = 0;
+                while (__hip_atomic_load(&res[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1u) {
+                    if (serial_duty(f, uf)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 24)) {
+                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                        break;
+                    }
                 }
             }
-        }
-        // ---- the state in front of the current tile: done by now in the steady state; otherwise take the duty
-        u32 *res = s_res[iter & 3u];
-        {
-            u32 spins = 0;
-            while (__hip_atomic_load(&res[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != iter + 1u) {
-                if (serial_duty(iter, t_cur, t_nxt, us)) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) {
-                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
-                    break;
-                }
+            trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 3);
+            const u32 G = uniform(res[0]), pm = uniform(res[1]);
+            const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
+            u64 tile_end = 0;
+            err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
+                                           wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
+                                           AUX ? aux.kind : nullptr, base + lead, s_klut);
+            if (tf == num_tiles - 1 && tid == 0) st->total = tile_end;
+            trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
+            if (TRACE && lane == 0)
+                aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
+                    (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+            // ahead of the others?  Then the oldest look-back that nobody has taken yet is ours (if its tile is ready).
+            if (next_duty <= f) next_duty = f + 1u;
+            if (next_duty <= k) {
+                if (__hip_atomic_load(&s_res[next_duty & 7u][5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == next_duty + 1u)
+                    next_duty++;
+                else
+                    (void)serial_duty(next_duty, (int)(next_duty % (u32)NU));
             }
+            mf = mf + 1 == DEPTH ? 0 : mf + 1;
+            uf = uf + 1 == NU ? 0 : uf + 1;
         }
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
-        const u32 G = uniform(res[0]), pm = uniform(res[1]);
-        const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
-        const u32 t_3 = uniform(res[4]);
-        u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
-        if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
-        if (TRACE && lane == 0)
-            aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
-                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-        if (!has_next) break;
-        // ahead of the others?  Then the look-back of the next tile is ours if it is ready and nobody has it yet.
-        (void)serial_duty(iter + 1u, t_nxt, t_nn, us_n);
-        t_cur = t_nxt;
-        t_nxt = t_nn;
-        t_nn = t_3;
-        ms ^= 1;
-        us = us_n;
+        mk = mk + 1 == DEPTH ? 0 : mk + 1;
+        uk = uk + 1 == NU ? 0 : uk + 1;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }
@@ -854,10 +868,10 @@ static constexpr int S1_DEFAULT_VARIANT = 1;
 
 struct S1Variant {
     int block, ch, wpe;
-    bool nb;
+    int depth;  // 0: the barrier kernel; otherwise tiles in flight of the barrier-free kernel
 };
-static const S1Variant S1_VARIANTS[] = {{512, 2, 4, false}, {1024, 2, 4, false}, {768, 2, 3, false},
-                                        {1024, 2, 4, true}, {1024, 1, 4, true}};
+static const S1Variant S1_VARIANTS[] = {{512, 2, 4, 0}, {1024, 2, 4, 0}, {768, 2, 3, 0},
+                                        {1024, 2, 4, 2}, {1024, 2, 4, 3}, {1024, 1, 4, 3}};
 static constexpr int S1_NVARIANTS = (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0]);
 static int g_s1_variant = -1;
 int stage1_set_variant(int v) {  // -1: back to SJHIP_S1_VARIANT / the default; returns the variant in effect
@@ -953,15 +967,31 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
             else S1_LAUNCHK((KERNEL<B, C, W, false, false>), B);                      \
         }                                                                             \
     } while (0)
-    if (v.nb) {
-        if (v.ch == 2) S1_LAUNCH(stage1_kernel_nb, 1024, 2, 4);
-        else S1_LAUNCH(stage1_kernel_nb, 1024, 1, 4);
+#define S1_LAUNCH_NB(B, C, D, W)                                                            \
+    do {                                                                                   \
+        const bool ax = aux_buf || d_kind;                                                 \
+        if (d_trace) {                                                                     \
+            if (nd || ax) return hipErrorInvalidValue;                                     \
+            S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false, true>), B);             \
+        } else if (nd) {                                                                   \
+            if (ax) S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, true, true>), B);             \
+            else S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, true, false>), B);               \
+        } else {                                                                           \
+            if (ax) S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, true>), B);            \
+            else S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false>), B);              \
+        }                                                                                  \
+    } while (0)
+    if (v.depth) {
+        if (v.ch == 2 && v.depth == 2) S1_LAUNCH_NB(1024, 2, 2, 4);
+        else if (v.ch == 2) S1_LAUNCH_NB(1024, 2, 3, 4);
+        else S1_LAUNCH_NB(1024, 1, 3, 4);
     } else {
         if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
         else if (v.block == 768) S1_LAUNCH(stage1_kernel, 768, 2, 3);
         else S1_LAUNCH(stage1_kernel, 512, 2, 4);
     }
 #undef S1_LAUNCH
+#undef S1_LAUNCH_NB
 #undef S1_LAUNCHK
     return hipGetLastError();
 }
