@@ -41,6 +41,9 @@ typedef struct sjhip_ctx sjhip_ctx;
 #define SJHIP_ERR_NODEVICE 3 /* "Host CPU does not meet target specs" analogue     simdjson_amd64.go:43  */
 #define SJHIP_ERR_TOOBIG 4  /* message longer than 4 GiB - 64 (positions are uint32 like the reference's index stream) */
 #define SJHIP_ERR_ARG 5
+#define SJHIP_STREAM_FULL 6  /* sjhip_stream_acquire: every slot holds a block: take a result first */
+#define SJHIP_STREAM_EMPTY 7 /* sjhip_stream_next: nothing submitted is outstanding */
+#define SJHIP_ERR_STREAM_CLOSED 8 /* the stream has delivered an error: it accepts and delivers nothing more */
 #define SJHIP_ERR_HIP (-1)  /* a HIP runtime call failed */
 
 /* ---- backend presence: replaces SupportedCPU() (simdjson_amd64.go:37) -------------------- */
@@ -84,6 +87,48 @@ int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t string
 /* bytes.TrimSpace exactly as parseMessage applies it (parse_json_amd64.go:55); for hosts that are not Go */
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len);
 
+/* ---- ParseNDStream: replaces the block pipeline of simdjson_amd64.go:101-216 --------------------------------------
+ * The binding cuts the input into blocks that end at a record boundary (simdjson_amd64.go:155-176; tmpSize = 10 MiB)
+ * and feeds them to a stream; every block is parsed as an independent NDJSON document with every string copied
+ * (:180) and the results come back in submission order.  A stream owns `slots` blocks in flight, spread round robin
+ * over `n_devices` devices starting at `first_device` (0 devices = all that are visible; 0 slots = 3 per device);
+ * every slot has its own context, HIP stream, pinned input block and pinned result buffers, so the H2D copy of one
+ * block, the kernels of another and the D2H copy of a third overlap.
+ *   acquire  : a pinned block of sjhip_stream_block_capacity() bytes to read the input into (the reference's tmpPool);
+ *              SJHIP_STREAM_FULL when every slot is busy (take a result first)
+ *   grow     : a record that runs past the acquired block: a larger pinned block, the first `keep` bytes kept
+ *   submit   : queue the acquired block (its first `len` bytes)            submit_copy = acquire + memcpy + submit
+ *   next     : the result of the oldest outstanding block (blocks until it is done).  Tape / Strings.B / Message
+ *              point into memory of the stream and stay valid until sjhip_stream_release (copy them into the
+ *              caller's slices: the reference's `reuse` recycling is the caller's side of that copy).  A block that
+ *              fails returns its error code (SJHIP_ERR_STAGE1 / _STAGE2 / ...), which ends the stream like the
+ *              reference's first Stream{Error}: later calls return SJHIP_ERR_STREAM_CLOSED.  SJHIP_STREAM_EMPTY when
+ *              nothing is outstanding (the caller reports io.EOF once its reader is exhausted).
+ * One thread may submit while another takes results. */
+typedef struct sjhip_stream sjhip_stream;
+typedef struct sjhip_stream_result {
+    const uint64_t *tape;
+    size_t tape_len;
+    const uint8_t *strings;
+    size_t strings_len;
+    const uint8_t *message; /* TrimSpace'd block (inside the pinned input block) */
+    size_t message_len;
+    int device;
+} sjhip_stream_result;
+sjhip_stream *sjhip_stream_create(int first_device, int n_devices, size_t block_bytes, int slots, uint32_t flags);
+void sjhip_stream_destroy(sjhip_stream *s);
+size_t sjhip_stream_block_capacity(const sjhip_stream *s);
+int sjhip_stream_slots(const sjhip_stream *s);
+int sjhip_stream_in_flight(sjhip_stream *s);
+const char *sjhip_stream_last_error(const sjhip_stream *s);
+int sjhip_stream_acquire(sjhip_stream *s, uint8_t **block, size_t *capacity);
+int sjhip_stream_grow(sjhip_stream *s, size_t keep, size_t new_capacity, uint8_t **block);
+int sjhip_stream_submit(sjhip_stream *s, size_t len);
+int sjhip_stream_cancel(sjhip_stream *s); /* hand the acquired block back unused */
+int sjhip_stream_submit_copy(sjhip_stream *s, const uint8_t *block, size_t len);
+int sjhip_stream_next(sjhip_stream *s, sjhip_stream_result *out);
+int sjhip_stream_release(sjhip_stream *s);
+
 /* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------
  * pos_out receives ABSOLUTE uint32 byte positions (running sum of the reference's deltas).
  * *ok = the reference's return value (error_mask == 0 && indexTotal > 0 && end-of-doc checks). */
@@ -99,7 +144,7 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
 
 /* ---- profiling aids (not needed by a binding) -------------------------------------------------------------------
  * sjhip_stage1_set_variant: kernel variant used by this process for stage 1 (A/B runs on hardware): 0 512-thread
- *   blocks with barriers, 1 1024 with barriers, 2 768 with barriers, 3 1024x2 barrier-free with 2 tiles in flight, 4 the same with 3, 5 1024x1 with 3;
+ *   blocks with barriers, 1 1024 with barriers, 2 768 with barriers, 3 1024x2 barrier-free with 2 tiles in flight, 4 the same with 3, 5 1024x1 with 3, 6 1024x2 with one barrier per tile and the look-back at the start of the round;
  *   -1 = the SJHIP_S1_VARIANT environment variable or the default.  Returns the variant in effect.
  * sjhip_stage1_trace: one stage-1 launch of a profiling build of the current variant that stamps s_memtime at the
  *   phase boundaries of every (tile, wave): trace_out[(tile * waves + wave) * words + k], k = 0 phase A begins,

@@ -13,6 +13,12 @@ u32p = C.POINTER(C.c_uint32)
 szp = C.POINTER(C.c_size_t)
 intp = C.POINTER(C.c_int)
 
+class StreamResult(C.Structure):
+    """sjhip_stream_result (include/sjhip.h)"""
+    _fields_ = [("tape", C.c_void_p), ("tape_len", C.c_size_t), ("strings", C.c_void_p), ("strings_len", C.c_size_t),
+                ("message", C.c_void_p), ("message_len", C.c_size_t), ("device", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/sjhip.h
 SYMBOLS = {
     "sjhip_supported": (C.c_int, []),
@@ -32,6 +38,19 @@ SYMBOLS = {
                                       intp]),
     "sjhip_stage1_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_float)]),
+    "sjhip_stream_create": (C.c_void_p, [C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint32]),
+    "sjhip_stream_destroy": (None, [C.c_void_p]),
+    "sjhip_stream_block_capacity": (C.c_size_t, [C.c_void_p]),
+    "sjhip_stream_slots": (C.c_int, [C.c_void_p]),
+    "sjhip_stream_in_flight": (C.c_int, [C.c_void_p]),
+    "sjhip_stream_last_error": (C.c_char_p, [C.c_void_p]),
+    "sjhip_stream_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), szp]),
+    "sjhip_stream_grow": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sjhip_stream_submit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "sjhip_stream_cancel": (C.c_int, [C.c_void_p]),
+    "sjhip_stream_submit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "sjhip_stream_next": (C.c_int, [C.c_void_p, C.POINTER(StreamResult)]),
+    "sjhip_stream_release": (C.c_int, [C.c_void_p]),
     "sjhip_stage1_set_variant": (C.c_int, [C.c_int]),
     "sjhip_stage1_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_uint), intp, intp]),

@@ -349,6 +349,37 @@ def test_parse_nd_stream():
     assert ref_bad.rc != 0 and n_ok == 3
 
 
+def test_stream_long_records_reuse_and_whitespace_block():
+    """sjhip_stream_*: a record longer than the pinned block (grow path), `reuse` recycling, every visible device,
+    and a whitespace-only block, which the reference parses and rejects (simdjson_amd64.go:178, parseMessage)."""
+    import io
+    import queue
+    import sjhip
+    rnd = random.Random(11)
+    recs = [('{"i":%d,"s":"%s"}' % (i, "x" * rnd.choice([3, 50, 700]))).encode() for i in range(3000)]
+    recs[1500] = b'{"big":"' + b"y" * (3 << 20) + b'"}'          # 3 MiB record, blocks of 256 KiB
+    stream = b"\n".join(recs) + b"\n"
+    bs = 256 << 10
+    blocks = list(sjhip.cut_blocks(io.BytesIO(stream), bs))
+    back = queue.SimpleQueue()
+    got = []
+    for pj in sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=4, reuse=back, n_devices=0):
+        got.append((bytes(pj.Message), pj.Tape.copy(), pj.Strings.copy()))
+        back.put(pj)
+    assert len(got) == len(blocks)
+    for (msg, tape, strs), blk in zip(got, blocks):
+        ref = O.parse(blk, ndjson=True, copy_strings=True)
+        assert ref.rc == 0 and np.array_equal(tape, ref.tape) and np.array_equal(strs, ref.strings)
+        assert msg == bytes(blk[ref.msg_off:ref.msg_off + ref.msg_len])
+    # blank lines for more than a block: the second block is whitespace only -> the stream ends with its error
+    ws = b'{"a":1}\n' + b"\n" * (3 * bs) + b'{"b":2}\n'
+    n_ok = 0
+    with pytest.raises(sjhip.ParseError):
+        for _ in sjhip.parse_nd_stream(io.BytesIO(ws), block_size=bs, inflight=2):
+            n_ok += 1
+    assert n_ok <= 1
+
+
 def test_concurrent_contexts():
     """One context per concurrent parse (the reference's goroutine-per-parse model, benchmarks_test.go:60-75):
     four host threads parse different documents on the same GPU at the same time; every result must be the oracle's."""

@@ -1,0 +1,81 @@
+"""ParseNDStream through the library (sjhip_stream_*): host memory -> tapes in host memory, configs[4] sized input
+(parking-citations x COPIES), 10 MiB blocks.  The input is read (memmove) straight into the pinned blocks and every
+result is copied out of pinned memory into preallocated arrays -- the work a Go caller does with its reader and
+its `reuse`d ParsedJson.  Prints one JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "simdjson-go_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import sjhip  # noqa: E402
+import workloads  # noqa: E402
+from sjhip import _lib  # noqa: E402
+
+
+def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
+    L = sjhip.lib()
+    n = len(data)
+    src = np.frombuffer(data, dtype=np.uint8)
+    cap = block + block // 8 + (64 << 10)
+    h = L.sjhip_stream_create(0, n_devices, cap, slots, 0)
+    assert h
+    out_t = np.empty(cap // 2, dtype=np.uint64)   # a reused ParsedJson: capacity for the largest block
+    out_s = np.empty(cap, dtype=np.uint8)
+    res = _lib.StreamResult()
+    off = 0
+    tape_words = strings = blocks = 0
+    t0 = time.perf_counter()
+
+    def take():
+        nonlocal tape_words, strings, blocks
+        rc = L.sjhip_stream_next(h, C.byref(res))
+        if rc in (7, 8):
+            return False
+        assert rc == 0, (rc, L.sjhip_stream_last_error(h))
+        if copy_out:
+            C.memmove(out_t.ctypes.data, res.tape, res.tape_len * 8)
+            C.memmove(out_s.ctypes.data, res.strings, res.strings_len)
+        tape_words += res.tape_len
+        strings += res.strings_len
+        blocks += 1
+        L.sjhip_stream_release(h)
+        return True
+
+    ptr, c = C.c_void_p(), C.c_size_t()
+    while off < n:
+        rc = L.sjhip_stream_acquire(h, C.byref(ptr), C.byref(c))
+        if rc == 6:
+            take()
+            continue
+        assert rc == 0
+        end = min(n, off + block)
+        if end < n:
+            nl = data.find(b"\n", end)
+            end = n if nl < 0 else nl + 1
+        C.memmove(ptr.value, src.ctypes.data + off, end - off)
+        assert L.sjhip_stream_submit(h, end - off) == 0
+        off = end
+    while take():
+        pass
+    dt = time.perf_counter() - t0
+    L.sjhip_stream_destroy(h)
+    return {"bytes": n, "blocks": blocks, "seconds": round(dt, 4), "GBps": round(n / dt / 1e9, 2),
+            "tape_words": tape_words, "strings_bytes": strings, "slots": slots, "devices": n_devices,
+            "copy_out": copy_out, "output_bytes_per_input_byte": round((tape_words * 8 + strings) / n, 3)}
+
+
+if __name__ == "__main__":
+    copies = int(os.environ.get("COPIES", "1000"))
+    data = workloads.c5_parking_nd(copies)
+    run(data[: 64 << 20])  # warm-up: arenas, pinned result buffers
+    out = []
+    for slots in (3, 6):
+        for copy_out in (True, False):
+            out.append(run(data, slots=slots, copy_out=copy_out))
+    print(json.dumps({"stream": out}))
