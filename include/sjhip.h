@@ -144,7 +144,8 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
 
 /* ---- profiling aids (not needed by a binding) -------------------------------------------------------------------
  * sjhip_stage1_set_variant: kernel variant used by this process for stage 1 (A/B runs on hardware): 0 512-thread
- *   blocks with barriers, 1 1024 with barriers, 2 768 with barriers, 3 1024x2 barrier-free with 2 tiles in flight, 4 the same with 3, 5 1024x1 with 3, 6 1024x2 with one barrier per tile and the look-back at the start of the round;
+ *   blocks with barriers, 1 1024 with barriers (default), 2 768 with barriers, 3 1024 barrier-free with 2 tiles in
+ *   flight per block, 4 the same with 3;
  *   -1 = the SJHIP_S1_VARIANT environment variable or the default.  Returns the variant in effect.
  * sjhip_stage1_trace: one stage-1 launch of a profiling build of the current variant that stamps s_memtime at the
  *   phase boundaries of every (tile, wave): trace_out[(tile * waves + wave) * words + k], k = 0 phase A begins,

@@ -639,149 +639,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }
 
-// ---- one barrier per tile, look-back at the start of the round ---------------------------------------------------
-// Same two-tiles-in-flight pipeline as stage1_kernel, but the look-back of the current tile no longer sits between two
-// block barriers with fifteen waves waiting for it.  Its inputs -- the AGG descriptors of the tiles in front -- were
-// published a whole flatten ago (every block publishes right behind its barrier), so wave 0 runs it at the START of
-// the round, before its own phase A: the ~8 k cycles it takes are load latency (the hand-off queues behind the CU's own
-// streaming loads), during which the other three waves of SIMD 0 use the issue slots; the SIMD still finishes its
-// four phase A's at the same time as the others.  What is left behind the barrier is the tile aggregate and the AGG
-// store (a few hundred cycles, wave 0 only); the other waves go straight on to the flatten.  The result record and
-// the ticket are double-buffered by round parity, so the second barrier is gone.
-template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
-__global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_e(const u8 *__restrict__ base, u64 lead, u64 len,
-                                                              u32 *__restrict__ out_pos, u64 pos_cap,
-                                                              Stage1State *__restrict__ st, u64 *__restrict__ desc,
-                                                              u32 num_tiles, S1Aux aux) {
-    constexpr int WAVES = BLOCK / 64;
-    constexpr int UNITS = WAVES * CH;
-    static_assert(UNITS <= 32, "pre_mask is a u32");
-    __shared__ u32 s_ticket[3];
-    __shared__ u32 s_tk[2];
-    __shared__ u32 s_unit[3][UNITS];
-    __shared__ u32 s_res[2][4];  // by round parity: G, pre_mask, BASE (lo, hi)
-    __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
-    __shared__ u32 s_pre[2][WAVES][CH * 64];
-    __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];
-    __shared__ u8 s_klut[AUX ? 256 : 4];
-
-    const int tid = threadIdx.x;
-    if (AUX && tid < 256) {  // '\n' is a token only in NDJSON
-        const u8 k = c_s1_klut.v[tid];
-        s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
-    }
-    const int lane = tid & 63;
-    const int wave = (int)uniform((u32)tid >> 6);
-    const u64 end = lead + len;
-    auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
-
-    if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
-    __syncthreads();
-    u32 t_cur = uniform(s_ticket[0]);
-    if (t_cur >= num_tiles) return;
-    uint4 pf[4];
-    {
-        const u64 un = (u64)t_cur * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
-    }
-    if (tid == 0) {
-        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
-        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
-    }
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux);
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
-    __syncthreads();
-    u32 t_nxt = uniform(s_ticket[1]), t_nn = uniform(s_ticket[2]);
-    if (t_nxt < num_tiles) {
-        const u64 un = (u64)t_nxt * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
-    }
-    u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // of the current tile; meaningful in wave 0 only
-    if (wave == 0) {
-        tile_aggregate<UNITS>(s_unit[0], lane, P0, T00, T01, pm0);
-        if (lane == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
-    }
-
-    int ms = 0, us = 0;
-    u32 round = 0;
-    bool err = false;
-    for (;; round++) {
-        const bool has_next = t_nxt < num_tiles;
-        const int us_n = us == 2 ? 0 : us + 1;
-        const u32 par = round & 1u;
-        if (wave == 0) {
-            // the ticket after t_nn: drawn now, it returns during the look-back
-            u32 tk = 0xffffffffu;
-            if (has_next && lane == 0) tk = atomicAdd(&st->tile_counter, 1u);
-            u32 G = 0;
-            u64 BASE = 0;
-            if (t_cur != 0) {
-                LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
-                u64 win[4];
-                lookback_load(desc, lb.j, lane, win);
-                u32 spins = 0;
-                for (;;) {
-                    const int r = lookback_eval(win, lb, lane, G, BASE);
-                    if (r == 1) break;
-                    if (r == 0) __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
-                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
-                        break;
-                    }
-                    lookback_load(desc, lb.j, lane, win);
-                }
-                if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
-            }
-            if (lane == 0) {
-                s_res[par][0] = G;
-                s_res[par][1] = pm0;
-                s_res[par][2] = (u32)BASE;
-                s_res[par][3] = (u32)(BASE >> 32);
-                s_tk[par] = tk;
-                if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
-            }
-            trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
-        }
-        if (has_next) {
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux);
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
-        }
-        __syncthreads();  // the only barrier of the round: the next tile's unit states and the result record are in LDS
-        u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
-        if (wave == 0 && has_next) {
-            tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
-            if (lane == 0) desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
-        }
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
-        const u32 G = uniform(s_res[par][0]), pm = uniform(s_res[par][1]);
-        const u64 BASE = ((u64)uniform(s_res[par][3]) << 32) | uniform(s_res[par][2]);
-        const u32 t_new = uniform(s_tk[par]);
-        u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
-        if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
-        if (TRACE && lane == 0)
-            aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
-                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-        if (!has_next) break;
-        P0 = P1;
-        T00 = T10;
-        T01 = T11;
-        pm0 = pm1;
-        t_cur = t_nxt;
-        t_nxt = t_nn;
-        t_nn = t_new;
-        ms ^= 1;
-        us = us_n;
-    }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-}
-
 // ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
 // The barrier kernel above stalls the whole CU twice per tile: at the first barrier the waves that finished phase A
 // early wait for the slowest one (the four waves of a SIMD finish one after the other), then everybody waits while
@@ -859,7 +716,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     }
 
     // arrival for tile T(k) = tk (unit slot uk); the last wave aggregates it and publishes its descriptor
-    auto arrive = [&](u32 k, u32 tk, int uk) {
+    auto arrive = [&](u32 k, u32 tk, int uk) -> bool {  // true: this wave was the last one
         u32 arrived = 0;
         if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[uk], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (uniform(arrived) == (u32)WAVES - 1u) {
@@ -874,7 +731,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
                 s_agg[uk][3] = pm1;
                 __hip_atomic_store(&s_ready[uk], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            return true;
         }
+        return false;
     };
     // The serial duty S(j) for tile T(j) in unit slot uj.  Returns false without doing anything if the tile is not
     // ready yet or another wave has the duty.
@@ -940,7 +799,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
         }
     }
-    arrive(0u, t_first, 0);
+    // pipeline fill: no wave is behind a flatten yet, so the wave that completes a tile takes its look-back at once
+    if (arrive(0u, t_first, 0)) (void)serial_duty(0u, 0);
 
     // k: the tile phase A runs on in this iteration; f = k - (DEPTH - 1): the tile that is flattened
     int mk = 1 % DEPTH, uk = 1 % NU;   // mask / unit slot of T(k)
@@ -955,7 +815,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
                                             s_unit[uk], aux);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
-            arrive(k, ta, uk);
+            if (arrive(k, ta, uk) && k + 1u < (u32)DEPTH &&
+                __hip_atomic_load(&s_res[(k - 1u) & 7u][5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == k)
+                (void)serial_duty(k, uk);
         }
         if (k + 1u >= (u32)DEPTH) {
             const u32 f = k + 1u - (u32)DEPTH;
@@ -1014,7 +876,7 @@ struct S1Variant {
     int depth;  // 0: the barrier kernel; otherwise tiles in flight of the barrier-free kernel
 };
 static const S1Variant S1_VARIANTS[] = {{512, 2, 4, 0}, {1024, 2, 4, 0}, {768, 2, 3, 0},
-                                        {1024, 2, 4, 2}, {1024, 2, 4, 3}, {1024, 1, 4, 3}, {1024, 2, 4, -1}};
+                                        {1024, 2, 4, 2}, {1024, 2, 4, 3}};
 static constexpr int S1_NVARIANTS = (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0]);
 static int g_s1_variant = -1;
 int stage1_set_variant(int v) {  // -1: back to SJHIP_S1_VARIANT / the default; returns the variant in effect
@@ -1124,12 +986,9 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
             else S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false>), B);              \
         }                                                                                  \
     } while (0)
-    if (v.depth < 0) {
-        S1_LAUNCH(stage1_kernel_e, 1024, 2, 4);
-    } else if (v.depth) {
-        if (v.ch == 2 && v.depth == 2) S1_LAUNCH_NB(1024, 2, 2, 4);
-        else if (v.ch == 2) S1_LAUNCH_NB(1024, 2, 3, 4);
-        else S1_LAUNCH_NB(1024, 1, 3, 4);
+    if (v.depth) {
+        if (v.depth == 2) S1_LAUNCH_NB(1024, 2, 2, 4);
+        else S1_LAUNCH_NB(1024, 2, 3, 4);
     } else {
         if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
         else if (v.block == 768) S1_LAUNCH(stage1_kernel, 768, 2, 3);
