@@ -87,6 +87,20 @@ int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t string
 /* bytes.TrimSpace exactly as parseMessage applies it (parse_json_amd64.go:55); for hosts that are not Go */
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len);
 
+/* ---- queries on the device-resident result (no reference counterpart in the parser: they replace what callers do with
+ * Iter / Object.FindKey on the host, ndjson_test.go:421-471, parsed_object.go:97-138, README.md:226-269) ------------
+ * Both work on the result of the last successful sjhip_parse / sjhip_parse_device of `ctx` (still on the device).
+ * A record matches when its root value is an object whose FIRST member with key == `key` (top level only, like
+ * Object.FindKey) has a string value == `value` (compared after unescaping) -- the reference's countWhere.
+ *   count_where : number of matching records; 8 bytes cross PCIe.
+ *   filter_where: compacts the matching records into a new self-contained (Tape, Strings.B) on the device, identical
+ *                 to ParseND of the document made of the matching lines (root chain re-linked, container / string
+ *                 offsets rebased); sjhip_fetch_filtered copies it to the host.  Needs SJHIP_FLAG_COPY_STRINGS. */
+int sjhip_count_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen, uint64_t *count);
+int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen,
+                       uint64_t *n_records, size_t *tape_len, size_t *strings_len);
+int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
+
 /* ---- ParseNDStream: replaces the block pipeline of simdjson_amd64.go:101-216 --------------------------------------
  * The binding cuts the input into blocks that end at a record boundary (simdjson_amd64.go:155-176; tmpSize = 10 MiB)
  * and feeds them to a stream; every block is parsed as an independent NDJSON document with every string copied

@@ -24,6 +24,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
                        size_t *tape_len, size_t *strings_len) {
     ctx->tape_len = ctx->strings_len = 0;
     ctx->pending = 0;
+    ctx->q_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // structural density is 0.02..0.22 per byte on real documents; start with len/3 and retry once
@@ -124,6 +125,8 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     if (hs->err) return SJHIP_ERR_STAGE2;
     ctx->tape_len = (size_t)hs->tape_len;
     ctx->strings_len = (size_t)hs->strings_len;
+    ctx->q_records = hs->records;
+    ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
     if (tape_len) *tape_len = ctx->tape_len;
     if (strings_len) *strings_len = ctx->strings_len;
     return SJHIP_OK;

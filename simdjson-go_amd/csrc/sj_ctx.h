@@ -20,9 +20,13 @@ struct sjhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_aux;
+    sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;
+    int q_valid = 0;              // the device holds the whole result of an unsharded parse: queries are possible
+    uint32_t q_records = 0;       // record-separating newline runs of that parse (records - 1)
+    size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
     const void *p_msg = nullptr;

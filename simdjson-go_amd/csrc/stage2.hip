@@ -1144,6 +1144,13 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
     return p;
 }
 
+// nl_off (tape offsets of the record-separating root pairs) and the state of the last run in workspace `ws`: query.hip
+void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off, const S2State **st) {
+    const S2Dev p = stage2_view(nullptr, 0, nullptr, nullptr, n_tokens, 0, ws, nullptr, 0, nullptr, 0, nullptr);
+    *nl_off = p.nl_off;
+    *st = p.st;
+}
+
 // Phase 1: token kinds and the device-wide scan of the tile aggregates.  Afterwards S2State holds tape_len /
 // strings_len of this message (what an NDJSON shard exchanges with the other shards).
 hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,

@@ -126,6 +126,29 @@ class Context:
         self._check(rc)
         return tl.value, sl.value
 
+    # ---- queries on the device-resident result (include/sjhip.h: sjhip_count_where / sjhip_filter_where) --------
+    def count_where(self, key, value):
+        """countWhere(key, value, pj) of the reference's tests (ndjson_test.go:421-471) on the device: records whose
+        root object has `key` (first occurrence, top level) with the string value `value`."""
+        k, v = bytes(key), bytes(value)
+        n = C.c_uint64(0)
+        self._check(_lib.lib().sjhip_count_where(self._h, k, len(k), v, len(v), C.byref(n)))
+        return n.value
+
+    def filter_where(self, key, value, fetch=True):
+        """Compacts the matching records into a new (Tape, Strings.B) on the device -- what ParseND returns for the
+        document made of the matching lines -- and fetches it.  -> (n_records, ParsedJson or None)"""
+        k, v = bytes(key), bytes(value)
+        n, tl, sl = C.c_uint64(0), C.c_size_t(0), C.c_size_t(0)
+        L = _lib.lib()
+        self._check(L.sjhip_filter_where(self._h, k, len(k), v, len(v), C.byref(n), C.byref(tl), C.byref(sl)))
+        if not fetch:
+            return n.value, None
+        tape = np.empty(tl.value, dtype=np.uint64)
+        strings = np.empty(sl.value, dtype=np.uint8)
+        self._check(L.sjhip_fetch_filtered(self._h, tape.ctypes.data, strings.ctypes.data))
+        return n.value, ParsedJson(b"", tape, strings)
+
     def fetch(self, tape_len, strings_len):
         tape = np.empty(tape_len, dtype=np.uint64)
         strings = np.empty(strings_len, dtype=np.uint8)

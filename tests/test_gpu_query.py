@@ -1,0 +1,126 @@
+"""GPU: queries on the device-resident tape (sjhip_count_where / sjhip_filter_where) against
+a host evaluation of the reference's countWhere (ndjson_test.go:421-471: Object.FindKey on every record's root object,
+then a string compare) and against the oracle's ParseND of the matching lines."""
+import json
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import fixtures
+import golden_util as GU
+import oracle_lib as O
+from test_gpu_parse import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def host_matches(line, key, value):
+    """FindKey(key) on the root object (first occurrence, top level), value must be a string equal to `value`."""
+    try:
+        pairs = json.loads(line, object_pairs_hook=lambda p: p)
+    except ValueError:
+        return False
+    if not isinstance(pairs, list) or (pairs and not isinstance(pairs[0], tuple)):
+        return False  # the root is an array (or an empty object parsed as [])
+    for k, v in pairs:
+        if k == key:
+            return isinstance(v, str) and v == value
+    return False
+
+
+def check_query(ctx, doc, key, value, copy=True):
+    lines = [l for l in doc.split(b"\n") if l.strip()]
+    want = [l for l in lines if host_matches(l.decode("utf-8"), key.decode(), value.decode())]
+    ctx.parse(doc, ndjson=True, copy_strings=copy)
+    assert ctx.count_where(key, value) == len(want)
+    if not copy:
+        return
+    n, pj = ctx.filter_where(key, value)
+    assert n == len(want)
+    if not want:
+        assert len(pj.Tape) == 0 and len(pj.Strings) == 0
+        return
+    ref = O.parse(b"\n".join(want), ndjson=True, copy_strings=True)
+    assert ref.rc == 0
+    assert np.array_equal(pj.Tape, ref.tape), (key, value)
+    assert np.array_equal(pj.Strings, ref.strings), (key, value)
+
+
+def test_parking_citations_hond(ctx):  # ndjson_test.go:250-267: 116
+    park = fixtures.load("parking-citations")
+    ctx.parse(park, ndjson=True)
+    assert ctx.count_where(b"Make", b"HOND") == GU.load("stage2")["parking_citations_hond"] == 116
+    check_query(ctx, park, b"Make", b"HOND")
+    check_query(ctx, park, b"Make", b"HOND", copy=False)
+    check_query(ctx, park, b"Color", b"WH")
+    check_query(ctx, park, b"Make", b"NO SUCH MAKE")
+    check_query(ctx, park * 7, b"RP State Plate", b"CA")
+
+
+def test_record_shapes(ctx):
+    """first-occurrence semantics, nested keys that must not match, non-string values, array roots, escapes (the
+    comparison sees unescaped bytes), and numbers whose raw word looks like a tag (the copy classifies tag / raw words
+    by position parity)"""
+    def dbl(bits):
+        return repr(struct.unpack("<d", struct.pack("<Q", bits))[0])
+    tricky = [dbl((ord(c) << 56) | 0x000123456789ab) for c in '"lud{[}]rtfn']
+    recs = [
+        b'{"k":"v"}',
+        b'{"k":"x","k":"v"}',                       # first occurrence decides: no match
+        b'{"k":"v","k":"x"}',                       # match
+        b'{"a":{"k":"v"},"b":[{"k":"v"}]}',         # nested only: no match
+        b'{"a":{"k":"x"},"k":"v","z":[1,2,{"k":3}]}',
+        b'{"k":1}', b'{"k":null}', b'{"k":["v"]}', b'{"k":{"v":"v"}}',
+        b'[{"k":"v"}]', b'[]', b'{}', b'[1,2,3]',
+        b'{"k":"\\u0076"}',                          # "v" through an escape
+        b'{"\\u006b":"v"}',                          # "k" through an escape
+        b'{"kk":"v","k":"vv","k ":"v"}',
+        ('{"n":[' + ",".join(tricky) + '],"k":"v","m":' + tricky[0] + "}").encode(),
+        ('{"big":-9223372036854775808,"u":18446744073709551615,"k":"v","d":' + tricky[1] + "}").encode(),
+        b'{"s":"' + b"x" * 300 + b'","k":"v"}',
+        b'{"k":"v","t":true,"f":false,"n":null}',
+    ]
+    rnd = random.Random(3)
+    for trial in range(6):
+        rnd.shuffle(recs)
+        doc = b"\n".join(recs * (1 + trial * 40)) + (b"\n" if trial & 1 else b"")
+        check_query(ctx, doc, b"k", b"v")
+        check_query(ctx, doc, b"k", b"vv")
+        check_query(ctx, doc, b"s", b"x" * 300 if trial & 1 else b"x" * 299)
+    # one record without a newline, and a plain (non-ND) document: one record
+    check_query(ctx, b'{"k":"v"}', b"k", b"v")
+    ctx.parse(b'{"k":"v","z":[1,2]}', ndjson=False)
+    assert ctx.count_where(b"k", b"v") == 1 and ctx.count_where(b"z", b"v") == 0
+
+
+def test_random_records(ctx):
+    from test_gpu_parse import _random_records
+    rnd, lines = _random_records(77, 3 << 20)
+    keys = [b"k0", b"k1", b"k2", b"k4", b"zz"]
+    doc = "\n".join(lines).encode("utf-8")
+    for key in keys:
+        vals = set()
+        for l in lines[:400]:
+            try:
+                v = json.loads(l)
+            except ValueError:
+                continue
+            if isinstance(v, dict) and isinstance(v.get(key.decode()), str):
+                try:
+                    v[key.decode()].encode("utf-8")
+                except UnicodeEncodeError:
+                    continue  # a lone surrogate (quirk Q2 bytes): not expressible as a query value here
+                vals.add(v[key.decode()])
+        for value in list(vals)[:3] + ["nope"]:
+            check_query(ctx, doc, key, value.encode("utf-8"))
+
+
+def test_full_size_count(ctx):  # 116 per file -> 116 000 on configs[4]
+    import workloads
+    nd = workloads.c5_parking_nd(1000)
+    ctx.parse(nd, ndjson=True)
+    assert ctx.count_where(b"Make", b"HOND") == 116_000
+    n, pj = ctx.filter_where(b"Make", b"HOND", fetch=False)
+    assert n == 116_000

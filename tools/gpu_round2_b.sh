@@ -1,10 +1,8 @@
 #!/bin/bash
-# round-2 GPU batch B: stage-1 variants with the claimed serial duty + timelines, parity tests under variants 3 / 4
+# round-2 GPU batch: query + stream tests and benches, whole GPU suite
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."
-(timeout 900 python tools/s1_experiment.py > gpurun_out/s1_experiment.log 2>&1; echo "exit $?" >> gpurun_out/s1_experiment.log)
-for v in 6; do
-(SJHIP_S1_VARIANT=$v timeout 900 python -m pytest tests/test_gpu_stage1.py tests/test_gpu_parse.py tests/test_gpu_quirks.py -m gpu -x -q > gpurun_out/pytest_v$v.log 2>&1; echo "exit $?" >> gpurun_out/pytest_v$v.log)
-done
+(timeout 600 python -m pytest tests/test_gpu_query.py tests/test_gpu_parse.py -m gpu -x -q -k "query or stream or hond or record or full_size_count" > gpurun_out/pytest_query.log 2>&1; echo "exit $?" >> gpurun_out/pytest_query.log)
 (timeout 600 python tools/stream_bench.py > gpurun_out/stream_bench.log 2>&1; echo "exit $?" >> gpurun_out/stream_bench.log)
-for f in gpurun_out/stream_bench.log gpurun_out/s1_experiment.log gpurun_out/pytest_v6.log; do echo "== $f"; tail -n 6 $f | cut -c1-600; done
+(timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/pytest_gpu_r2c.log 2>&1; echo "exit $?" >> gpurun_out/pytest_gpu_r2c.log)
+for f in gpurun_out/pytest_query.log gpurun_out/stream_bench.log gpurun_out/pytest_gpu_r2c.log; do echo "== $f"; tail -n 14 $f | cut -c1-700; done
