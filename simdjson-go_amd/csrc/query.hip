@@ -31,7 +31,7 @@ namespace {
 
 static constexpr u64 PAYLOAD = 0x00ffffffffffffffull;  // JSONVALUEMASK, parsed_json.go:27
 static constexpr u32 NONE32 = 0xffffffffu;
-static constexpr int QMAX = 256;  // longest key / value a query may name
+static constexpr int QMAX = 1024;  // longest key / value a query may name (they travel as kernel arguments)
 
 struct QView {
     const u64 *tape;
@@ -243,7 +243,11 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off, con
 
 static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q,
                      uint32_t *records) {
-    if (!ctx || !key || !val || klen > QMAX || vlen > QMAX) return SJHIP_ERR_ARG;
+    if (!ctx || !key || !val) return SJHIP_ERR_ARG;
+    if (klen > QMAX || vlen > QMAX) {
+        ctx_set_error(ctx, "query key / value longer than %d bytes", QMAX);
+        return SJHIP_ERR_ARG;
+    }
     if (!ctx->q_valid || ctx->tape_len == 0) {
         ctx_set_error(ctx, "no parse result on the device (queries follow a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;

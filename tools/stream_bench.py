@@ -18,7 +18,26 @@ import workloads  # noqa: E402
 from sjhip import _lib  # noqa: E402
 
 
-def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
+_POOL = None
+
+
+def pmemmove(dst, src, n, threads):
+    """memmove split over `threads` host threads (ctypes releases the GIL): one thread moves ~10 GB/s, the PCIe link
+    five times that -- a reader that fills the pinned block is the bottleneck of the pipeline unless it is parallel."""
+    global _POOL
+    if threads <= 1 or n < (1 << 20):
+        C.memmove(dst, src, n)
+        return
+    if _POOL is None:
+        import concurrent.futures
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=16)
+    part = (n + threads - 1) // threads
+    futs = [_POOL.submit(C.memmove, dst + o, src + o, min(part, n - o)) for o in range(0, n, part)]
+    for f in futs:
+        f.result()
+
+
+def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True, copy_threads=1, fill=True):
     L = sjhip.lib()
     n = len(data)
     src = np.frombuffer(data, dtype=np.uint8)
@@ -29,6 +48,9 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
     out_s = np.empty(cap, dtype=np.uint8)
     res = _lib.StreamResult()
     off = 0
+    blocks_sent = 0
+    nslots = L.sjhip_stream_slots(h)
+    held = {}
     tape_words = strings = blocks = 0
     t0 = time.perf_counter()
 
@@ -39,8 +61,8 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
             return False
         assert rc == 0, (rc, L.sjhip_stream_last_error(h))
         if copy_out:
-            C.memmove(out_t.ctypes.data, res.tape, res.tape_len * 8)
-            C.memmove(out_s.ctypes.data, res.strings, res.strings_len)
+            pmemmove(out_t.ctypes.data, res.tape, res.tape_len * 8, copy_threads)
+            pmemmove(out_s.ctypes.data, res.strings, res.strings_len, copy_threads)
         tape_words += res.tape_len
         strings += res.strings_len
         blocks += 1
@@ -55,10 +77,14 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
             continue
         assert rc == 0
         end = min(n, off + block)
-        if end < n:
+        if end < n and data[end - 1:end] != b"\n":
             nl = data.find(b"\n", end)
             end = n if nl < 0 else nl + 1
-        C.memmove(ptr.value, src.ctypes.data + off, end - off)
+        slot = blocks_sent % nslots
+        if fill or held.get(slot) != end - off:  # fill=False: identical blocks are filled once (ceiling of the pipeline)
+            pmemmove(ptr.value, src.ctypes.data + off, end - off, copy_threads)
+            held[slot] = end - off
+        blocks_sent += 1
         assert L.sjhip_stream_submit(h, end - off) == 0
         off = end
     while take():
@@ -67,7 +93,8 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True):
     L.sjhip_stream_destroy(h)
     return {"bytes": n, "blocks": blocks, "seconds": round(dt, 4), "GBps": round(n / dt / 1e9, 2),
             "tape_words": tape_words, "strings_bytes": strings, "slots": slots, "devices": n_devices,
-            "copy_out": copy_out, "output_bytes_per_input_byte": round((tape_words * 8 + strings) / n, 3)}
+            "copy_out": copy_out, "copy_threads": copy_threads, "fill": fill,
+            "output_bytes_per_input_byte": round((tape_words * 8 + strings) / n, 3)}
 
 
 if __name__ == "__main__":
@@ -75,7 +102,9 @@ if __name__ == "__main__":
     data = workloads.c5_parking_nd(copies)
     run(data[: data.rfind(b"\n", 0, 64 << 20) + 1])  # warm-up: arenas, pinned result buffers
     out = []
-    for slots in (3, 6):
-        for copy_out in (True, False):
-            out.append(run(data, slots=slots, copy_out=copy_out))
+    for slots, copy_out, threads, fill in ((3, True, 1, True), (3, True, 4, True), (3, True, 8, True), (4, True, 8, True),
+                                           (3, False, 8, True), (3, False, 1, False), (4, False, 1, False), (6, False, 1, False)):
+        blk = (10 << 20) if fill else 28 * (len(data) // copies)  # fill=False: every block the same 28 files
+        out.append(run(data, block=blk, slots=slots, copy_out=copy_out, copy_threads=threads, fill=fill))
+        print(json.dumps(out[-1]), flush=True)
     print(json.dumps({"stream": out}))
