@@ -218,6 +218,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                 run += (u32)popc64(v_em[c]);
             }
             v_ucnt[u] = (u32)masks_total;
+            for (size_t c = u * 64; c < u * 64 + 64; c++) v_rec[c].abs = (u32)masks_total + v_pre[c];  // k_str_emit
             masks_total += run;
         }
     }
@@ -287,6 +288,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             const u64 a0 = (u64)pos[i] + 1, a1 = i + 1 < n ? pos[i + 1] : len;
             const u64 so = emitted_before(v_ucnt.data(), v_rec.data(), a0);
             const u64 se = emitted_before(v_ucnt.data(), v_rec.data(), a1);
+            if (so != emitted_before_abs(v_rec.data(), a0) || se != emitted_before_abs(v_rec.data(), a1)) return 95;
             tape[toff[i]] = string_word(true, strings_base + so, 0);
             tape[toff[i] + 1] = se - so;
         } else if (k == K_STRING && !strbad[i]) {

@@ -279,6 +279,7 @@ SJ_HD int parse_number(const u8 *buf, u32 avail, u64 *tag, u64 *val, u32 *numlen
         }
         bool syntax = i >= pos, range = false;
         u64 v = 0;
+        u32 nd = 0;  // nineteen digits always fit 64 bits: only the twentieth needs the overflow test (a 64-bit division)
         for (; i < pos; i++) {
             const u8 c = buf[i];
             if (c < '0' || c > '9') {
@@ -286,8 +287,10 @@ SJ_HD int parse_number(const u8 *buf, u32 avail, u64 *tag, u64 *val, u32 *numlen
                 break;
             }
             const u64 dgt = (u64)(c - '0');
-            if (v > (0xffffffffffffffffull - dgt) / 10) range = true;
+            if (nd < 19) v = v * 10 + dgt;
+            else if (range || v > (0xffffffffffffffffull - dgt) / 10) range = true;
             else v = v * 10 + dgt;
+            nd++;
         }
         if (!syntax) {
             if (!range && ((!neg && v <= 0x7fffffffffffffffull) || (neg && v <= 0x8000000000000000ull))) {

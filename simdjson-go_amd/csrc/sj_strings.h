@@ -153,10 +153,12 @@ SJ_HD UEscape unicode_escape(const StrView &m, u64 au) {
 //   em   emit mask
 //   pre  bits 0-14 the emitted bytes of the unit in front of the chunk, bit 15 "the chunk needs patching in
 //        pass 2" (it holds an escape, or a unicode escape of the previous chunk reaches into it)
+//   abs  the absolute Strings.B offset of the chunk's first emitted byte (unit prefix + pre), filled in by
+//        k_str_emit once the unit scan has run
 struct alignas(16) ChunkRec {
     u64 em;
     u32 pre;
-    u32 pad;
+    u32 abs;
 };
 static constexpr u32 CHUNK_PRE_MASK = 0x7fffu, CHUNK_SLOW = 0x8000u;
 SJ_HD bool str_chunk_has_escapes(const StrView &m, u64 c) {
@@ -263,6 +265,14 @@ SJ_HD u64 emitted_before(const u32 *unit_base, const ChunkRec *rec, u64 a) {
     const u32 bit = (u32)(a & 63);
     const u64 below = bit ? (r.em & (~0ull >> (64 - bit))) : 0ull;
     return (u64)unit_base[a >> 12] + (r.pre & CHUNK_PRE_MASK) + (u64)popc64(below);
+}
+
+// the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)
+SJ_HD u64 emitted_before_abs(const ChunkRec *rec, u64 a) {
+    const ChunkRec r = rec[a >> 6];
+    const u32 bit = (u32)(a & 63);
+    const u64 below = bit ? (r.em & (~0ull >> (64 - bit))) : 0ull;
+    return (u64)r.abs + (u64)popc64(below);
 }
 
 }  // namespace sj

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
         if (lane >= s) incl += o;
     }
     // (the 'u' mask is only an intermediate: pass 2 re-derives the escapes of flagged chunks)
-    p.rec[c] = ChunkRec{em, (incl - n) | (escapes ? CHUNK_SLOW : 0u), 0u};
+    p.rec[c] = ChunkRec{em, (incl - n) | (escapes ? CHUNK_SLOW : 0u), 0u};  // .abs: k_str_emit
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
@@ -350,8 +350,11 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const bool patched = (pre_raw & CHUNK_SLOW) != 0;
     const u32 n = (u32)popc64(em);
     const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
+    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
+    // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
+    // two record loads instead of two records + two unit prefixes
+    p.rec[c].abs = (u32)g + pre;
     if (total == 0) return;  // wave-uniform
-    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit (needed at the very end)
     u8 *out = &s_io[wave][pre];
     u32 head = 0;
     u8 *in8 = &s_io[wave][0];
@@ -737,27 +740,25 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
 #pragma unroll
     for (int h = 0; h < S2_ITEMS; h += 4) {
         u64 aw[4];           // atoms: the 8 message bytes at the token
-        u32 uc0[4], cp0[4];  // strings (masks): the three words of E(a0) and of E(a1)
+        u32 cp0[4];          // strings (masks): the two words of E(a0) and of E(a1)
         u64 em0[4];
-        u32 uc1[4], cp1[4];
+        u32 cp1[4];
         u64 em1[4];
         u32 nxt[4];          // position of the next token
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = h + j;
             aw[j] = 0;
-            uc0[j] = cp0[j] = uc1[j] = cp1[j] = 0;
+            cp0[j] = cp1[j] = 0;
             em0[j] = em1[j] = 0;
             nxt[j] = k + 1 < S2_ITEMS ? pp[k + 1] : s_pos[tid * S2_ITEMS + S2_ITEMS];
             if (is_atom[k]) aw[j] = load8_guarded(mv, pp[k]);
             if (MASKS && is_str[k]) {
                 const u64 a0 = (u64)pp[k] + p.sv.lead + 1, a1 = (u64)nxt[j] + p.sv.lead;
                 const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
-                uc0[j] = p.unit_cnt[a0 >> 12];
-                cp0[j] = r0.pre & CHUNK_PRE_MASK;
+                cp0[j] = r0.abs;  // absolute Strings.B offset of the chunk (k_str_emit)
                 em0[j] = r0.em;
-                uc1[j] = p.unit_cnt[a1 >> 12];
-                cp1[j] = r1.pre & CHUNK_PRE_MASK;
+                cp1[j] = r1.abs;
                 em1[j] = r1.em;
             }
         }
@@ -772,8 +773,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             if (MASKS) {
                 const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
                 const u32 b1 = (u32)(((u64)nxt[j] + p.sv.lead) & 63u);
-                const u64 so = (u64)uc0[j] + cp0[j] + (u64)popc64(em0[j] & ~(~0ull << b0));
-                const u64 se = (u64)uc1[j] + cp1[j] + (u64)popc64(em1[j] & ~(~0ull << b1));
+                const u64 so = (u64)cp0[j] + (u64)popc64(em0[j] & ~(~0ull << b0));
+                const u64 se = (u64)cp1[j] + (u64)popc64(em1[j] & ~(~0ull << b1));
                 if (is_str[k]) w0 = string_word(true, p.strings_base + so, 0);
                 w1 = se - so;
                 two = is_str[k];
@@ -1180,6 +1181,8 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, c
     p.msg_base = msg_base;
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
+    // the string bytes first: k_str_emit also leaves every chunk's absolute Strings.B offset for k_s2_emit
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
     hipLaunchKernelGGL(k_numbers, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
@@ -1192,7 +1195,6 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, c
     hipLaunchKernelGGL(k_br_check, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_roots, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
