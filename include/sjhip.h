@@ -101,6 +101,17 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
                        uint64_t *n_records, size_t *tape_len, size_t *strings_len);
 int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 
+/* ---- Serializer.Serialize on the device (parsed_serialize.go:200-431, format version 3) -----------------------------
+ * Splits the device-resident tape of the last parse (SJHIP_FLAG_COPY_STRINGS) into the reference's three columns --
+ * tags (one byte per tape entry), values (8 / 16 bytes per value-bearing entry), strings (= Strings.B, the reference's
+ * string buffer without de-duplication hits) -- and frames them as a CompressNone stream (every block type 0), which
+ * the reference's Deserialize reads; S2 / zstd compression of the columns (CompressFast / Default / Best) is host work.
+ *   serialize        : builds the columns on the device; sizes of the columns and of the framed stream
+ *   fetch_serialized : writes the framed stream into `dst` (>= stream_len bytes): header varints from the host, the
+ *                      three columns straight from the device */
+int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t *strings_len, size_t *stream_len);
+int sjhip_fetch_serialized(sjhip_ctx *ctx, uint8_t *dst, size_t cap, size_t *len);
+
 /* ---- ParseNDStream: replaces the block pipeline of simdjson_amd64.go:101-216 --------------------------------------
  * The binding cuts the input into blocks that end at a record boundary (simdjson_amd64.go:155-176; tmpSize = 10 MiB)
  * and feeds them to a stream; every block is parsed as an independent NDJSON document with every string copied

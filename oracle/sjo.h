@@ -112,6 +112,13 @@ double sjo_bench_parse(const uint8_t *msg, size_t len, uint32_t flags, int threa
                        size_t *tape_len_out);
 double sjo_bench_nd_blocks(const uint8_t *msg, size_t len, int threads, size_t block_bytes, int iters, int *failed_out);
 
+/* ---- sjo_serialize.c: Serializer.Serialize / Deserialize, format v3, CompressNone (parsed_serialize.go) ---- */
+int sjo_serialize(const uint64_t *tape, size_t tape_len, const uint8_t *strings, size_t strings_len, const uint8_t *msg,
+                  size_t msg_len, int dedup, uint8_t **out, size_t *out_len, uint8_t **tags_out, size_t *tags_len,
+                  uint8_t **values_out, size_t *values_len, uint8_t **sbuf_out, size_t *sbuf_len);
+int sjo_deserialize(const uint8_t *src, size_t src_len, uint64_t **tape_out, size_t *tape_len, uint8_t **strings_out,
+                    size_t *strings_len, uint8_t **message_out, size_t *message_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,8 @@ struct sjhip_ctx {
     int q_valid = 0;              // the device holds the whole result of an unsharded parse: queries are possible
     uint32_t q_records = 0;       // record-separating newline runs of that parse (records - 1)
     size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
+    int ser_valid = 0;            // last sjhip_serialize (serialize.hip): column sizes, framed stream size
+    size_t ser_tags = 0, ser_vals = 0, ser_rest = 0, ser_stream = 0;
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
     const void *p_msg = nullptr;

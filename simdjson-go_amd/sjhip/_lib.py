@@ -41,6 +41,8 @@ SYMBOLS = {
     "sjhip_count_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p]),
     "sjhip_filter_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p, szp, szp]),
     "sjhip_fetch_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sjhip_serialize": (C.c_int, [C.c_void_p, szp, szp, szp, szp]),
+    "sjhip_fetch_serialized": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, szp]),
     "sjhip_stream_create": (C.c_void_p, [C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint32]),
     "sjhip_stream_destroy": (None, [C.c_void_p]),
     "sjhip_stream_block_capacity": (C.c_size_t, [C.c_void_p]),

@@ -149,6 +149,19 @@ class Context:
         self._check(L.sjhip_fetch_filtered(self._h, tape.ctypes.data, strings.ctypes.data))
         return n.value, ParsedJson(b"", tape, strings)
 
+    def serialize(self, fetch=True):
+        """Serializer.Serialize (format v3, CompressNone) of the device-resident result of the last parse.
+        -> the framed stream as a uint8 array (what the reference's Deserialize reads), or its sizes with fetch=False."""
+        L = _lib.lib()
+        tl, vl, sl, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(L.sjhip_serialize(self._h, C.byref(tl), C.byref(vl), C.byref(sl), C.byref(n)))
+        if not fetch:
+            return {"tags": tl.value, "values": vl.value, "strings": sl.value, "stream": n.value}
+        out = np.empty(n.value, dtype=np.uint8)
+        got = C.c_size_t(0)
+        self._check(L.sjhip_fetch_serialized(self._h, out.ctypes.data, out.size, C.byref(got)))
+        return out[: got.value]
+
     def fetch(self, tape_len, strings_len):
         tape = np.empty(tape_len, dtype=np.uint64)
         strings = np.empty(strings_len, dtype=np.uint8)

@@ -82,6 +82,13 @@ def lib():
         L.sjo_bench_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), szp]
         L.sjo_bench_nd_blocks.restype = C.c_double
         L.sjo_bench_nd_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+        # sjo_serialize.c
+        bpp = C.POINTER(u8p)
+        L.sjo_serialize.restype = C.c_int
+        L.sjo_serialize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                    bpp, szp, bpp, szp, bpp, szp, bpp, szp]
+        L.sjo_deserialize.restype = C.c_int
+        L.sjo_deserialize.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(u64p), szp, bpp, szp, bpp, szp]
         _LIB = L
     return _LIB
 
@@ -163,3 +170,35 @@ class FastParser:
         p.tape = np.ctypeslib.as_array(tape, shape=(tl.value,)).copy() if rc == 0 and tl.value else np.zeros(0, np.uint64)
         p.strings = np.ctypeslib.as_array(strs, shape=(sl.value,)).copy() if rc == 0 and sl.value else np.zeros(0, np.uint8)
         return p
+
+
+def _take(ptr, n, dtype=np.uint8):
+    a = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, dtype)
+    lib().sjo_free(ptr)
+    return a
+
+
+def serialize(tape, strings, message, dedup=True):
+    """Serializer.Serialize (format v3, CompressNone).  -> (stream bytes, tags, values, string buffer)"""
+    t = np.ascontiguousarray(tape, dtype=np.uint64)
+    s = np.ascontiguousarray(strings, dtype=np.uint8)
+    m = _as_np_u8(message)
+    outs = [u8p() for _ in range(4)]
+    lens = [C.c_size_t(0) for _ in range(4)]
+    rc = lib().sjo_serialize(t.ctypes.data, t.size, s.ctypes.data if s.size else None, s.size, m.ctypes.data if m.size else None,
+                             m.size, int(dedup), C.byref(outs[0]), C.byref(lens[0]), C.byref(outs[1]), C.byref(lens[1]),
+                             C.byref(outs[2]), C.byref(lens[2]), C.byref(outs[3]), C.byref(lens[3]))
+    assert rc == 0, rc
+    return tuple(_take(o, l.value) for o, l in zip(outs, lens))
+
+
+def deserialize(stream):
+    """Serializer.Deserialize.  -> (rc, tape, strings, message)"""
+    a = _as_np_u8(stream)
+    tape, strs, msg = u64p(), u8p(), u8p()
+    tl, sl, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    rc = lib().sjo_deserialize(a.ctypes.data, a.size, C.byref(tape), C.byref(tl), C.byref(strs), C.byref(sl), C.byref(msg),
+                               C.byref(ml))
+    if rc:
+        return rc, None, None, None
+    return 0, _take(tape, tl.value, np.uint64), _take(strs, sl.value), _take(msg, ml.value)
