@@ -112,6 +112,14 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
 int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t *strings_len, size_t *stream_len);
 int sjhip_fetch_serialized(sjhip_ctx *ctx, uint8_t *dst, size_t cap, size_t *len);
 
+/* ---- Iter.MarshalJSON on the device (parsed_json.go:401-556) ---------------------------------------------------------
+ * The device-resident result of the last parse as compact JSON text, records separated by '\n' -- byte for byte what
+ * pj.Iter().MarshalJSON() returns: escapeBytes for strings, strconv.AppendInt / AppendUint, appendFloat (the reference's
+ * copy of Go's Ryu shortest formatting with its ES6-style %f / %e choice).  The text stays on the device until
+ * sjhip_fetch_marshaled copies it into `dst` (>= text_len bytes). */
+int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len);
+int sjhip_fetch_marshaled(sjhip_ctx *ctx, uint8_t *dst);
+
 /* ---- ParseNDStream: replaces the block pipeline of simdjson_amd64.go:101-216 --------------------------------------
  * The binding cuts the input into blocks that end at a record boundary (simdjson_amd64.go:155-176; tmpSize = 10 MiB)
  * and feeds them to a stream; every block is parsed as an independent NDJSON document with every string copied

@@ -112,6 +112,11 @@ double sjo_bench_parse(const uint8_t *msg, size_t len, uint32_t flags, int threa
                        size_t *tape_len_out);
 double sjo_bench_nd_blocks(const uint8_t *msg, size_t len, int threads, size_t block_bytes, int iters, int *failed_out);
 
+/* ---- sjo_marshal.c: Iter.MarshalJSONBuffer on a whole ParsedJson (parsed_json.go:401-556) ---- */
+int sjo_format_float(uint64_t bits, char *out40);
+int sjo_marshal_json(const uint64_t *tape, size_t n, const uint8_t *strings, const uint8_t *msg, uint8_t **out,
+                     size_t *out_len);
+
 /* ---- sjo_serialize.c: Serializer.Serialize / Deserialize, format v3, CompressNone (parsed_serialize.go) ---- */
 int sjo_serialize(const uint64_t *tape, size_t tape_len, const uint8_t *strings, size_t strings_len, const uint8_t *msg,
                   size_t msg_len, int dedup, uint8_t **out, size_t *out_len, uint8_t **tags_out, size_t *tags_len,

@@ -137,6 +137,7 @@ extern "C" int sj_selftest_parse_number(const uint8_t *buf, size_t len, uint64_t
 
 #include "sj_host.h"
 #include "sj_stage2.h"
+#include "sj_ftoa.h"
 #include "sj_strings.h"
 
 extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
@@ -356,3 +357,9 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     return 0;
 }
 extern "C" void sj_selftest_free(void *p) { free(p); }
+
+// number formatting of the tape -> JSON text path (sj_ftoa.h): appendFloat / AppendInt / AppendUint
+extern "C" unsigned sj_selftest_format_float(uint64_t bits, uint8_t *out32) { return format_float(bits, out32); }
+extern "C" unsigned sj_selftest_format_int(uint64_t raw, int is_unsigned, uint8_t *out24) {
+    return is_unsigned ? format_uint(raw, out24) : format_int(raw, out24);
+}

@@ -26,6 +26,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->pending = 0;
     ctx->q_valid = 0;
     ctx->ser_valid = 0;
+    ctx->ms_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // structural density is 0.02..0.22 per byte on real documents; start with len/3 and retry once

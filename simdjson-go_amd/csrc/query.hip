@@ -303,6 +303,7 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->ser_valid = 0;  // the serializer's columns live in the same arenas
+    ctx->ms_valid = 0;
     const size_t per = ((size_t)n * 4 + 255) / 256 * 256;
     rc = arena_reserve(ctx, ctx->d_q, per * 5 + 256);
     if (rc) return rc;

@@ -23,6 +23,7 @@
 #include "sj_ctx.h"
 #include "sj_device.h"
 #include "sj_stage2.h"
+#include "sj_tapewalk.h"
 
 using namespace sj;
 
@@ -34,8 +35,8 @@ using namespace sj;
 
 namespace {
 
-static constexpr u64 PAYLOAD = 0x00ffffffffffffffull;
-static constexpr int ST_THREADS = 256, ST_ITEMS = 8, ST_TILE = ST_THREADS * ST_ITEMS;
+static constexpr u64 PAYLOAD = TW_PAYLOAD;
+static constexpr int ST_THREADS = TW_THREADS, ST_ITEMS = TW_ITEMS, ST_TILE = TW_TILE;
 
 struct SerView {
     const u64 *tape;
@@ -48,100 +49,6 @@ struct SerView {
     u8 *tags;
     u8 *vals;
 };
-
-__device__ __forceinline__ bool two_word_tag(u64 w) {
-    const u32 t = (u32)(w >> 56);
-    return t == '"' || t == 'l' || t == 'u' || t == 'd';
-}
-
-// block-wide exclusive scans over one value per thread (4 waves)
-__device__ __forceinline__ long long block_excl_max(long long v, long long *s_w, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    long long incl = v;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const long long o = __shfl_up(incl, s, 64);
-        if (lane >= s) incl = o > incl ? o : incl;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    long long before = -1;
-    for (int w = 0; w < wave; w++) before = s_w[w] > before ? s_w[w] : before;
-    long long ex = __shfl_up(incl, 1, 64);
-    if (lane == 0) ex = -1;
-    __syncthreads();
-    return ex > before ? ex : before;
-}
-__device__ __forceinline__ unsigned long long block_excl_sum(unsigned long long v, unsigned long long *s_w, int tid,
-                                                              unsigned long long *total) {
-    const int lane = tid & 63, wave = tid >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const unsigned long long o = (unsigned long long)__shfl_up((long long)incl, s, 64);
-        if (lane >= s) incl += o;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    unsigned long long before = 0, tot = 0;
-    for (int w = 0; w < ST_THREADS / 64; w++) {
-        if (w < wave) before += s_w[w];
-        tot += s_w[w];
-    }
-    if (total) *total = tot;
-    __syncthreads();
-    return before + incl - v;
-}
-
-__global__ __launch_bounds__(ST_THREADS) void k_ser_last(SerView p) {
-    __shared__ long long s_w[ST_THREADS / 64];
-    const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * ST_TILE + (u64)tid * ST_ITEMS;
-    long long last = -1;
-#pragma unroll
-    for (int k = 0; k < ST_ITEMS; k++)
-        if (base + k < p.n && !two_word_tag(p.tape[base + k])) last = (long long)(base + k);
-    // block maximum
-    const int lane = tid & 63;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const long long o = __shfl_xor(last, s, 64);
-        last = o > last ? o : last;
-    }
-    if (lane == 0) s_w[tid >> 6] = last;
-    __syncthreads();
-    if (tid == 0) {
-        long long m = s_w[0];
-        for (int w = 1; w < ST_THREADS / 64; w++) m = s_w[w] > m ? s_w[w] : m;
-        p.tile_last[blockIdx.x] = m;
-    }
-}
-
-// one block: tile_last[t] := the last anchor in front of tile t (exclusive running maximum)
-__global__ __launch_bounds__(1024) void k_ser_scan_last(SerView p) {
-    __shared__ long long s_m[1024];
-    const u32 tid = threadIdx.x, per = (p.tiles + 1023u) / 1024u;
-    const u32 lo = tid * per < p.tiles ? tid * per : p.tiles, hi = lo + per < p.tiles ? lo + per : p.tiles;
-    long long m = -1;
-    for (u32 t = lo; t < hi; t++) m = p.tile_last[t] > m ? p.tile_last[t] : m;
-    s_m[tid] = m;
-    __syncthreads();
-    if (tid == 0) {
-        long long run = -1;
-        for (int k = 0; k < 1024; k++) {
-            const long long v = s_m[k];
-            s_m[k] = run;
-            run = v > run ? v : run;
-        }
-    }
-    __syncthreads();
-    long long run = s_m[tid];
-    for (u32 t = lo; t < hi; t++) {
-        const long long v = p.tile_last[t];
-        p.tile_last[t] = run;
-        run = v > run ? v : run;
-    }
-}
 
 // one block: exclusive prefix sums of the two per-tile counts + totals
 __global__ __launch_bounds__(1024) void k_ser_scan_cnt(SerView p) {
@@ -276,6 +183,7 @@ size_t put_uvarint(uint8_t *dst, uint64_t v) {
 int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t *strings_len, size_t *stream_len) {
     if (!ctx) return SJHIP_ERR_ARG;
     ctx->ser_valid = 0;
+    ctx->ms_valid = 0;
     if (!ctx->q_valid || ctx->tape_len == 0) {
         ctx_set_error(ctx, "no parse result on the device (sjhip_serialize follows a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;
@@ -306,8 +214,8 @@ int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t
     p.cnt_v = (unsigned long long *)w;
     p.vals = (u8 *)ctx->d_qtape.p;
     p.tags = (u8 *)ctx->d_qstrings.p;
-    hipLaunchKernelGGL(k_ser_last, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_ser_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
+    hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
     hipLaunchKernelGGL(k_ser_tile<false>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
     hipLaunchKernelGGL(k_ser_scan_cnt, dim3(1), dim3(1024), 0, ctx->stream, p);
     hipLaunchKernelGGL(k_ser_tile<true>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);

@@ -29,6 +29,8 @@ struct sjhip_ctx {
     size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
     int ser_valid = 0;            // last sjhip_serialize (serialize.hip): column sizes, framed stream size
     size_t ser_tags = 0, ser_vals = 0, ser_rest = 0, ser_stream = 0;
+    int ms_valid = 0;             // last sjhip_marshal_json (marshal.hip): the text is in d_qtape
+    size_t ms_len = 0;
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
     const void *p_msg = nullptr;

@@ -43,6 +43,8 @@ SYMBOLS = {
     "sjhip_fetch_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sjhip_serialize": (C.c_int, [C.c_void_p, szp, szp, szp, szp]),
     "sjhip_fetch_serialized": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, szp]),
+    "sjhip_marshal_json": (C.c_int, [C.c_void_p, szp]),
+    "sjhip_fetch_marshaled": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sjhip_stream_create": (C.c_void_p, [C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint32]),
     "sjhip_stream_destroy": (None, [C.c_void_p]),
     "sjhip_stream_block_capacity": (C.c_size_t, [C.c_void_p]),

@@ -162,6 +162,18 @@ class Context:
         self._check(L.sjhip_fetch_serialized(self._h, out.ctypes.data, out.size, C.byref(got)))
         return out[: got.value]
 
+    def marshal_json(self, fetch=True):
+        """pj.Iter().MarshalJSON() of the device-resident result of the last parse: compact JSON text, records
+        separated by newlines.  -> bytes (or the length with fetch=False)"""
+        L = _lib.lib()
+        n = C.c_size_t(0)
+        self._check(L.sjhip_marshal_json(self._h, C.byref(n)))
+        if not fetch:
+            return n.value
+        out = np.empty(n.value, dtype=np.uint8)
+        self._check(L.sjhip_fetch_marshaled(self._h, out.ctypes.data))
+        return out.tobytes()
+
     def fetch(self, tape_len, strings_len):
         tape = np.empty(tape_len, dtype=np.uint64)
         strings = np.empty(strings_len, dtype=np.uint8)

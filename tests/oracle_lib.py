@@ -89,6 +89,11 @@ def lib():
                                     bpp, szp, bpp, szp, bpp, szp, bpp, szp]
         L.sjo_deserialize.restype = C.c_int
         L.sjo_deserialize.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(u64p), szp, bpp, szp, bpp, szp]
+        # sjo_marshal.c
+        L.sjo_format_float.restype = C.c_int
+        L.sjo_format_float.argtypes = [C.c_uint64, C.c_char_p]
+        L.sjo_marshal_json.restype = C.c_int
+        L.sjo_marshal_json.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, bpp, szp]
         _LIB = L
     return _LIB
 
@@ -202,3 +207,22 @@ def deserialize(stream):
     if rc:
         return rc, None, None, None
     return 0, _take(tape, tl.value, np.uint64), _take(strs, sl.value), _take(msg, ml.value)
+
+
+def marshal_json(tape, strings, message):
+    """Iter.MarshalJSON of the whole ParsedJson.  -> (rc, bytes)"""
+    t = np.ascontiguousarray(tape, dtype=np.uint64)
+    s = np.ascontiguousarray(strings, dtype=np.uint8)
+    m = _as_np_u8(message)
+    out, n = u8p(), C.c_size_t(0)
+    rc = lib().sjo_marshal_json(t.ctypes.data, t.size, s.ctypes.data if s.size else None, m.ctypes.data if m.size else None,
+                                C.byref(out), C.byref(n))
+    if rc:
+        return rc, b""
+    return 0, _take(out, n.value).tobytes()
+
+
+def format_float(bits):
+    buf = C.create_string_buffer(48)
+    n = lib().sjo_format_float(bits, buf)
+    return buf.raw[:n].decode()

@@ -1,0 +1,80 @@
+"""GPU: Iter.MarshalJSON on the device (sjhip_marshal_json) against the reference's expected
+texts (the `want` column of TestParsePassCases / TestParseND) and byte for byte against the oracle's MarshalJSON."""
+import random
+import struct
+
+import pytest
+
+import fixtures
+import golden_util as GU
+import oracle_lib as O
+from test_gpu_parse import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+CORP = GU.load("corpus")
+
+
+def check_marshal(ctx, doc, nd, what):
+    for copy in (True, False):
+        ref = O.parse(doc, ndjson=nd, copy_strings=copy)
+        assert ref.rc == 0, what
+        rc, want = O.marshal_json(ref.tape, ref.strings, doc[ref.msg_off:ref.msg_off + ref.msg_len])
+        assert rc == 0, what
+        ctx.parse(doc, ndjson=nd, copy_strings=copy)
+        got = ctx.marshal_json()
+        if got != want:
+            k = next(i for i in range(min(len(got), len(want)) + 1) if got[i:i + 1] != want[i:i + 1])
+            raise AssertionError((what, copy, len(got), len(want), k, got[max(0, k - 30):k + 30], want[max(0, k - 30):k + 30]))
+    return want
+
+
+def test_reference_expected_texts(ctx):  # simdjson_amd64_test.go:701-955, :33-86
+    for c in CORP["pass_cases"]:
+        if not c["want_err"]:
+            assert check_marshal(ctx, bytes.fromhex(c["js_hex"]), False, c["name"]) == bytes.fromhex(c["want_hex"])
+    for c in CORP["parse_nd"]:
+        if not c["want_err"]:
+            assert check_marshal(ctx, bytes.fromhex(c["js_hex"]), True, c["name"]) == bytes.fromhex(c["want_hex"])
+
+
+@pytest.mark.parametrize("name", fixtures.ALL)
+def test_fixtures(ctx, name):
+    check_marshal(ctx, fixtures.load(name), name == "parking-citations", name)
+
+
+def test_numbers_strings_and_shapes(ctx):
+    rnd = random.Random(9)
+    floats = []
+    for e in range(0, 2047, 3):  # across the binades, incl. their first and last values
+        for m in (0, rnd.getrandbits(52), (1 << 52) - 1):
+            x = struct.unpack("<d", struct.pack("<Q", (e << 52) | m))[0]
+            floats += [repr(x), repr(-x)]
+    floats += ["0.0", "-0.0", "1e-7", "1e-6", "1e21", "1e20", "123456789012345678901234567890", "5e-324", "1.7976931348623157e308",
+               "0.1", "100", "1E+2", "2.5e-8", "4.35", "1e22", "9007199254740993"]
+    ints = ["0", "-1", "9223372036854775807", "-9223372036854775808", "9223372036854775808", "18446744073709551615", "42"]
+    check_marshal(ctx, ("[" + ",".join(floats + ints) + "]").encode(), False, "numbers")
+    ctl = "".join("\\u%04x" % c for c in range(0x20)) + '\\"\\\\\\/\\b\\f\\n\\r\\t' + "é世\U0001f600 plain"
+    docs = [
+        '{"k":"' + ctl + '","' + ctl + '":[true,false,null,{},[],{"a":{"b":{"c":[1,[2,[3]]]}}}]}',
+        '[[],[[]],{},{"a":{}},[{"b":[]},{}],"",{"":""}]',
+        '{"a":"b","c":"d","e":["f","g",{"h":"i"}],"j":{"k":"l","m":["n"]}}',
+        '["' + "x" * 5000 + '","' + '\\n' * 3000 + '",' + ",".join('"s%d"' % i for i in range(3000)) + "]",
+    ]
+    for i, d in enumerate(docs):
+        check_marshal(ctx, d.encode("utf-8"), False, f"shape{i}")
+    nd = "\n".join('{"i":%d,"f":%s,"s":"%s","a":[%s]}' % (i, floats[i % len(floats)], "q\\n" * (i % 7), ",".join(ints[: i % 5]))
+                   for i in range(4000))
+    check_marshal(ctx, nd.encode(), True, "nd")
+    check_marshal(ctx, (nd + "\n\n").encode(), True, "nd-trailing-newlines")
+
+
+def test_random_documents(ctx):
+    from test_gpu_parse import _random_records
+    rnd, lines = _random_records(321, 2 << 20)
+    check_marshal(ctx, ("[" + ",".join(lines) + "]").encode("utf-8"), False, "random-array")
+    check_marshal(ctx, "\n".join(lines).encode("utf-8"), True, "random-nd")
+
+
+def test_full_size_c5(ctx):
+    import workloads
+    check_marshal(ctx, workloads.c5_parking_nd(200), True, "parking x200")
