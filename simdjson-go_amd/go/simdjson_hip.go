@@ -32,6 +32,7 @@ import (
 	"io"
 	"runtime"
 	"sync"
+	"sync/atomic"
 	"unsafe"
 )
 
@@ -47,8 +48,17 @@ type hipCtx struct {
 	h *C.sjhip_ctx
 }
 
+// New contexts are created round robin over the visible devices: concurrent Parse calls (and the blocks of a
+// stream) spread over every GPU of the node.
+var nextDevice uint32
+
 var ctxPool = sync.Pool{New: func() interface{} {
-	h := C.sjhip_ctx_create(0)
+	n := int(C.sjhip_device_count())
+	if n < 1 {
+		return (*hipCtx)(nil)
+	}
+	dev := int(atomic.AddUint32(&nextDevice, 1)-1) % n
+	h := C.sjhip_ctx_create(C.int(dev))
 	if h == nil {
 		return (*hipCtx)(nil)
 	}
@@ -173,11 +183,12 @@ type Stream struct {
 	Error error
 }
 
-// ParseNDStream keeps the contract of simdjson_amd64.go:116-216: the input is cut into blocks of
-// about 10 MiB that end on a record boundary, every block is parsed as an independent ND
-// document, results arrive on res in input order, and the first error (io.EOF at the end of the
-// input) is the last value sent before res is closed.  Blocks are independent, so with several
-// GPUs the context pool can hand out contexts living on different devices.
+// ParseNDStream keeps the contract of simdjson_amd64.go:116-216: the input is cut into blocks of about 10 MiB that
+// end on a record boundary, every block is parsed as an independent ND document with every string copied, results
+// arrive on res in input order, and the first error (io.EOF at the end of the input) is the last value sent before
+// res is closed.  The pipeline itself lives in the library (sjhip_stream_*, csrc/stream_api.hip): the reader fills
+// pinned blocks directly, every block in flight has its own context and HIP stream on one of the node's GPUs (round
+// robin), and results are copied out of pinned memory into the (recycled) ParsedJson.
 func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 	if !SupportedCPU() {
 		go func() {
@@ -186,71 +197,122 @@ func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 		}()
 		return
 	}
-	const blockSize = 10 << 20
-	inFlight := (runtime.GOMAXPROCS(0) + 1) / 2
-	if inFlight < 1 {
-		inFlight = 1
+	const blockSize = 10 << 20 // tmpSize, simdjson_amd64.go:127
+	const reserve = blockSize/8 + 64<<10
+	st := C.sjhip_stream_create(0, 0, C.size_t(blockSize+reserve), 0, 0)
+	if st == nil {
+		go func() {
+			res <- Stream{Error: errors.New("Host CPU does not meet target specs")}
+			close(res)
+		}()
+		return
 	}
-	// ordered: one single-slot mailbox per block, consumed in submission order
-	ordered := make(chan chan Stream, inFlight)
-
-	go func() { // deliverer
+	go func() {
 		defer close(res)
-		failed := false
-		for box := range ordered {
-			out := <-box
-			if !failed {
-				res <- out
-			}
-			if out.Error != nil {
-				failed = true
-			}
-		}
-	}()
-
-	go func() { // block cutter + dispatcher
-		defer close(ordered)
+		defer C.sjhip_stream_destroy(st)
 		rd := bufio.NewReaderSize(r, blockSize)
-		submit := func(s Stream) {
-			box := make(chan Stream, 1)
-			box <- s
-			ordered <- box
+
+		// deliver takes the oldest outstanding result; false once the stream has ended with an error
+		deliver := func() bool {
+			var out C.sjhip_stream_result
+			rc := C.sjhip_stream_next(st, &out)
+			switch rc {
+			case C.SJHIP_OK:
+			case C.SJHIP_STREAM_EMPTY:
+				return true
+			case C.SJHIP_ERR_STAGE1:
+				res <- Stream{Error: fmt.Errorf("parsing input: %w", errors.New("Failed to find all structural indices for stage 1"))}
+				return false
+			case C.SJHIP_ERR_STAGE2:
+				res <- Stream{Error: fmt.Errorf("parsing input: %w", errors.New("Bad parsing while executing stage 2"))}
+				return false
+			default:
+				res <- Stream{Error: fmt.Errorf("parsing input: sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
+				return false
+			}
+			var pj ParsedJson
+			select { // `select { case v := <-reuse: ... default: }`, simdjson_amd64.go:181-190
+			case old := <-reuse:
+				if old != nil {
+					pj = *old
+				}
+			default:
+			}
+			tl, sl, ml := int(out.tape_len), int(out.strings_len), int(out.message_len)
+			if cap(pj.Tape) < tl {
+				pj.Tape = make([]uint64, tl)
+			}
+			pj.Tape = pj.Tape[:tl]
+			if pj.Strings == nil {
+				pj.Strings = &TStrings{}
+			}
+			if cap(pj.Strings.B) < sl {
+				pj.Strings.B = make([]byte, sl)
+			}
+			pj.Strings.B = pj.Strings.B[:sl]
+			if cap(pj.Message) < ml {
+				pj.Message = make([]byte, ml)
+			}
+			pj.Message = pj.Message[:ml]
+			if tl > 0 {
+				copy(pj.Tape, unsafe.Slice((*uint64)(unsafe.Pointer(out.tape)), tl))
+			}
+			if sl > 0 {
+				copy(pj.Strings.B, unsafe.Slice((*byte)(unsafe.Pointer(out.strings)), sl))
+			}
+			if ml > 0 {
+				copy(pj.Message, unsafe.Slice((*byte)(unsafe.Pointer(out.message)), ml))
+			}
+			C.sjhip_stream_release(st)
+			res <- Stream{Value: &pj}
+			return true
 		}
+
 		for {
-			block := make([]byte, blockSize, blockSize+4096)
-			n, rerr := io.ReadFull(rd, block)
-			block = block[:n]
-			if rerr == nil { // a full block: extend it to the end of the current record
+			var blk *C.uint8_t
+			var capacity C.size_t
+			rc := C.sjhip_stream_acquire(st, &blk, &capacity)
+			if rc == C.SJHIP_STREAM_FULL { // every slot holds a block: deliver the oldest one first
+				if !deliver() {
+					return
+				}
+				continue
+			}
+			if rc != C.SJHIP_OK {
+				res <- Stream{Error: fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
+				return
+			}
+			buf := unsafe.Slice((*byte)(unsafe.Pointer(blk)), int(capacity))
+			n, rerr := io.ReadFull(rd, buf[:blockSize]) // straight into pinned memory (tmpPool's role)
+			if rerr == nil {                            // a full block: extend it to the end of the current record
 				rest, lerr := rd.ReadBytes('\n')
-				block = append(block, rest...)
+				if n+len(rest) > int(capacity) { // a record longer than the reserve: a larger pinned block
+					if C.sjhip_stream_grow(st, C.size_t(n), C.size_t(n+len(rest)), &blk) != C.SJHIP_OK {
+						res <- Stream{Error: fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
+						return
+					}
+					buf = unsafe.Slice((*byte)(unsafe.Pointer(blk)), n+len(rest))
+				}
+				copy(buf[n:], rest)
+				n += len(rest)
 				if lerr != nil {
 					rerr = lerr
 				}
 			} else if rerr == io.ErrUnexpectedEOF {
 				rerr = io.EOF
 			}
-			if len(block) > 0 {
-				box := make(chan Stream, 1)
-				ordered <- box
-				go func(data []byte) {
-					pj := internalParsedJson{copyStrings: true}
-					select {
-					case old := <-reuse:
-						if old != nil {
-							pj.ParsedJson = *old
-						}
-					default:
-					}
-					if err := pj.parseMessage(data, true); err != nil {
-						box <- Stream{Error: fmt.Errorf("parsing input: %w", err)}
-						return
-					}
-					done := pj.ParsedJson
-					box <- Stream{Value: &done}
-				}(block)
+			if n > 0 { // `if len(tmp) > 0`, :178
+				C.sjhip_stream_submit(st, C.size_t(n))
+			} else {
+				C.sjhip_stream_cancel(st)
 			}
 			if rerr != nil {
-				submit(Stream{Error: rerr}) // io.EOF on a clean end
+				for C.sjhip_stream_in_flight(st) > 0 { // drain in order; the first error ends the stream
+					if !deliver() {
+						return
+					}
+				}
+				res <- Stream{Error: rerr} // io.EOF on a clean end
 				return
 			}
 		}
