@@ -29,8 +29,10 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->ms_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    // structural density is 0.02..0.22 per byte on real documents; start with len/3 and retry once
-    size_t pos_cap = len / 3 + 4096;
+    // One position (4 B) and one kind (1 B) per message byte is the worst case (every byte a structural): 5 bytes per
+    // input byte of a grow-only, recycled arena -- 1.3 GB for configs[1] on a 288 GB device -- instead of guessing a
+    // density and running stage 1 a second time on documents denser than the guess ("[[[[..." / "[1,1,1,...").
+    const size_t pos_cap = (len + 63) / 64 * 64 + 64;
     size_t n = 0;
     int ok = 0;
     // every string copied (the reference's default): stage 1 leaves its string masks for the byte-parallel unescape
@@ -40,8 +42,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         if (rc) return rc;
         aux = ctx->d_aux.p;
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
-        pos_cap = (pos_cap + 63) / 64 * 64;
+    {
         // positions, then the token kinds stage 1 writes next to them (1 byte each, 256-byte aligned)
         int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * (sizeof(uint32_t) + 1));
         if (rc) return rc;
@@ -49,8 +50,6 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
                                have_last, &n, &ok, aux, ctx->p_kind);
         if (rc) return rc;
-        if (n <= pos_cap) break;
-        pos_cap = n;
     }
     if (!ok) return SJHIP_ERR_STAGE1;
     int rc = arena_reserve(ctx, ctx->d_s2, stage2_workspace_bytes(n));

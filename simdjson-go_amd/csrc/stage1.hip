@@ -48,6 +48,23 @@ __device__ __forceinline__ void trace_put(u64 *trace, u32 tile, int waves, int w
 }
 __constant__ KindLut c_s1_klut = make_kind_lut();
 
+// ---- tiles ---------------------------------------------------------------------------------
+// A tile is UNITS = WAVES * CH wave units of 4 KiB.  A document rarely is a whole number of rounds of (blocks x tiles):
+// configs[1] is 2053 tiles for 256 blocks, 8.02 rounds -- five blocks would run a ninth tile while 251 idle.  So only
+// the whole rounds use full tiles; what is left is cut into at most one tile per block of `su` units each (the other
+// units of such a tile are void: no loads, no classification), and a document smaller than one round is spread over
+// as many blocks as it has units.  Tiles are still numbered, drawn and chained in byte order.
+struct TileMap {
+    u32 nf;  // tiles below nf hold UNITS units each
+    u32 su;  // the tiles from nf on hold su units each (1 <= su <= UNITS)
+};
+static constexpr u64 VOID_UNIT = 1ull << 40;
+template <int UNITS>
+__device__ __forceinline__ u64 tile_unit(TileMap tm, u32 t, int local) {  // wave-uniform arguments
+    if (t < tm.nf) return (u64)t * UNITS + (u64)local;
+    return (u32)local < tm.su ? (u64)tm.nf * UNITS + (u64)(t - tm.nf) * tm.su + (u64)local : VOID_UNIT;
+}
+
 // ---- tile descriptors ------------------------------------------------------------------
 // One naturally aligned 8-byte granule per tile, status and payload together, relaxed
 // agent-scope accesses (MI355X guide, Guideline 16 form R2):
@@ -254,8 +271,8 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
-__device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, u32 t, u32 t_next, bool has_next,
-                                        int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
+__device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
+                                        bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
                                         const S1Aux &aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
@@ -267,7 +284,18 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
 #pragma unroll
 #endif
     for (int k = 0; k < CH; k++) {
-        const u64 unit = (u64)t * UNITS + (u64)(k * WAVES + wave);  // wave-uniform
+        const u64 unit = tile_unit<UNITS>(tm, t, k * WAVES + wave);  // wave-uniform
+        // the unit behind this one (next pass, or the first pass of the next tile): its loads are issued below
+        const u64 unit_nx = k + 1 < CH ? tile_unit<UNITS>(tm, t, (k + 1) * WAVES + wave)
+                                       : (has_next ? tile_unit<UNITS>(tm, t_next, wave) : VOID_UNIT);
+        if (unit == VOID_UNIT) {  // a tail tile holds fewer units than a full one: nothing to classify
+            m[(k * 2 + 0) * 64 + lane] = 0;
+            m[(k * 2 + 1) * 64 + lane] = 0;
+            pre[k * 64 + lane] = 0;
+            if (lane == 0) s_unit[k * WAVES + wave] = 0;
+            if (unit_nx != VOID_UNIT) unit_issue(base, unit_nx * 4096, is_interior(unit_nx), lane, lead, end, pf);
+            continue;
+        }
         const u64 unit_off = unit * 4096;
         const bool interior = is_interior(unit);
         u32 w[16];
@@ -298,13 +326,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
 
         // the chunk registers are dead now: put the next pass in flight; it has the rest of this pass to arrive
         __builtin_amdgcn_sched_barrier(0);  // keep the loads below the last use of w
-        if (k + 1 < CH) {
-            const u64 un = unit + WAVES;
-            unit_issue(base, un * 4096, is_interior(un), lane, lead, end, pf);
-        } else if (has_next) {
-            const u64 un = (u64)t_next * UNITS + (u64)wave;
-            unit_issue(base, un * 4096, is_interior(un), lane, lead, end, pf);
-        }
+        if (unit_nx != VOID_UNIT) unit_issue(base, unit_nx * 4096, is_interior(unit_nx), lane, lead, end, pf);
 
         // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
@@ -380,7 +402,7 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 // (512: the window that held the masks; 1024 in the whole-parse kernel) takes several rounds.
 static constexpr u32 S1_STAGE_CAP = 1024;
 template <int BLOCK, int CH, bool BIG, u32 BIGCAP = S1_STAGE_CAP>
-__device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
+__device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
                                              u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
                                              const u8 *s_klut) {
@@ -406,10 +428,9 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *
         sel[k] = m[(k * 2 + (int)h) * 64 + lane];
         const u32 both = pre[k * 64 + lane];
         upto[k] = h ? both >> 16 : both & 0xffffu;
-        if (unit_h && lane == 0 && ((u64)t * UNITS + (u64)(k * WAVES + wave)) * 4096 < lead + len_)
-            unit_h[(u64)t * UNITS + (u64)(k * WAVES + wave)] = (u8)h;
+        const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
+        if (unit_h && lane == 0 && un * 4096 < lead + len_) unit_h[un] = (u8)h;  // (a void unit lies behind everything)
     }
-    const u64 tile_off = (u64)t * (BLOCK * CH) * 64;
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int u = k * WAVES + wave;
@@ -419,7 +440,7 @@ __device__ __forceinline__ bool flatten_tile(u64 *m, u32 *stage_big, const u32 *
         const u32 lo0 = (u32)s, hi0 = (u32)(s >> 32);
         const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
         const u32 loc = upto[k] - n;  // offset of this lane's first position inside the unit
-        u32 pos0 = (u32)(tile_off + ((u64)k * BLOCK + (u64)wave * 64 + lane) * 64 - lead);
+        u32 pos0 = (u32)(tile_unit<UNITS>(tm, t, u) * 4096 + (u64)lane * 64 - lead);  // (unused for a void unit: no bits)
         __builtin_amdgcn_wave_barrier();  // the staging buffers are free: all masks are in registers / already copied out
         // up to 512 positions fit the window that held the masks; the whole-parse kernel has a larger buffer for
         // denser units (its copy-out is the expensive one: it also writes the token kinds)
@@ -502,7 +523,7 @@ template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
-                                                                        u64 *__restrict__ desc, u32 num_tiles, S1Aux aux) {
+                                                                        u64 *__restrict__ desc, u32 num_tiles, TileMap tm, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
@@ -537,22 +558,22 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // wave 0 between them while the other waves wait (their issue slots go to the other blocks of the CU).
     uint4 pf[4];
     {
-        const u64 un = (u64)t_cur * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        const u64 un = tile_unit<UNITS>(tm, t_cur, wave);
+        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
     if (tid == 0) {
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
         s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
     }
     trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
                                     aux);
     trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
-        const u64 un = (u64)t_nxt * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        const u64 un = tile_unit<UNITS>(tm, t_nxt, wave);
+        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
     u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // of the current tile; meaningful in wave 0 only
     if (wave == 0) {
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
         if (has_next) {
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
                                             s_pre[ms ^ 1][wave], s_unit[us_n], aux);
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
         }
@@ -619,7 +640,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
         const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
         u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH, AUX>(s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
+        err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
         if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
         trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
@@ -660,7 +681,7 @@ template <int BLOCK, int CH, int DEPTH, int WPE, bool NDJSON, bool AUX, bool TRA
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
                                                                Stage1State *__restrict__ st, u64 *__restrict__ desc,
-                                                               u32 num_tiles, S1Aux aux) {
+                                                               u32 num_tiles, TileMap tm, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     constexpr int NU = 2 * DEPTH;  // unit-state slots
@@ -707,8 +728,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     if (t_first >= num_tiles) return;
     uint4 pf[4];
     {
-        const u64 un = (u64)t_first * UNITS + (u64)wave;
-        unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        const u64 un = tile_unit<UNITS>(tm, t_first, wave);
+        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
     }
     if (tid == 0) {
 #pragma unroll
@@ -788,15 +809,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     };
 
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
                                     aux);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();  // the tickets T(1) .. T(DEPTH) are in s_tk
     {
         const u32 t1 = uniform(s_tk[1]);
         if (t1 < num_tiles) {
-            const u64 un = (u64)t1 * UNITS + (u64)wave;
-            unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+            const u64 un = tile_unit<UNITS>(tm, t1, wave);
+            if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
         }
     }
     // pipeline fill: no wave is behind a flatten yet, so the wave that completes a tile takes its look-back at once
@@ -812,7 +833,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         if (ta < num_tiles) {
             const u32 tn = uniform(s_tk[(k + 1u) & 7u]);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
                                             s_unit[uk], aux);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             if (arrive(k, ta, uk) && k + 1u < (u32)DEPTH &&
@@ -840,7 +861,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const u32 G = uniform(res[0]), pm = uniform(res[1]);
             const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
             u64 tile_end = 0;
-            err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
+            err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
                                            wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
                                            AUX ? aux.kind : nullptr, base + lead, s_klut);
             if (tf == num_tiles - 1 && tid == 0) st->total = tile_end;
@@ -907,28 +928,59 @@ static u32 grid_for(K kernel, int block, u32 tiles) {
     return (u32)(tiles < cap ? tiles : cap);
 }
 
-static inline u32 stage1_tiles(size_t len, size_t lead) {
+// Tile plan of a message: whole rounds of full tiles, then one short round of small tiles (see TileMap)
+struct S1Plan {
+    TileMap tm;
+    u32 tiles;
+};
+static u32 s1_block_slots(const S1Variant &v) {  // blocks the device runs at once (the persistent grid)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    static const int over = getenv("SJHIP_S1_BLOCKS_PER_CU") ? atoi(getenv("SJHIP_S1_BLOCKS_PER_CU")) : 0;
+    const int per_cu = over > 0 ? over : (v.block <= 512 ? 2 : 1);  // 128 VGPRs: 16 waves per CU
+    return (u32)cus * (u32)per_cu;
+}
+static S1Plan s1_plan(size_t len, size_t lead) {
     const S1Variant v = s1_variant();
-    const u64 tile_bytes = (u64)v.block * v.ch * 64;
-    const u64 span = (u64)lead + len;
-    return (u32)((span + tile_bytes - 1) / tile_bytes);
+    const u64 units_per_tile = (u64)(v.block / 64) * v.ch;
+    const u64 units = ((u64)lead + len + 4095) / 4096;
+    const u64 slots = s1_block_slots(v);
+    static const bool no_tail = getenv("SJHIP_S1_NO_TAIL") != nullptr;  // A/B: full tiles only
+    S1Plan p;
+    u64 nf = units / (units_per_tile * slots) * slots;  // whole rounds
+    u64 rest = units - nf * units_per_tile;
+    u64 su = (rest + slots - 1) / slots;                // at most one small tile per block
+    if (no_tail || su >= units_per_tile) {              // nearly a whole round anyway: full tiles
+        nf += (rest + units_per_tile - 1) / units_per_tile;
+        rest = 0;
+        su = units_per_tile;
+    }
+    if (su == 0) su = 1;
+    p.tm.nf = (u32)nf;
+    p.tm.su = (u32)su;
+    p.tiles = (u32)(nf + (rest + su - 1) / su);
+    return p;
 }
 
 size_t stage1_workspace_bytes(size_t len) {
-    const size_t tiles = (len + 128) / (256 * 2 * 64) + 2;  // smallest tile of any variant
+    const size_t tiles = (len + 128) / (256 * 2 * 64) + 2 + 2048;  // smallest tile of any variant + one round of small tiles
     return sizeof(Stage1State) + tiles * sizeof(u64);
 }
 
 // zero the Stage1State and the tile descriptors (must precede every launch)
 hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream) {
-    const u32 tiles = stage1_tiles(len, lead);
+    const u32 tiles = s1_plan(len, lead).tiles;
     return hipMemsetAsync(ws, 0, sizeof(Stage1State) + (size_t)tiles * sizeof(u64), stream);
 }
 
 // words of trace a launch of the current variant writes (sjhip_stage1_trace): tiles x waves x TRACE_WORDS
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out) {
     const S1Variant v = s1_variant();
-    const u32 tiles = stage1_tiles(len, lead);
+    const u32 tiles = s1_plan(len, lead).tiles;
     if (tiles_out) *tiles_out = tiles;
     if (waves_out) *waves_out = v.block / 64;
     return (size_t)tiles * (size_t)(v.block / 64) * TRACE_WORDS;
@@ -941,7 +993,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
-    const u32 tiles = stage1_tiles(len, lead);
+    const S1Plan plan = s1_plan(len, lead);
+    const u32 tiles = plan.tiles;
     Stage1State *st = reinterpret_cast<Stage1State *>(ws);
     u64 *desc = reinterpret_cast<u64 *>(st + 1);
     if (tiles == 0) return hipSuccess;
@@ -957,7 +1010,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
-                       st, desc, tiles, aux)
+                       st, desc, tiles, plan.tm, aux)
 #define S1_LAUNCH(KERNEL, B, C, W)                                                    \
     do {                                                                              \
         const bool ax = aux_buf || d_kind;                                            \
