@@ -22,6 +22,7 @@ Objects on the same line (all measured live in this run unless they say "committ
                 return codes exchanged with all_gather), with its roofline object; strong scaling.
   stream        ParseNDStream through the library (sjhip_stream_*): host memory -> tapes in host memory, 10 MiB blocks.
   query         sjhip_count_where("Make", "HOND") on the device-resident tape of configs[4]: only 8 bytes cross PCIe.
+  serialize / marshal_json   Serializer.Serialize (CompressNone) and Iter.MarshalJSON of the same tape on the device.
   cpu_baseline  the oracle's AVX2 / PCLMULQDQ restatement of the reference (oracle/sjo_fast.c, kind "port": Go is not
                 installed, the reference itself cannot be built) on this host in the reference's three shapes
                 (BASELINE.md section 3): stage 1 on one thread, Parse() with stage 1 || stage 2 on two threads, and
@@ -327,6 +328,17 @@ def main():
                               "filter_ms": round(t_f * 1e3, 3), "filter_records": nf,
                               "filter_result_bytes": int(pjf.Tape.nbytes + pjf.Strings.nbytes),
                               "full_result_bytes": int(tl * 8 + sl)}
+            # ---- N3 / N4: Serializer columns and MarshalJSON of the same device-resident result
+            ser = ctx.serialize(fetch=False)
+            t_s = timed(lambda: ctx.serialize(fetch=False), 3)
+            n_text = ctx.marshal_json(fetch=False)
+            t_m = timed(lambda: ctx.marshal_json(fetch=False), 3)
+            extra["serialize"] = {"workload": "Serializer.Serialize (format v3, CompressNone) of configs[4]'s tape: tag / value columns "
+                                              "built on the device, Strings.B as the string column", "ms": round(t_s * 1e3, 3),
+                                  "GBps_of_input": round(len(shard) / t_s / 1e9, 1), "stream_bytes": ser["stream"],
+                                  "columns": {k: ser[k] for k in ("tags", "values", "strings")}}
+            extra["marshal_json"] = {"workload": "Iter.MarshalJSON of configs[4]'s tape on the device", "ms": round(t_m * 1e3, 3),
+                                     "GBps_of_input": round(len(shard) / t_m / 1e9, 1), "text_bytes": n_text}
             del d_nd
             torch.cuda.empty_cache()
             # ---- N1: ParseNDStream through the library, host memory -> host memory
