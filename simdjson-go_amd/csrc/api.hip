@@ -180,14 +180,13 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    // The workspace memset is part of every launch (descriptors must be zero), but only the
-    // kernel itself is bracketed by the events: memset k+1 is issued before event pair k+1.
+    // The workspace preparation (zeroed descriptors, the two edge units) is part of every launch, but only the
+    // kernel itself is bracketed by the events: preparation k+1 is issued before event pair k+1.
     float total = 0.f;
     for (int i = 0; i < iters; i++) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
         (void)a;
-        HIPCHK(stage1_prepare(len, (size_t)(reinterpret_cast<uintptr_t>(d_msg) & 63), ctx->d_ws.p, ctx->stream),
-               "stage1 memset");
+        HIPCHK(stage1_prepare(d_msg, len, ctx->d_ws.p, ctx->stream), "stage1 prepare");
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream), "event");
         HIPCHK(stage1_launch_prepared(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream),
                "stage1 launch");
@@ -219,7 +218,7 @@ int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_po
     rc = arena_reserve(ctx, ctx->d_kat, nw * sizeof(uint64_t));
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, nw * sizeof(uint64_t), ctx->stream), "trace memset");
-    HIPCHK(stage1_prepare(len, lead, ctx->d_ws.p, ctx->stream), "stage1 memset");
+    HIPCHK(stage1_prepare(d_msg, len, ctx->d_ws.p, ctx->stream), "stage1 prepare");
     HIPCHK(stage1_launch_prepared(d_msg, len, 0, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, nullptr, nullptr,
                                   (unsigned long long *)ctx->d_kat.p),
            "stage1 launch (trace)");

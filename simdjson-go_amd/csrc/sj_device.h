@@ -47,7 +47,7 @@ hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_p
                               void *str_aux = nullptr);
 
 size_t stage1_workspace_bytes(size_t len);
-hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream);
+hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream);
 // String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / q / st / unit_h, the string
 // kernels of stage 2 add one 16-byte record per chunk (sj_strings.h ChunkRec) and unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
 // base of the message); everything is sized in whole 4 KiB units.

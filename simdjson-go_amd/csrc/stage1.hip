@@ -57,12 +57,14 @@ __constant__ KindLut c_s1_klut = make_kind_lut();
 struct TileMap {
     u32 nf;  // tiles below nf hold UNITS units each
     u32 su;  // the tiles from nf on hold su units each (1 <= su <= UNITS)
+    u32 nu;  // units of the message: ceil((lead + len) / 4096); a tile's units from nu on are void
 };
 static constexpr u64 VOID_UNIT = 1ull << 40;
 template <int UNITS>
 __device__ __forceinline__ u64 tile_unit(TileMap tm, u32 t, int local) {  // wave-uniform arguments
-    if (t < tm.nf) return (u64)t * UNITS + (u64)local;
-    return (u32)local < tm.su ? (u64)tm.nf * UNITS + (u64)(t - tm.nf) * tm.su + (u64)local : VOID_UNIT;
+    const u64 u = t < tm.nf ? (u64)t * UNITS + (u64)local
+                            : ((u32)local < tm.su ? (u64)tm.nf * UNITS + (u64)(t - tm.nf) * tm.su + (u64)local : VOID_UNIT);
+    return u < tm.nu ? u : VOID_UNIT;
 }
 
 // ---- tile descriptors ------------------------------------------------------------------
@@ -112,8 +114,9 @@ __device__ __forceinline__ u32 lanes_below_popc(u64 mask) {  // popcount of mask
 // ---- carries into the first chunk of a wave unit -------------------------------------------
 // Parity of the backslash run that ends right before byte `p` (p > lead), i.e. the reference's
 // prev_iter_ends_odd_backslash at a chunk boundary (find_odd_backslash_sequences_amd64.s:34-58).
-__device__ __forceinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u64 p) {
+__device__ __forceinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u64 p, u64 end = ~0ull) {
     u32 n = 0;
+    if (p > end) return 0;  // (a chunk of the last unit that lies behind the message: blanks in front of it)
     while (p > lead && base[p - 1] == '\\') {
         n++;
         p--;
@@ -123,16 +126,6 @@ __device__ __forceinline__ u32 peek_backslash_parity(const u8 *base, u64 lead, u
 
 static constexpr u64 BS8 = 0x5c5c5c5c5c5c5c5cull, SP8 = 0x2020202020202020ull;
 
-// The 8 message bytes in front of offset `off` (off % 64 == 0, off >= 4096), blanks beyond the end.
-__device__ __forceinline__ u64 load_prev8(const u8 *base, u64 off, u64 end) {
-    if (off - 8 >= end) return SP8;
-    u64 v = *reinterpret_cast<const u64 *>(base + off - 8);  // inside the line of a valid byte
-    if (off > end) {
-        const u64 keep = (1ull << (8 * (end - (off - 8)))) - 1;
-        v = (v & keep) | (SP8 & ~keep);
-    }
-    return v;
-}
 // carry_in of the chunk at `off` from the 8 bytes before it
 __device__ __forceinline__ u32 carry_from_prev8(u64 prev8, const u8 *base, u64 lead, u64 off) {
     const u64 x = prev8 ^ BS8;
@@ -153,37 +146,33 @@ __device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base,
 
 // ---- chunk load ------------------------------------------------------------------------
 // `base` is 64-byte aligned; the message occupies [lead, lead+len) of it.  A wave unit is 64
-// consecutive chunks (4 KiB, one per lane).  Interior units (every byte belongs to the message) take
-// the fast path: one scalar base + lane * 64.  The first and the last unit of a message take the
-// edge path: bytes outside the message are replaced by 0x20, exactly like the reference's
-// space-masked tail (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as
-// well, which leaves the initial pseudo_pred (=1) semantics untouched.  A 64-byte line that holds
-// at least one message byte is readable as a whole (same page); other lines are not touched.
-__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, u64 unit_off, bool interior, int lane, u64 lead,
-                                           u64 end, uint4 (&v)[4]) {
-    if (interior) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(base + unit_off) + lane * 4;
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = p[q];
-    } else {
-        const u64 off = unit_off + (u64)lane * 64;
-        const bool any = off < end && off + 64 > lead;
-        const uint4 *p = reinterpret_cast<const uint4 *>(base + (any ? off : 0));
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = p[q];
-    }
+// consecutive chunks (4 KiB, one per lane): one scalar base + lane * 64.  The first and the last unit of a
+// message are not read from the message: k_s1_prepare leaves a copy of each in the workspace in which the bytes
+// outside the message are 0x20, exactly like the reference's space-masked tail
+// (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as well, which leaves the initial
+// pseudo_pred (=1) semantics untouched.  So the tile loop has one load path and never reads outside the message.
+static constexpr size_t S1_EDGE_BYTES = 2 * 4096;
+__device__ __forceinline__ const u8 *unit_src(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu) {
+    return unit == 0 ? edge : (unit + 1 == nu ? edge + 4096 : base + unit * 4096);  // wave-uniform
 }
-// edge units only: blank the bytes of this lane's chunk that lie outside the message
-__device__ __forceinline__ void edge_blank(u32 (&w)[16], u64 off, u64 lead, u64 end) {
-    // bytes [lo, hi) of the chunk belong to the message
-    const long long lo = (long long)lead - (long long)off, hi = (long long)end - (long long)off;
+__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu, int lane,
+                                           uint4 (&v)[4]) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(unit_src(base, edge, unit, nu)) + lane * 4;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const long long l = lo - 4 * j, h = hi - 4 * j;  // valid bytes of dword j: [l, h)
-        const u32 ml = l <= 0 ? 0u : (l >= 4 ? ~0u : ((1u << (8 * (int)l)) - 1u));  // bytes below l
-        const u32 mh = h <= 0 ? 0u : (h >= 4 ? ~0u : ((1u << (8 * (int)h)) - 1u));  // bytes below h
-        const u32 keep = mh & ~ml;
-        w[j] = (w[j] & keep) | (0x20202020u & ~keep);
+    for (int q = 0; q < 4; q++) v[q] = p[q];
+}
+// Zeroes the Stage1State and the tile descriptors (must precede every launch) and builds the two edge units.
+__global__ __launch_bounds__(256) void k_s1_prepare(const u8 *__restrict__ base, u64 lead, u64 end, u32 nu, u8 *__restrict__ edge,
+                                                    u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words) {
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, gsz = (u64)gridDim.x * 256;
+    if (gid < sizeof(Stage1State) / 8) state[gid] = 0;
+    for (u64 i = gid; i < desc_words; i += gsz) desc[i] = 0;
+    if (blockIdx.x < 2 && nu != 0) {
+        const u64 unit = blockIdx.x == 0 ? 0 : (u64)nu - 1;
+        for (u32 i = threadIdx.x; i < 4096; i += 256) {
+            const u64 off = unit * 4096 + i;
+            edge[blockIdx.x * 4096 + i] = (off >= lead && off < end) ? base[off] : (u8)0x20;
+        }
     }
 }
 
@@ -273,11 +262,9 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
-                                        const S1Aux &aux) {
+                                        const S1Aux &aux, const u8 *__restrict__ edge) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
-    // interior unit: all 4096 bytes belong to the message (wave-uniform -> scalar unit)
-    auto is_interior = [&](u64 unit) { return (unit != 0 || lead == 0) && (unit + 1) * 4096 <= end; };
 #if defined(SJ_S1_ROLL)
 #pragma unroll 1
 #else
@@ -293,11 +280,10 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             m[(k * 2 + 1) * 64 + lane] = 0;
             pre[k * 64 + lane] = 0;
             if (lane == 0) s_unit[k * WAVES + wave] = 0;
-            if (unit_nx != VOID_UNIT) unit_issue(base, unit_nx * 4096, is_interior(unit_nx), lane, lead, end, pf);
+            if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
             continue;
         }
         const u64 unit_off = unit * 4096;
-        const bool interior = is_interior(unit);
         u32 w[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -307,26 +293,18 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             w[4 * q + 3] = pf[q].w;
         }
         u32 carry0 = 0, pp0 = 1;  // carries into lane 0 from the bytes in front of the unit
-        if (interior) {
-            if (unit != 0) {
-                const u64 prev8 = *reinterpret_cast<const u64 *>(base + unit_off - 8);  // scalar load
-                carry0 = carry_from_prev8(prev8, base, lead, unit_off);
-                pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
-            }
-        } else {
-            edge_blank(w, unit_off + (u64)lane * 64, lead, end);
-            if (unit != 0) {
-                const u64 prev8 = load_prev8(base, unit_off, end);
-                carry0 = carry_from_prev8(prev8, base, lead, unit_off);
-                pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
-            }
+        if (unit != 0) {  // those 8 bytes are message bytes: lead < 64, and the unit begins in front of `end`
+            const u64 prev8 = *reinterpret_cast<const u64 *>(base + unit_off - 8);  // scalar load
+            carry0 = carry_from_prev8(prev8, base, lead, unit_off);
+            pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
         }
 
+        // the next pass goes in flight before this one is classified: a whole pass of math to arrive in (the compiler
+        // keeps the chunk in its own registers; issuing the loads only after classify(), into the registers the chunk
+        // dies in, measured 1-2 % slower)
+        if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
+        __builtin_amdgcn_sched_barrier(0);
         const Classes c = classify(w);
-
-        // the chunk registers are dead now: put the next pass in flight; it has the rest of this pass to arrive
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads below the last use of w
-        if (unit_nx != VOID_UNIT) unit_issue(base, unit_nx * 4096, is_interior(unit_nx), lane, lead, end, pf);
 
         // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
@@ -337,7 +315,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             const bool all_bs = c.bs == ~0ull;
             const u32 trail_odd = all_bs ? 0u : ((u32)__builtin_clzll(~c.bs) & 1u);
             u32 carry_in = wave_shift_up(trail_odd, carry0);
-            if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64);
+            if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64, end);
             const u64 escaped = escaped_mask(c.bs, carry_in);
             quote_bits &= ~escaped;
             if (AUX) starters = c.bs & ~escaped;
@@ -523,7 +501,8 @@ template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
-                                                                        u64 *__restrict__ desc, u32 num_tiles, TileMap tm, S1Aux aux) {
+                                                                        u64 *__restrict__ desc, u32 num_tiles, TileMap tm, S1Aux aux,
+                                                                        const u8 *__restrict__ edge) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
@@ -543,7 +522,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
-    auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
 
     // At launch every block of the grid queues up on the ticket counter: the first ticket is drawn alone
     // (one atomic per block), the next two while phase A of the first tile is already running.
@@ -559,7 +537,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     uint4 pf[4];
     {
         const u64 un = tile_unit<UNITS>(tm, t_cur, wave);
-        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
     }
     if (tid == 0) {
         s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
@@ -567,13 +545,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     }
     trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux);
+                                    aux, edge);
     trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
     __syncthreads();
     u32 t_nxt = uniform(s_ticket[1]);
     if (t_nxt < num_tiles) {
         const u64 un = tile_unit<UNITS>(tm, t_nxt, wave);
-        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
     }
     u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // of the current tile; meaningful in wave 0 only
     if (wave == 0) {
@@ -592,7 +570,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_next) {
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux);
+                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux, edge);
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
         }
         // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
@@ -681,7 +659,7 @@ template <int BLOCK, int CH, int DEPTH, int WPE, bool NDJSON, bool AUX, bool TRA
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
                                                                Stage1State *__restrict__ st, u64 *__restrict__ desc,
-                                                               u32 num_tiles, TileMap tm, S1Aux aux) {
+                                                               u32 num_tiles, TileMap tm, S1Aux aux, const u8 *__restrict__ edge) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     constexpr int NU = 2 * DEPTH;  // unit-state slots
@@ -717,7 +695,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
-    auto interior = [&](u64 un) { return (un != 0 || lead == 0) && (un + 1) * 4096 <= end; };
 
     // prologue (two block barriers, once per block): first ticket alone, the next DEPTH while phase A of the first
     // tile runs
@@ -729,7 +706,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     uint4 pf[4];
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
-        if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
     }
     if (tid == 0) {
 #pragma unroll
@@ -810,14 +787,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
 
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux);
+                                    aux, edge);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();  // the tickets T(1) .. T(DEPTH) are in s_tk
     {
         const u32 t1 = uniform(s_tk[1]);
         if (t1 < num_tiles) {
             const u64 un = tile_unit<UNITS>(tm, t1, wave);
-            if (un != VOID_UNIT) unit_issue(base, un * 4096, interior(un), lane, lead, end, pf);
+            if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
         }
     }
     // pipeline fill: no wave is behind a flatten yet, so the wave that completes a tile takes its look-back at once
@@ -834,7 +811,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const u32 tn = uniform(s_tk[(k + 1u) & 7u]);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
-                                            s_unit[uk], aux);
+                                            s_unit[uk], aux, edge);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             if (arrive(k, ta, uk) && k + 1u < (u32)DEPTH &&
                 __hip_atomic_load(&s_res[(k - 1u) & 7u][5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == k)
@@ -962,19 +939,32 @@ static S1Plan s1_plan(size_t len, size_t lead) {
     if (su == 0) su = 1;
     p.tm.nf = (u32)nf;
     p.tm.su = (u32)su;
+    p.tm.nu = (u32)units;
     p.tiles = (u32)(nf + (rest + su - 1) / su);
     return p;
 }
 
+// workspace: Stage1State | the two edge units (k_s1_prepare) | tile descriptors
 size_t stage1_workspace_bytes(size_t len) {
     const size_t tiles = (len + 128) / (256 * 2 * 64) + 2 + 2048;  // smallest tile of any variant + one round of small tiles
-    return sizeof(Stage1State) + tiles * sizeof(u64);
+    return sizeof(Stage1State) + S1_EDGE_BYTES + tiles * sizeof(u64);
 }
 
-// zero the Stage1State and the tile descriptors (must precede every launch)
-hipError_t stage1_prepare(size_t len, size_t lead, void *ws, hipStream_t stream) {
-    const u32 tiles = s1_plan(len, lead).tiles;
-    return hipMemsetAsync(ws, 0, sizeof(Stage1State) + (size_t)tiles * sizeof(u64), stream);
+// zero the Stage1State and the tile descriptors, copy the edge units (must precede every launch)
+hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
+    const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
+    const u64 lead = a & 63;
+    const S1Plan plan = s1_plan(len, lead);
+    u8 *w = reinterpret_cast<u8 *>(ws);
+    u8 *edge = w + sizeof(Stage1State);
+    u64 *desc = reinterpret_cast<u64 *>(edge + S1_EDGE_BYTES);
+    // the state and the descriptors are not adjacent: two ranges, one kernel (state first: 8 words)
+    const u64 desc_words = plan.tiles;
+    const u32 blocks = (u32)((desc_words + 255) / 256 < 2 ? 2 : ((desc_words + 255) / 256 > 64 ? 64 : (desc_words + 255) / 256));
+    hipLaunchKernelGGL(k_s1_prepare, dim3(blocks), dim3(256), 0, stream, base, lead, lead + (u64)len, plan.tm.nu, edge,
+                       reinterpret_cast<u64 *>(w), desc, desc_words);
+    return hipGetLastError();
 }
 
 // words of trace a launch of the current variant writes (sjhip_stage1_trace): tiles x waves x TRACE_WORDS
@@ -996,7 +986,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     const S1Plan plan = s1_plan(len, lead);
     const u32 tiles = plan.tiles;
     Stage1State *st = reinterpret_cast<Stage1State *>(ws);
-    u64 *desc = reinterpret_cast<u64 *>(st + 1);
+    const u8 *edge = reinterpret_cast<const u8 *>(st + 1);
+    u64 *desc = reinterpret_cast<u64 *>(const_cast<u8 *>(edge) + S1_EDGE_BYTES);
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
@@ -1010,7 +1001,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
-                       st, desc, tiles, plan.tm, aux)
+                       st, desc, tiles, plan.tm, aux, edge)
 #define S1_LAUNCH(KERNEL, B, C, W)                                                    \
     do {                                                                              \
         const bool ax = aux_buf || d_kind;                                            \
@@ -1055,7 +1046,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf, u8 *d_kind) {
-    hipError_t e = stage1_prepare(len, reinterpret_cast<uintptr_t>(d_msg) & 63, ws, stream);
+    hipError_t e = stage1_prepare(d_msg, len, ws, stream);
     if (e != hipSuccess) return e;
     return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr);
 }
