@@ -42,6 +42,7 @@ struct S1Aux {
 //   0 phase A begins   1 phase A done (arrival)   2 serial section done (the wave that ran it; 0 otherwise)
 //   3 state of the tile known (past the second barrier / the result flag)   4 flatten done   5 HW_ID
 static constexpr int TRACE_WORDS = 8;
+
 template <bool TRACE>
 __device__ __forceinline__ void trace_put(u64 *trace, u32 tile, int waves, int wave, int lane, int k) {
     if (TRACE && lane == 0) trace[((u64)tile * waves + wave) * TRACE_WORDS + k] = __builtin_readcyclecounter();
@@ -262,7 +263,7 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
-                                        const S1Aux &aux, const u8 *__restrict__ edge) {
+                                        const S1Aux &aux, const u8 *__restrict__ edge, bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
 #if defined(SJ_S1_ROLL)
@@ -304,7 +305,17 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // dies in, measured 1-2 % slower)
         if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
         __builtin_amdgcn_sched_barrier(0);
+        // issue priority by progress: the SIMD arbiter prefers its oldest wave, which then finishes a pass long before
+        // the others and leaves the tail of every phase to one or two waves that cannot fill the pipe; with the waves
+        // that are behind going first the four finish together (measured -4 %).  TOP: this wave stays in front (wave 0
+        // of the barrier kernel: it has the look-back to do while the others are still in this phase).
+        if (k == 0 || TOP) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(1);
         const Classes c = classify(w);
+        __builtin_amdgcn_sched_barrier(0);
+        if (TOP) __builtin_amdgcn_s_setprio(3);
+        else if (k == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
 
         // ---- backslash carry: parity of the run of backslashes at the END of the previous chunk.
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
@@ -412,6 +423,8 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int u = k * WAVES + wave;
+        if (k == 0) __builtin_amdgcn_s_setprio(3);  // (see phase_a)
+        else __builtin_amdgcn_s_setprio(1);
         const u32 C = (u32)__builtin_amdgcn_readlane((int)cl, u);
         const u64 g = BASE + ((u32)__builtin_amdgcn_readlane((int)incl, u) - C);
         const u64 s = sel[k];
@@ -506,9 +519,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
-    __shared__ u32 s_ticket[3];
+    __shared__ u32 s_ticket[4];
     __shared__ u32 s_unit[3][UNITS];
-    __shared__ u32 s_res[4];  // look-back result of the current tile: G, pre_mask, BASE (lo, hi)
+    __shared__ u32 s_res2[2][4];  // look-back result of tile T(i) in slot i & 1: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[2][WAVES][CH * 64];  // per chunk: inclusive structural counts of its unit, both hypotheses
     __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];  // whole parse: positions of one dense unit
@@ -532,8 +545,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 
     // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
     // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.  Per tile
-    // there are two block barriers; what is serial per tile (aggregate, ticket, look-back) is done by
-    // wave 0 between them while the other waves wait (their issue slots go to the other blocks of the CU).
+    // there is one block barrier; what is serial per tile (aggregate, ticket, look-back) is done by wave 0
+    // beside the other waves' work (see the loop).
     uint4 pf[4];
     {
         const u64 un = tile_unit<UNITS>(tm, t_cur, wave);
@@ -559,10 +572,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (lane == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
     }
 
+    // One block barrier per tile.  Iteration i: phase A of T(i+1) (wave 0 at top priority, so it is through first);
+    // wave 0 then draws nothing new but resolves the look-back of T(i), whose aggregate it published an iteration ago,
+    // while the other waves are still in phase A; barrier; wave 0 aggregates and publishes T(i+1) (a few hundred
+    // cycles into its flatten); everybody flattens T(i).  Rings: tickets 4 (T(j) in slot j & 3, the new one is
+    // written before the barrier into the slot of T(i-1)), look-back results 2, unit state 3, masks 2 (per wave).
     int ms = 0, us = 0;  // mask / unit slots of t_cur
     bool err = false;
-    for (;;) {
-        const u32 t_nn = uniform(s_ticket[2]);  // the tile after t_nxt
+    for (u32 it = 0;; it++) {
+        const u32 t_nn = uniform(s_ticket[(it + 2u) & 3u]);  // the tile after t_nxt
         const bool has_next = t_nxt < num_tiles;
         const int us_n = us == 2 ? 0 : us + 1;
         u32 tk = 0;  // the ticket after t_nn: drawn now, it returns while phase A runs
@@ -570,27 +588,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_next) {
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux, edge);
+                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux, edge, wave == 0);
             trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
         }
-        // wave 0 reads the look-back window of the current tile before the barrier: the loads return while it
-        // waits for the other waves (the predecessors published their aggregates about a phase ago)
-        LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
-        u64 win[4] = {0, 0, 0, 0};
-        if (wave == 0 && t_cur != 0) lookback_load(desc, lb.j, lane, win);
-        __syncthreads();
-        u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
+        u32 *res = s_res2[it & 1u];
         if (wave == 0) {
-            if (has_next) {
-                tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
-                if (lane == 0) {
-                    desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
-                    s_ticket[2] = tk;
-                }
-            }
             u32 G = 0;
             u64 BASE = 0;
             if (t_cur != 0) {
+                LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
+                u64 win[4];
+                lookback_load(desc, lb.j, lane, win);
                 u32 spins = 0;
                 for (;;) {
                     const int r = lookback_eval(win, lb, lane, G, BASE);
@@ -605,18 +613,24 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                 if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
             }
             if (lane == 0) {
-                s_res[0] = G;
-                s_res[1] = pm0;
-                s_res[2] = (u32)BASE;
-                s_res[3] = (u32)(BASE >> 32);
+                res[0] = G;
+                res[1] = pm0;
+                res[2] = (u32)BASE;
+                res[3] = (u32)(BASE >> 32);
+                if (has_next) s_ticket[(it + 3u) & 3u] = tk;
                 if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
             }
             trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
         }
         __syncthreads();
+        u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
+        if (wave == 0 && has_next) {
+            tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
+            if (lane == 0) desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+        }
         trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
-        const u32 G = uniform(s_res[0]), pm = uniform(s_res[1]);
-        const u64 BASE = ((u64)uniform(s_res[3]) << 32) | uniform(s_res[2]);
+        const u32 G = uniform(res[0]), pm = uniform(res[1]);
+        const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
@@ -918,7 +932,7 @@ static u32 s1_block_slots(const S1Variant &v) {  // blocks the device runs at on
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     }
     static const int over = getenv("SJHIP_S1_BLOCKS_PER_CU") ? atoi(getenv("SJHIP_S1_BLOCKS_PER_CU")) : 0;
-    const int per_cu = over > 0 ? over : (v.block <= 512 ? 2 : 1);  // 128 VGPRs: 16 waves per CU
+    const int per_cu = over > 0 ? over : (v.block <= 512 ? 2 : 1);  // 16 waves per CU
     return (u32)cus * (u32)per_cu;
 }
 static S1Plan s1_plan(size_t len, size_t lead) {
