@@ -156,11 +156,21 @@ static constexpr size_t S1_EDGE_BYTES = 2 * 4096;
 __device__ __forceinline__ const u8 *unit_src(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu) {
     return unit == 0 ? edge : (unit + 1 == nu ? edge + 4096 : base + unit * 4096);  // wave-uniform
 }
+// a unit in flight: this lane's chunk and (every lane the same) the 8 message bytes in front of the unit, which the
+// carries into its first chunk come from -- fetched with the chunk so that nothing waits for a scalar load later
+// (measured -2.5 %).  One unit per wave is in flight; a second one (each pass loaded a whole tile ahead) measured
+// 5-8 % SLOWER: the flatten's stores then queue behind twice as many loads.
+struct UnitRegs {
+    uint4 v[4];
+    u64 prev8;
+};
 __device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu, int lane,
-                                           uint4 (&v)[4]) {
+                                           UnitRegs &r) {
     const uint4 *p = reinterpret_cast<const uint4 *>(unit_src(base, edge, unit, nu)) + lane * 4;
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = p[q];
+    for (int q = 0; q < 4; q++) r.v[q] = p[q];
+    // (unit 0 has nothing in front of it: its own first bytes are read instead and not used)
+    r.prev8 = *reinterpret_cast<const u64 *>(base + (unit ? unit * 4096 - 8 : 0));
 }
 // Zeroes the Stage1State and the tile descriptors (must precede every launch) and builds the two edge units.
 __global__ __launch_bounds__(256) void k_s1_prepare(const u8 *__restrict__ base, u64 lead, u64 end, u32 nu, u8 *__restrict__ edge,
@@ -262,7 +272,7 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
-                                        bool has_next, int lane, int wave, uint4 (&pf)[4], u64 *m, u32 *pre, u32 *s_unit,
+                                        bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
                                         const S1Aux &aux, const u8 *__restrict__ edge, bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
@@ -288,14 +298,14 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         u32 w[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            w[4 * q + 0] = pf[q].x;
-            w[4 * q + 1] = pf[q].y;
-            w[4 * q + 2] = pf[q].z;
-            w[4 * q + 3] = pf[q].w;
+            w[4 * q + 0] = pf.v[q].x;
+            w[4 * q + 1] = pf.v[q].y;
+            w[4 * q + 2] = pf.v[q].z;
+            w[4 * q + 3] = pf.v[q].w;
         }
         u32 carry0 = 0, pp0 = 1;  // carries into lane 0 from the bytes in front of the unit
         if (unit != 0) {  // those 8 bytes are message bytes: lead < 64, and the unit begins in front of `end`
-            const u64 prev8 = *reinterpret_cast<const u64 *>(base + unit_off - 8);  // scalar load
+            const u64 prev8 = ((u64)uniform((u32)(pf.prev8 >> 32)) << 32) | uniform((u32)pf.prev8);
             carry0 = carry_from_prev8(prev8, base, lead, unit_off);
             pp0 = pseudo_pred_from_prev8(prev8, base, lead, unit_off);
         }
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.  Per tile
     // there is one block barrier; what is serial per tile (aggregate, ticket, look-back) is done by wave 0
     // beside the other waves' work (see the loop).
-    uint4 pf[4];
+    UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_cur, wave);
         if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     __syncthreads();
     const u32 t_first = uniform(s_tk[0]);
     if (t_first >= num_tiles) return;
-    uint4 pf[4];
+    UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
         if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
