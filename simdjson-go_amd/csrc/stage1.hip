@@ -663,22 +663,22 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
 }
 
 // ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
-// The barrier kernel above stalls the whole CU twice per tile: at the first barrier the waves that finished phase A
-// early wait for the slowest one (the four waves of a SIMD finish one after the other), then everybody waits while
-// wave 0 runs the serial section, whose look-back costs one cross-CU hand-off (~3 us behind the CU's own streaming
-// loads) plus the wait for the slowest of the ~256 tiles in front (they all run at the same time).  The s_memtime
-// timelines (profiles/) show about a third of every wave's life spent that way.
-// Here the waves of a block only meet through LDS words, a wave never waits for something another wave could be
-// doing, and the result of a look-back is asked for DEPTH-1 phase A's after the tile was aggregated:
-//   iteration k of a wave:   phase A of tile T(k)  ->  arrive  ->  [ need res(k-DEPTH+1) ]  ->  flatten T(k-DEPTH+1)
-//   * arrival: +1 on an LDS counter; the wave that finds WAVES-1 there aggregates the tile, publishes its AGG
-//     descriptor and marks the tile ready (a few hundred cycles);
-//   * the serial duty S(j) -- ticket T(j+DEPTH+1), look-back of T(j), PREFIX descriptor, result record res(j) =
-//     {state, unit parities, output base} -- is CLAIMED (LDS compare-and-swap) by whichever wave gets to it first:
-//     a wave that has just finished a flatten (it is ahead of the others; the duty slows it down, so the role
-//     rotates), or at the latest the first wave that needs res(j) and finds it neither done nor claimed.
-// Ring sizes: tickets and res / claim 8 (k & 7), masks DEPTH (private per wave), unit state 2*DEPTH: a wave can be
-// DEPTH iterations ahead of the slowest one, which may still be flattening the tile DEPTH-1 behind its own phase A.
+// With the barrier kernel every block moves in step with the slowest block of its generation: the ~256 tiles in front
+// of a tile are the ones the other blocks are working on at the same time, so a look-back cannot finish before the
+// slowest of them has published its aggregate, and the flatten of the tile -- one barrier later -- waits for it
+// (without look-back and barrier the same kernel runs a quarter faster).  Here the waves of a block meet only through
+// LDS flags and the flatten of a tile lags its phase A by D = DEPTH - 1 tiles:
+//   iteration i of a wave:   phase A of T(i+1)  ->  arrive  ->  [ need res(i+1-D) ]  ->  flatten T(i+1-D)
+//   * arrival: +1 on an LDS counter; the wave that completes a tile aggregates it, publishes its AGG descriptor and
+//     marks it ready;
+//   * the serial work -- ticket T(i+3), look-back of the aggregated tiles in order, PREFIX descriptor, result record
+//     res(j) = {state, unit parities, output base} and its flag -- is wave 0's: it runs phase A at top priority
+//     (s_setprio), is through first, resolves what it must (the tile it is about to flatten) and tries the next
+//     aggregated tile once without waiting; with DEPTH 3 that try is a whole round after the tile's aggregate was
+//     published, and when a block in front is late nobody waits for it in this round.
+// Rings: tickets 8 (T(j) in slot j & 7, published through s_tkn), unit state / arrival / aggregates 8, results 4,
+// masks DEPTH (private per wave).  A wave can be DEPTH iterations ahead of the slowest wave of its block: res(j)
+// needs every wave's arrival for T(j), which lies behind that wave's flatten of T(j-D-1).
 template <int BLOCK, int CH, int DEPTH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
@@ -686,17 +686,18 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
                                                                u32 num_tiles, TileMap tm, S1Aux aux, const u8 *__restrict__ edge) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
-    constexpr int NU = 2 * DEPTH;  // unit-state slots
+    constexpr u32 D = DEPTH - 1;
     static_assert(UNITS <= 32, "pre_mask is a u32");
-    static_assert(DEPTH >= 2 && DEPTH <= 3, "ticket ring of 8");
+    static_assert(DEPTH >= 2 && DEPTH <= 3, "rings of 8 and 4");
     constexpr u32 STAGE_CAP = AUX ? (DEPTH == 2 ? S1_STAGE_CAP : 512u) : 4u;
-    __shared__ u32 s_tk[8];         // T(k) in slot k & 7
-    __shared__ u32 s_unit[NU][UNITS];
-    __shared__ u32 s_arrive[NU];    // waves that have finished phase A of the tile in unit slot k % NU
-    __shared__ u32 s_ready[NU];     // k + 1 once tile T(k) is aggregated and its AGG published
-    __shared__ u32 s_agg[NU][4];    // P, T0, T1, pre_mask of that tile
-    __shared__ u32 s_claim[8];      // k + 1 once the serial duty S(k) has been taken (slot k & 7)
-    __shared__ u32 s_res[8][8];     // res(k) in slot k & 7: G, pre_mask, BASE lo, BASE hi, -, sequence k + 1
+    __shared__ u32 s_tk[8];         // T(j) in slot j & 7
+    __shared__ u32 s_tkn;           // T(0) .. T(s_tkn - 1) are in s_tk
+    __shared__ u32 s_unit[8][UNITS];
+    __shared__ u32 s_arrive[8];     // waves that have finished phase A of the tile in slot j & 7
+    __shared__ u32 s_ready[8];      // j + 1 once T(j) is aggregated (s_agg) and its AGG descriptor published
+    __shared__ u32 s_agg[8][4];     // P, T0, T1, pre_mask of that tile
+    __shared__ u32 s_res[4][4];     // look-back result of T(j) in slot j & 3: G, pre_mask, BASE (lo, hi)
+    __shared__ u32 s_resflag[4];    // j + 1 once s_res[j & 3] holds the result of T(j)
     __shared__ u64 s_mask[DEPTH][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[DEPTH][WAVES][CH * 64];
     __shared__ u32 s_stage[AUX ? WAVES : 1][STAGE_CAP];
@@ -707,22 +708,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u8 k = c_s1_klut.v[tid];
         s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
     }
-    if (tid < NU) {
+    if (tid < 8) {
         s_arrive[tid] = 0;
         s_ready[tid] = 0;
-    }
-    if (tid < 8) {
-        s_res[tid][5] = 0;
-        s_claim[tid] = (u32)tid - 7u;  // the value the claim of S(tid) expects: (k + 1) - 8
-        s_tk[tid] = 0xffffffffu;
+        s_resflag[tid & 3] = 0;
     }
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
 
-    // prologue (two block barriers, once per block): first ticket alone, the next DEPTH while phase A of the first
-    // tile runs
-    __syncthreads();
+    // prologue (two block barriers, once per block), as in the barrier kernel
     if (tid == 0) s_tk[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
     const u32 t_first = uniform(s_tk[0]);
@@ -733,48 +728,49 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
     }
     if (tid == 0) {
-#pragma unroll
-        for (int k = 1; k <= DEPTH; k++) s_tk[k] = atomicAdd(&st->tile_counter, 1u);
+        s_tk[1] = atomicAdd(&st->tile_counter, 1u);
+        s_tk[2] = atomicAdd(&st->tile_counter, 1u);
+        s_tkn = 3;
+    }
+    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
+    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
+                                    aux, edge);
+    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
+    __syncthreads();
+    {
+        const u32 t1 = uniform(s_tk[1]);
+        if (t1 < num_tiles) {
+            const u64 un = tile_unit<UNITS>(tm, t1, wave);
+            if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
+        }
+    }
+    if (wave == 0) {
+        u32 P, T0, T1, pm;
+        tile_aggregate<UNITS>(s_unit[0], lane, P, T0, T1, pm);
+        if (lane == 0) {
+            desc_store(&desc[t_first], t_first == 0 ? pack_prefix(P, T0) : pack_agg(P, T0, T1));
+            s_agg[0][0] = P;
+            s_agg[0][1] = T0;
+            s_agg[0][2] = T1;
+            s_agg[0][3] = pm;
+            __hip_atomic_store(&s_ready[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 
-    // arrival for tile T(k) = tk (unit slot uk); the last wave aggregates it and publishes its descriptor
-    auto arrive = [&](u32 k, u32 tk, int uk) -> bool {  // true: this wave was the last one
-        u32 arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[uk], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (uniform(arrived) == (u32)WAVES - 1u) {
-            u32 P1, T10, T11, pm1;
-            tile_aggregate<UNITS>(s_unit[uk], lane, P1, T10, T11, pm1);
-            if (lane == 0) {
-                desc_store(&desc[tk], tk == 0 ? pack_prefix(P1, T10) : pack_agg(P1, T10, T11));
-                s_arrive[uk] = 0;  // next used NU tiles from now
-                s_agg[uk][0] = P1;
-                s_agg[uk][1] = T10;
-                s_agg[uk][2] = T11;
-                s_agg[uk][3] = pm1;
-                __hip_atomic_store(&s_ready[uk], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // wave 0: the look-back of T(j).  wait: stay until it is resolved; otherwise one try, false if the tile is not
+    // aggregated yet or a descriptor in front of it is still missing.
+    auto resolve = [&](u32 j, bool wait) -> bool {
+        const int uj = (int)(j & 7u);
+        u32 spins = 0;
+        while (__hip_atomic_load(&s_ready[uj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1u) {
+            if (!wait) return false;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {  // bounded: a bug must not hang the device
+                if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                break;
             }
-            return true;
         }
-        return false;
-    };
-    // The serial duty S(j) for tile T(j) in unit slot uj.  Returns false without doing anything if the tile is not
-    // ready yet or another wave has the duty.
-    auto serial_duty = [&](u32 j, int uj) -> bool {
-        if (__hip_atomic_load(&s_ready[uj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1u) return false;
-        u32 won = 0;
-        if (lane == 0) {
-            u32 expect = j - 7u;
-            won = __hip_atomic_compare_exchange_strong(&s_claim[j & 7u], &expect, j + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP)
-                      ? 1u
-                      : 0u;
-        }
-        if (!uniform(won)) return false;
         const u32 tj = uniform(s_tk[j & 7u]);
-        u32 *res = s_res[j & 7u];
-        // ticket T(j+DEPTH+1), drawn only while the newest known ticket is still a tile; it returns during the look-back
-        u32 tk = 0xffffffffu;
-        if (lane == 0 && s_tk[(j + DEPTH) & 7u] < num_tiles) tk = atomicAdd(&st->tile_counter, 1u);
         const u32 P0 = uniform(s_agg[uj][0]), T00 = uniform(s_agg[uj][1]), T01 = uniform(s_agg[uj][2]),
                   pm0 = uniform(s_agg[uj][3]);
         u32 G = 0;
@@ -783,12 +779,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             LookBack lb = {(long long)tj - 1, 0, 0, 0};
             u64 win[4];
             lookback_load(desc, lb.j, lane, win);
-            u32 spins = 0;
+            spins = 0;
             for (;;) {
                 const int r = lookback_eval(win, lb, lane, G, BASE);
                 if (r == 1) break;
-                if (r == 0) __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
+                if (r == 0) {
+                    if (!wait) return false;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (++spins > (1u << 22)) {
                     if (lane == 0) atomicOr(&st->error, 0x80000000u);
                     break;
                 }
@@ -797,92 +796,97 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             if (lane == 0) desc_store(&desc[tj], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
         }
         if (lane == 0) {
-            s_tk[(j + DEPTH + 1) & 7u] = tk;
+            u32 *res = s_res[j & 3u];
             res[0] = G;
             res[1] = pm0;
             res[2] = (u32)BASE;
             res[3] = (u32)(BASE >> 32);
             if (tj == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
-            __hip_atomic_store(&res[5], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_resflag[j & 3u], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         trace_put<TRACE>(aux.trace, tj, WAVES, wave, lane, 2);
         return true;
     };
 
-    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge);
-    trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
-    __syncthreads();  // the tickets T(1) .. T(DEPTH) are in s_tk
-    {
-        const u32 t1 = uniform(s_tk[1]);
-        if (t1 < num_tiles) {
-            const u64 un = tile_unit<UNITS>(tm, t1, wave);
-            if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
-        }
-    }
-    // pipeline fill: no wave is behind a flatten yet, so the wave that completes a tile takes its look-back at once
-    if (arrive(0u, t_first, 0)) (void)serial_duty(0u, 0);
-
-    // k: the tile phase A runs on in this iteration; f = k - (DEPTH - 1): the tile that is flattened
-    int mk = 1 % DEPTH, uk = 1 % NU;   // mask / unit slot of T(k)
-    int mf = 0, uf = 0;                // of T(f): the first tile flattened is T(0)
-    u32 next_duty = 0;                 // no res(j) below this is missing (wave-local view)
+    u32 lb_next = 0;  // wave 0: the first tile whose look-back is not resolved yet
     bool err = false;
-    for (u32 k = 1;; k++) {
-        const u32 ta = uniform(s_tk[k & 7u]);
-        if (ta < num_tiles) {
-            const u32 tn = uniform(s_tk[(k + 1u) & 7u]);
-            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[mk][wave], s_pre[mk][wave],
-                                            s_unit[uk], aux, edge);
-            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
-            if (arrive(k, ta, uk) && k + 1u < (u32)DEPTH &&
-                __hip_atomic_load(&s_res[(k - 1u) & 7u][5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == k)
-                (void)serial_duty(k, uk);
-        }
-        if (k + 1u >= (u32)DEPTH) {
-            const u32 f = k + 1u - (u32)DEPTH;
-            const u32 tf = uniform(s_tk[f & 7u]);
-            if (tf >= num_tiles) break;  // tickets are monotonic: nothing left in flight
-            // ---- the state in front of T(f): done by now in the steady state; otherwise take the duty
-            u32 *res = s_res[f & 7u];
-            {
-                u32 spins = 0;
-                while (__hip_atomic_load(&res[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1u) {
-                    if (serial_duty(f, uf)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 24)) {
-                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
-                        break;
-                    }
+    for (u32 it = 0;; it++) {
+        // tickets T(it+1) (phase A now) and T(it+2) (its first chunk is loaded at the end of this phase A)
+        if (it != 0) {
+            u32 spins = 0;
+            while (__hip_atomic_load(&s_tkn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 3u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {
+                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    break;
                 }
             }
-            trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 3);
-            const u32 G = uniform(res[0]), pm = uniform(res[1]);
-            const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
-            u64 tile_end = 0;
-            err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
-                                           wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
-                                           AUX ? aux.kind : nullptr, base + lead, s_klut);
-            if (tf == num_tiles - 1 && tid == 0) st->total = tile_end;
-            trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
-            if (TRACE && lane == 0)
-                aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
-                    (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-            // ahead of the others?  Then the oldest look-back that nobody has taken yet is ours (if its tile is ready).
-            if (next_duty <= f) next_duty = f + 1u;
-            if (next_duty <= k) {
-                if (__hip_atomic_load(&s_res[next_duty & 7u][5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == next_duty + 1u)
-                    next_duty++;
-                else
-                    (void)serial_duty(next_duty, (int)(next_duty % (u32)NU));
-            }
-            mf = mf + 1 == DEPTH ? 0 : mf + 1;
-            uf = uf + 1 == NU ? 0 : uf + 1;
         }
-        mk = mk + 1 == DEPTH ? 0 : mk + 1;
-        uk = uk + 1 == NU ? 0 : uk + 1;
+        const u32 ta = uniform(s_tk[(it + 1u) & 7u]), tn = uniform(s_tk[(it + 2u) & 7u]);
+        const bool more = ta < num_tiles;
+        u32 tk = 0xffffffffu;  // T(it+3): drawn now, it returns while phase A runs
+        if (more && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
+        if (more) {
+            const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
+            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
+                                            s_unit[ua], aux, edge, wave == 0);
+            trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
+            u32 arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (uniform(arrived) == (u32)WAVES - 1u) {  // the last wave of the tile
+                u32 P1, T10, T11, pm1;
+                tile_aggregate<UNITS>(s_unit[ua], lane, P1, T10, T11, pm1);
+                if (lane == 0) {
+                    desc_store(&desc[ta], pack_agg(P1, T10, T11));
+                    s_arrive[ua] = 0;  // next used eight tiles from now
+                    s_agg[ua][0] = P1;
+                    s_agg[ua][1] = T10;
+                    s_agg[ua][2] = T11;
+                    s_agg[ua][3] = pm1;
+                    __hip_atomic_store(&s_ready[ua], it + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (wave == 0 && lane == 0) {  // (every iteration, so that nobody waits for a ticket that is never drawn)
+            s_tk[(it + 3u) & 7u] = tk;
+            __hip_atomic_store(&s_tkn, it + 4u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool flat = it + 1u >= D;  // the tile to flatten in this iteration: T(it + 1 - D)
+        const u32 f = it + 1u - D;
+        const u32 tf = flat ? uniform(s_tk[f & 7u]) : 0u;
+        if (flat && tf >= num_tiles) break;  // tickets are monotonic: nothing left in flight
+        if (wave == 0) {
+            if (flat)
+                while (lb_next <= f) (void)resolve(lb_next++, true);
+            // one try at the next aggregated tile, a round after its aggregate went out
+            if (lb_next <= it && uniform(s_tk[lb_next & 7u]) < num_tiles && resolve(lb_next, false)) lb_next++;
+        }
+        if (!flat) continue;
+        {
+            u32 spins = 0;
+            while (__hip_atomic_load(&s_resflag[f & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {
+                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    break;
+                }
+            }
+        }
+        const u32 *res = s_res[f & 3u];
+        const int mf = (int)(f % (u32)DEPTH), uf = (int)(f & 7u);
+        trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 3);
+        const u32 G = uniform(res[0]), pm = uniform(res[1]);
+        const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
+        u64 tile_end = 0;
+        err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
+                                       wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
+                                       AUX ? aux.kind : nullptr, base + lead, s_klut);
+        if (tf == num_tiles - 1 && tid == 0) st->total = tile_end;
+        trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
+        if (TRACE && lane == 0)
+            aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
+                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
 }

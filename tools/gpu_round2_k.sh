@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for lib in "" $(ls build_ab/*.so); do
   echo "== lib ${lib:-default}"
-  for c in 426 1700; do
+  for c in ${COPIES_LIST:-426 1700}; do
     SJHIP_LIB=${lib:+$PWD/$lib} COPIES=$c timeout 120 python tools/s1_time.py 2>&1 | tail -1
   done
 done
