@@ -128,16 +128,22 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind),
-           "stage1 launch");
+    // the last block of the kernel leaves the final state (and the last message byte) in pinned host memory: one
+    // stream synchronisation, no copy kernels behind the launch
     Stage1State *hs = (Stage1State *)ctx->h_scratch;
-    HIPCHK(hipMemcpyAsync(hs, ctx->d_ws.p, sizeof(Stage1State), hipMemcpyDeviceToHost, ctx->stream), "D2H state");
-    uint8_t *hlast = ctx->h_scratch + 128;
-    if (!have_last && len > 0)
-        HIPCHK(hipMemcpyAsync(hlast, (const uint8_t *)d_msg + len - 1, 1, hipMemcpyDeviceToHost, ctx->stream),
-               "D2H last byte");
+    hs->done = 0;
+    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind, hs),
+           "stage1 launch");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
-    if (!have_last) last_byte = len ? *hlast : 0;
+    if (hs->done == 0) {  // (a message without tiles never launches the kernel)
+        memset(hs, 0, sizeof *hs);
+        if (!have_last && len > 0) {
+            uint8_t *hlast = ctx->h_scratch + 128;
+            HIPCHK(hipMemcpy(hlast, (const uint8_t *)d_msg + len - 1, 1, hipMemcpyDeviceToHost), "D2H last byte");
+            hs->last_byte = *hlast;
+        }
+    }
+    if (!have_last) last_byte = (uint8_t)hs->last_byte;
     ctx->s1 = *hs;
     if (hs->error & 0x80000000u) {  // a bounded spin loop of the kernel ran out: internal error, never a verdict
         ctx_set_error(ctx, "stage-1 kernel aborted (internal synchronisation timeout)");

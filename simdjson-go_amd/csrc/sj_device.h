@@ -13,7 +13,9 @@ struct Stage1State {
     uint32_t error;          // OR of (control char inside string)   -> reference error_mask != 0
     uint64_t total;          // number of structural indexes
     uint32_t ends_in_quote;  // reference prev_iter_inside_quote != 0 at the end
-    uint32_t pad[11];
+    uint32_t done;           // blocks that have finished: the last one copies this record to pinned host memory
+    uint32_t last_byte;      // msg[len - 1] (host copy only: the end-of-document verdict needs it)
+    uint32_t pad[9];
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
 
@@ -81,11 +83,14 @@ inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr);
+                                  unsigned long long *d_trace = nullptr, Stage1State *h_state = nullptr);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
+// h_state: pinned host memory (device-visible); the last block to finish leaves the final Stage1State there, so the
+// host needs a stream synchronisation but no copy
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr);
+                         hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
+                         Stage1State *h_state = nullptr);
 
 }  // namespace sj

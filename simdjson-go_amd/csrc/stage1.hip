@@ -37,7 +37,29 @@ struct S1Aux {
     u8 *unit_h;
     u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
+    Stage1State *host; // pinned host memory or null: the last block to finish copies the final state there
 };
+// End of a block (after a block barrier: every wave has issued its last update of *st).  The block that finds all the
+// others finished publishes the state -- and the last message byte -- to the host record.
+__device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len) {
+    if (!aux.host) return;
+    // every update of *st is an agent-scope atomic (performed at the memory side, like the tile descriptors): once
+    // this wave's are acknowledged and the block has met, one relaxed counter tells which block is the last
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            Stage1State *h = aux.host;
+            h->error = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h->total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h->ends_in_quote = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h->tile_counter = __hip_atomic_load(&st->tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h->last_byte = len ? msg[len - 1] : 0u;
+            h->done = d + 1u;
+        }
+    }
+}
 // per-phase timeline of a tile for every wave (profiling builds of the kernels, sjhip_stage1_trace):
 //   0 phase A begins   1 phase A done (arrival)   2 serial section done (the wave that ran it; 0 otherwise)
 //   3 state of the tile known (past the second barrier / the result flag)   4 flatten done   5 HW_ID
@@ -180,10 +202,15 @@ __global__ __launch_bounds__(256) void k_s1_prepare(const u8 *__restrict__ base,
     for (u64 i = gid; i < desc_words; i += gsz) desc[i] = 0;
     if (blockIdx.x < 2 && nu != 0) {
         const u64 unit = blockIdx.x == 0 ? 0 : (u64)nu - 1;
-        for (u32 i = threadIdx.x; i < 4096; i += 256) {
-            const u64 off = unit * 4096 + i;
-            edge[blockIdx.x * 4096 + i] = (off >= lead && off < end) ? base[off] : (u8)0x20;
-        }
+        // 16 bytes per thread, all loads in flight together (byte loads: only message bytes are touched)
+        const u64 off = unit * 4096 + (u64)threadIdx.x * 16;
+        u32 w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+        u8 b[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) b[i] = (off + i >= lead && off + i < end) ? base[off + i] : (u8)0x20;
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((u32)b[i] << (8 * (i & 3)));
+        *reinterpret_cast<uint4 *>(edge + blockIdx.x * 4096 + threadIdx.x * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -551,7 +578,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
     u32 t_cur = uniform(s_ticket[0]);
-    if (t_cur >= num_tiles) return;
+    if (t_cur >= num_tiles) {
+        block_done(st, aux, base + lead, len);
+        return;
+    }
 
     // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
     // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.  Per tile
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                 res[2] = (u32)BASE;
                 res[3] = (u32)(BASE >> 32);
                 if (has_next) s_ticket[(it + 3u) & 3u] = tk;
-                if (t_cur == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
+                if (t_cur == num_tiles - 1) __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
         }
@@ -644,7 +674,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
                                        tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
-        if (t_cur == num_tiles - 1 && tid == 0) st->total = tile_end;
+        if (t_cur == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
             aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
@@ -660,6 +690,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         us = us_n;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+    block_done(st, aux, base + lead, len);
 }
 
 // ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
@@ -721,7 +752,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     if (tid == 0) s_tk[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
     const u32 t_first = uniform(s_tk[0]);
-    if (t_first >= num_tiles) return;
+    if (t_first >= num_tiles) {
+        block_done(st, aux, base + lead, len);
+        return;
+    }
     UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
@@ -801,7 +835,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             res[1] = pm0;
             res[2] = (u32)BASE;
             res[3] = (u32)(BASE >> 32);
-            if (tj == num_tiles - 1) st->ends_in_quote = (G ^ P0) & 1u;
+            if (tj == num_tiles - 1) __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&s_resflag[j & 3u], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         trace_put<TRACE>(aux.trace, tj, WAVES, wave, lane, 2);
@@ -882,13 +916,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
                                        wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
                                        AUX ? aux.kind : nullptr, base + lead, s_klut);
-        if (tf == num_tiles - 1 && tid == 0) st->total = tile_end;
+        if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
             aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
                 (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+    block_done(st, aux, base + lead, len);
 }
 
 // ---- launcher --------------------------------------------------------------------------
@@ -1007,7 +1042,8 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                                  hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace) {
+                                  hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
+                                  Stage1State *h_state) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -1019,7 +1055,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace)};
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state};
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = a.qm;
@@ -1073,10 +1109,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 }
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf, u8 *d_kind) {
+                         hipStream_t stream, void *aux_buf, u8 *d_kind, Stage1State *h_state) {
     hipError_t e = stage1_prepare(d_msg, len, ws, stream);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
 }
 
 }  // namespace sj
