@@ -118,75 +118,211 @@ __global__ __launch_bounds__(256) void k_q_mark(QView q, QRec o) {
     o.first_str[r] = fs;
 }
 
-// ---- pass 2: one block.  Exclusive prefixes of words / string bytes over the records, and the Strings.B range of
-// every record: [its first string, the first string of any later record) -- strings are laid out in document order.
-__global__ __launch_bounds__(1024) void k_q_scan(QView q, QRec o) {
-    __shared__ unsigned long long s_w[1024], s_c[1024], s_b[1024];
-    __shared__ u32 s_first[1024];
-    const u32 n = q.R + 1, tid = threadIdx.x;
-    const u32 per = (n + 1023u) / 1024u;
-    const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    unsigned long long w = 0, c = 0;
-    u32 first = NONE32;
-    for (u32 r = lo; r < hi; r++) {
-        w += o.words[r];
-        c += o.flag[r];
-        if (first == NONE32) first = o.first_str[r];
+// ---- pass 2: exclusive prefixes of words / string bytes over the records, and the Strings.B range of every record:
+// [its first string, the first string of any later record) -- strings are laid out in document order, so "the first
+// string of any later record" is a minimum over the records behind it.  Tiles of 1024 records (256 threads x 4
+// consecutive records), tile sums scanned by one block, then applied: sums -> scan -> apply (word prefixes, string
+// lengths and their tile sums) -> scan -> apply (string prefixes).
+static constexpr int QT = 256, QI = 4, QTILE = QT * QI;
+struct QTiles {
+    unsigned long long *tw;  // [tiles] tape words of the tile's matching records -> their exclusive prefix
+    unsigned long long *tb;  // [tiles] Strings.B bytes of the tile's matching records -> their exclusive prefix
+    u32 *tc;                 // [tiles] matching records of the tile
+    u32 *tf;                 // [tiles] first string of the tile -> first string of any later tile
+};
+__device__ __forceinline__ unsigned long long q_block_excl_sum(unsigned long long v, unsigned long long *s_w, int tid,
+                                                                unsigned long long *total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned long long o = (unsigned long long)__shfl_up((long long)incl, s, 64);
+        if (lane >= s) incl += o;
     }
-    s_w[tid] = w;
-    s_c[tid] = c;
-    s_first[tid] = first;
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    if (tid == 0) {  // 1024 partial sums: serial is fine next to the record walks
-        unsigned long long aw = 0, ac = 0;
-        for (int k = 0; k < 1024; k++) {
-            const unsigned long long tw = s_w[k], tc = s_c[k];
-            s_w[k] = aw;
-            aw += tw;
-            ac += tc;
-        }
-        o.totals[0] = ac;
-        o.totals[1] = aw;
-        u32 nxt = (u32)q.strings_len;  // s_first[k] := the first string behind chunk k
-        for (int k = 1023; k >= 0; k--) {
-            const u32 f = s_first[k];
-            s_first[k] = nxt;
-            if (f != NONE32) nxt = f;
-        }
+    unsigned long long before = 0, tot = 0;
+    for (int w = 0; w < QT / 64; w++) {
+        if (w < wave) before += s_w[w];
+        tot += s_w[w];
     }
+    if (total) *total = tot;
     __syncthreads();
-    u32 nxt = s_first[tid];  // Strings.B ranges, walking the chunk backwards
-    unsigned long long b = 0;
-    for (u32 r = hi; r-- > lo;) {
-        const u32 f = o.first_str[r];
-        u32 len = 0;
-        if (f != NONE32) {
-            len = nxt - f;
-            nxt = f;
-        }
-        len = o.flag[r] ? len : 0u;
-        o.s_len[r] = len;
-        b += len;
+    return before + incl - v;
+}
+// minimum over the threads behind this one (NONE32 if there is none)
+__device__ __forceinline__ u32 q_block_excl_suffix_min(u32 v, u32 *s_w, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const u32 o = (u32)__shfl_down((int)incl, s, 64);
+        if (lane + s < 64) incl = o < incl ? o : incl;
     }
-    s_b[tid] = b;
+    if (lane == 0) s_w[wave] = incl;
     __syncthreads();
+    u32 after = NONE32;
+    for (int w = 0; w < QT / 64; w++)
+        if (w > wave) after = s_w[w] < after ? s_w[w] : after;
+    u32 ex = (u32)__shfl_down((int)incl, 1, 64);
+    if (lane == 63) ex = NONE32;
+    __syncthreads();
+    return ex < after ? ex : after;
+}
+template <typename T>
+__device__ __forceinline__ void q_load4(const T *p, u32 base, u32 n, T fill, T (&v)[QI]) {
+#pragma unroll
+    for (int k = 0; k < QI; k++) v[k] = base + k < n ? p[base + k] : fill;  // consecutive: 16 bytes per thread
+}
+
+__global__ __launch_bounds__(QT) void k_q_tile_sums(QRec o, u32 n, QTiles T) {
+    __shared__ unsigned long long s_w[QT / 64];
+    __shared__ u32 s_m[QT / 64];
+    const int tid = threadIdx.x;
+    const u32 base = blockIdx.x * QTILE + (u32)tid * QI;
+    u32 w[QI], fl[QI], f[QI];
+    q_load4(o.words, base, n, 0u, w);
+    q_load4(o.flag, base, n, 0u, fl);
+    q_load4(o.first_str, base, n, NONE32, f);
+    unsigned long long tw = 0, tc = 0;
+    u32 mn = NONE32;
+#pragma unroll
+    for (int k = 0; k < QI; k++) {
+        tw += w[k];
+        tc += fl[k];
+        mn = f[k] < mn ? f[k] : mn;
+    }
+    unsigned long long tot_w = 0, tot_c = 0;
+    (void)q_block_excl_sum(tw, s_w, tid, &tot_w);
+    (void)q_block_excl_sum(tc, s_w, tid, &tot_c);
+    const u32 later = q_block_excl_suffix_min(mn, s_m, tid);
     if (tid == 0) {
-        unsigned long long ab = 0;
-        for (int k = 0; k < 1024; k++) {
-            const unsigned long long tb = s_b[k];
-            s_b[k] = ab;
-            ab += tb;
+        T.tw[blockIdx.x] = tot_w;
+        T.tc[blockIdx.x] = (u32)tot_c;
+        T.tf[blockIdx.x] = mn < later ? mn : later;
+    }
+}
+
+// one block over the tiles.  FIRST: tw -> exclusive prefix, tf -> first string of any later tile, totals[0], [1];
+// otherwise tb -> exclusive prefix, totals[2]
+template <bool FIRST>
+__global__ __launch_bounds__(1024) void k_q_tile_scan(QTiles T, u32 tiles, unsigned long long *totals, u32 strings_len) {
+    __shared__ unsigned long long s_a[1024], s_c[1024];
+    __shared__ u32 s_f[1024];
+    const u32 tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
+    const u32 lo = tid * per < tiles ? tid * per : tiles, hi = lo + per < tiles ? lo + per : tiles;
+    unsigned long long *col = FIRST ? T.tw : T.tb;
+    unsigned long long a = 0, c = 0;
+    u32 first = NONE32;
+    for (u32 t = lo; t < hi; t++) {
+        a += col[t];
+        if (FIRST) {
+            c += T.tc[t];
+            first = T.tf[t] < first ? T.tf[t] : first;
         }
-        o.totals[2] = ab;
+    }
+    s_a[tid] = a;
+    s_c[tid] = c;
+    s_f[tid] = first;
+    __syncthreads();
+    if (tid == 0) {  // 1024 partials: serial is fine
+        unsigned long long ra = 0, rc = 0;
+        for (int k = 0; k < 1024; k++) {
+            const unsigned long long va = s_a[k];
+            s_a[k] = ra;
+            ra += va;
+            rc += s_c[k];
+        }
+        if (FIRST) {
+            totals[0] = rc;
+            totals[1] = ra;
+            u32 nxt = strings_len;
+            for (int k = 1023; k >= 0; k--) {
+                const u32 v = s_f[k];
+                s_f[k] = nxt;
+                nxt = v < nxt ? v : nxt;
+            }
+        } else {
+            totals[2] = ra;
+        }
     }
     __syncthreads();
-    unsigned long long pw = s_w[tid], pb = s_b[tid];
-    for (u32 r = lo; r < hi; r++) {
-        const u32 tw = o.words[r];
-        o.words[r] = (u32)pw;
-        o.s_pre[r] = (u32)pb;
-        pw += tw;
-        pb += o.s_len[r];
+    unsigned long long run = s_a[tid];
+    for (u32 t = lo; t < hi; t++) {
+        const unsigned long long v = col[t];
+        col[t] = run;
+        run += v;
+    }
+    if (FIRST) {
+        u32 nxt = s_f[tid];
+        for (u32 t = hi; t > lo; t--) {
+            const u32 v = T.tf[t - 1];
+            T.tf[t - 1] = nxt;
+            nxt = v < nxt ? v : nxt;
+        }
+    }
+}
+
+// words[r] := new index of the record's open root; s_len[r]; tile sums of s_len
+__global__ __launch_bounds__(QT) void k_q_tile_apply1(QRec o, u32 n, QTiles T) {
+    __shared__ unsigned long long s_w[QT / 64];
+    __shared__ u32 s_m[QT / 64];
+    const int tid = threadIdx.x;
+    const u32 base = blockIdx.x * QTILE + (u32)tid * QI;
+    u32 w[QI], fl[QI], f[QI];
+    q_load4(o.words, base, n, 0u, w);
+    q_load4(o.flag, base, n, 0u, fl);
+    q_load4(o.first_str, base, n, NONE32, f);
+    unsigned long long tw = 0;
+    u32 mn = NONE32;
+#pragma unroll
+    for (int k = 0; k < QI; k++) {
+        tw += w[k];
+        mn = f[k] < mn ? f[k] : mn;
+    }
+    unsigned long long pw = T.tw[blockIdx.x] + q_block_excl_sum(tw, s_w, tid, nullptr);
+    const u32 later = q_block_excl_suffix_min(mn, s_m, tid), behind_tile = T.tf[blockIdx.x];
+    u32 nxt = later < behind_tile ? later : behind_tile;  // first string of any record behind this thread's four
+    u32 len[QI];
+    unsigned long long tb = 0;
+#pragma unroll
+    for (int k = QI - 1; k >= 0; k--) {
+        u32 l = 0;
+        if (f[k] != NONE32) {
+            l = nxt - f[k];
+            nxt = f[k];
+        }
+        len[k] = fl[k] ? l : 0u;
+        tb += len[k];
+    }
+#pragma unroll
+    for (int k = 0; k < QI; k++) {
+        if (base + k < n) {
+            o.words[base + k] = (u32)pw;
+            o.s_len[base + k] = len[k];
+        }
+        pw += w[k];
+    }
+    unsigned long long tot_b = 0;
+    (void)q_block_excl_sum(tb, s_w, tid, &tot_b);
+    if (tid == 0) T.tb[blockIdx.x] = tot_b;
+}
+
+// s_pre[r] := new Strings.B offset of the record's first string
+__global__ __launch_bounds__(QT) void k_q_tile_apply2(QRec o, u32 n, QTiles T) {
+    __shared__ unsigned long long s_w[QT / 64];
+    const int tid = threadIdx.x;
+    const u32 base = blockIdx.x * QTILE + (u32)tid * QI;
+    u32 len[QI];
+    q_load4(o.s_len, base, n, 0u, len);
+    unsigned long long tb = 0;
+#pragma unroll
+    for (int k = 0; k < QI; k++) tb += len[k];
+    unsigned long long pb = T.tb[blockIdx.x] + q_block_excl_sum(tb, s_w, tid, nullptr);
+#pragma unroll
+    for (int k = 0; k < QI; k++) {
+        if (base + k < n) o.s_pre[base + k] = (u32)pb;
+        pb += len[k];
     }
 }
 
@@ -305,7 +441,9 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     ctx->ser_valid = 0;  // the serializer's columns live in the same arenas
     ctx->ms_valid = 0;
     const size_t per = ((size_t)n * 4 + 255) / 256 * 256;
-    rc = arena_reserve(ctx, ctx->d_q, per * 5 + 256);
+    const u32 tiles = (n + QTILE - 1) / QTILE;
+    const size_t per_t = ((size_t)tiles * 8 + 255) / 256 * 256;
+    rc = arena_reserve(ctx, ctx->d_q, per * 5 + per_t * 3 + 256);
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_qtape, ctx->tape_len * 8 + 64);
     if (rc) return rc;
@@ -324,8 +462,20 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     o.s_len = (u32 *)w;
     w += per;
     o.s_pre = (u32 *)w;
+    w += per;
+    QTiles T;
+    T.tw = (unsigned long long *)w;
+    w += per_t;
+    T.tb = (unsigned long long *)w;
+    w += per_t;
+    T.tc = (u32 *)w;
+    T.tf = (u32 *)(w + per_t / 2);
     hipLaunchKernelGGL(k_q_mark, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, o);
-    hipLaunchKernelGGL(k_q_scan, dim3(1), dim3(1024), 0, ctx->stream, q, o);
+    hipLaunchKernelGGL(k_q_tile_sums, dim3(tiles), dim3(QT), 0, ctx->stream, o, n, T);
+    hipLaunchKernelGGL(k_q_tile_scan<true>, dim3(1), dim3(1024), 0, ctx->stream, T, tiles, o.totals, (u32)q.strings_len);
+    hipLaunchKernelGGL(k_q_tile_apply1, dim3(tiles), dim3(QT), 0, ctx->stream, o, n, T);
+    hipLaunchKernelGGL(k_q_tile_scan<false>, dim3(1), dim3(1024), 0, ctx->stream, T, tiles, o.totals, (u32)q.strings_len);
+    hipLaunchKernelGGL(k_q_tile_apply2, dim3(tiles), dim3(QT), 0, ctx->stream, o, n, T);
     HIPCHK(hipGetLastError(), "filter launch");
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
     HIPCHK(hipMemcpyAsync(h, o.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");

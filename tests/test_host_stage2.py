@@ -143,6 +143,30 @@ def test_number_parsing_against_strtod(L):
         nbig += used
         assert got == ref(b), s[:60]
     assert nbig > 1000  # the big-integer tie-break path was exercised
+    # the integer fast path (parse_int_fast) and its hand-over to the general routine: every digit count around the
+    # 9 / 18 / 19 / 20 digit limits, signs, leading zeros, every kind of byte behind the number, the 32-byte window
+    ends = [b",", b"}", b"]", b" ", b"\t", b"\r", b"\n", b":", b".5,", b"e3,", b"E+2,", b"+,", b"-,", b"a,", b"\x00,", b"", b"0,",
+            b".,", b"e,"]
+    for nd in range(0, 23):
+        for trial in range(40):
+            digits = "".join(rnd.choice("0123456789") for _ in range(nd))
+            if trial % 4 == 0 and nd:
+                digits = rnd.choice("123456789") + digits[1:]
+            if trial % 8 == 1 and nd:
+                digits = "9" * nd
+            for sign in (b"", b"-", b"+"):
+                for e in ends:
+                    b = sign + digits.encode() + e
+                    got, _ = mine(b)
+                    assert got == ref(b), b
+                    padded = b + b" " * 40
+                    got, _ = mine(padded)
+                    assert got == ref(padded), padded
+    for v in (2**63 - 1, 2**63, 2**63 + 1, 2**64 - 1, 2**64, 10**18 - 1, 10**18, 10**9 - 1, 10**9, 10**17, 999999999999999999):
+        for sgn in ("", "-"):
+            b = (sgn + str(v)).encode() + b","
+            got, _ = mine(b)
+            assert got == ref(b), b
 
 
 def test_numbers_cut_by_the_32_byte_window(L):
