@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o s1 -- python $REPO/tools/s1_time.py > $OUT/p$i.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o s1 -- python $REPO/tools/s1_time.py > $OUT/p$i.log 2>&1
 done
 cd $REPO && python tools/summarize_prof.py $OUT $OUT/summary.txt > /dev/null
 grep -E "stage1_kernel" $OUT/summary.txt | sed 's/void sj::stage1_kernel<\([0-9, ]*\)>.*un /k<\1> /'

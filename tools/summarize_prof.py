@@ -21,6 +21,28 @@ def main(root, out):
                 lines.append(f"  kernel {name[:70]:70s} calls={calls} avg_us={avg:.3f} total_us={total:.1f} pct={pct:.1f}")
         except sqlite3.Error as e:
             lines.append(f"  (no top_kernels: {e})")
+        # one kernel name can cover launches on documents of very different sizes (the bench runs stage 1 on configs[1]
+        # and on a 1 GiB document): split a kernel's dispatches into duration groups when they fall apart by > 2x
+        try:
+            per_k = defaultdict(list)
+            for name, dur in cur.execute("select name,(end-start)/1000.0 from kernels"):
+                per_k[name].append(dur)
+            for name, v in per_k.items():
+                v.sort()
+                groups, cur_g = [], [v[0]]
+                for x in v[1:]:
+                    if x > 2.0 * cur_g[0]:
+                        groups.append(cur_g)
+                        cur_g = [x]
+                    else:
+                        cur_g.append(x)
+                groups.append(cur_g)
+                if len(groups) > 1:
+                    for g in groups:
+                        lines.append(f"  kernel-group {name[:70]:70s} calls={len(g)} avg_us={sum(g)/len(g):.3f} "
+                                     f"min_us={g[0]:.3f} max_us={g[-1]:.3f}")
+        except sqlite3.Error as e:
+            lines.append(f"  (no per-dispatch durations: {e})")
         try:
             per = defaultdict(lambda: defaultdict(float))
             for kname, cname, disp, val in cur.execute(
