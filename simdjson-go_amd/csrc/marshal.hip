@@ -175,6 +175,7 @@ __global__ __launch_bounds__(1024) void k_ms_scan(unsigned long long *a, unsigne
 }
 
 // ---- the tape pass: EMIT = false lengths, EMIT = true text ---------------------------------------------------------
+static constexpr u32 MS_WINDOW = 40960;  // bytes of text a tile stages in LDS (3 blocks per CU)
 template <bool EMIT>
 __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     __shared__ long long s_l[TW_THREADS / 64];
@@ -252,7 +253,14 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
         if (bad) atomicOr(&p.totals[2], 1ull);
         return;
     }
-    u8 *o = p.text + p.cnt_b[blockIdx.x] + (ex >> 16);
+    // The text of a tile is one contiguous range.  When it fits the window the threads write it into LDS (byte stores
+    // that cost a fraction of scattered global ones) and the block copies the window out with coalesced 4-byte
+    // stores; a tile with more text (long strings) writes straight to memory.
+    __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? MS_WINDOW : 16];
+    const u64 tile_bytes = tot >> 16;
+    const bool staged = tile_bytes <= MS_WINDOW;  // block-uniform
+    u8 *const gdst = p.text + p.cnt_b[blockIdx.x];
+    u8 *o = (staged ? s_text : gdst) + (ex >> 16);
     u64 si = p.cnt_s[blockIdx.x] + (ex & 0xffffu);  // ordinal of the thread's first string entry
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++) {
@@ -289,6 +297,14 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
             *o++ = (u8)t;  // { [ } ]
         }
         if (o < end) *o++ = sep_is_colon ? ':' : ',';
+    }
+    if (staged) {
+        __syncthreads();
+        const u32 nb = (u32)tile_bytes, nw = nb >> 2;
+        for (u32 i = (u32)tid; i < nw; i += TW_THREADS)  // unaligned 4-byte global stores are fine on gfx950
+            *reinterpret_cast<u32 *>(gdst + 4 * i) = *reinterpret_cast<const u32 *>(s_text + 4 * i);
+        const u32 tail = nw * 4 + (u32)tid;
+        if (tail < nb) gdst[tail] = s_text[tail];
     }
 }
 
