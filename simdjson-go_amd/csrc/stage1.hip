@@ -476,27 +476,30 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
         // copies the first cnt staged positions to out_pos[gd ...] (and their kinds to kind_out)
         auto copy_out = [&](u32 cnt, u64 gd) {
             if (kind_out) {  // whole parse: the kind of every token next to its position (sj_stage2.h)
-                for (u32 i0 = 0; i0 < cnt; i0 += 256) {  // four gathers in flight per lane; the tile's bytes are still in L2
-                    u32 at[4];
-                    u8 b[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const u32 i = i0 + q * 64 + lane;
-                        at[q] = stage[i < cnt ? i : 0];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) b[q] = msg0[at[q]];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const u32 i = i0 + q * 64 + lane;
-                        if (i < cnt && (fits || gd + i < pos_cap)) {
-                            out_pos[gd + i] = at[q];
-                            kind_out[gd + i] = s_klut[b[q]];
-                        }
+                // four consecutive positions per lane: one 16-byte LDS read, four gathers in flight (the tile's bytes
+                // are still in L2), one 16-byte store of the positions and one 4-byte store of their kinds (neither is
+                // aligned to its size in memory: fine on gfx950)
+                const u32 c4 = (fits ? cnt : 0u) & ~3u;
+                for (u32 i = (u32)lane * 4u; i < c4; i += 256u) {
+                    const uint4 at = *reinterpret_cast<const uint4 *>(stage + i);
+                    const u8 b0 = msg0[at.x], b1 = msg0[at.y], b2 = msg0[at.z], b3 = msg0[at.w];
+                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = at;
+                    const u32 k4 = (u32)s_klut[b0] | ((u32)s_klut[b1] << 8) | ((u32)s_klut[b2] << 16) | ((u32)s_klut[b3] << 24);
+                    *reinterpret_cast<u32 *>(kind_out + gd + i) = k4;
+                }
+                for (u32 i = c4 + (u32)lane; i < cnt; i += 64) {  // the last <= 3 (or, without room for all, everything)
+                    if (fits || gd + i < pos_cap) {
+                        const u32 at = stage[i];
+                        out_pos[gd + i] = at;
+                        kind_out[gd + i] = s_klut[msg0[at]];
                     }
                 }
             } else if (fits) {
-                for (u32 i = lane; i < cnt; i += 64) out_pos[gd + i] = stage[i];
+                // 16 bytes per lane (the positions are only 4-byte aligned in memory: fine on gfx950), then the rest
+                const u32 c4 = cnt & ~3u;
+                for (u32 i = (u32)lane * 4u; i < c4; i += 256u)
+                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = *reinterpret_cast<const uint4 *>(stage + i);
+                if (c4 + (u32)lane < cnt) out_pos[gd + c4 + lane] = stage[c4 + lane];
             } else {
                 for (u32 i = lane; i < cnt; i += 64)
                     if (gd + i < pos_cap) out_pos[gd + i] = stage[i];
