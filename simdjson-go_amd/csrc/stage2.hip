@@ -403,10 +403,10 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     __builtin_amdgcn_wave_barrier();
     if (g + total > p.strings_cap) return;
     u8 *dst = p.strings + g;
-    const u32 words = total >> 2;
-    for (u32 i = lane; i < words; i += 64)  // unaligned 4-byte global stores are fine on gfx950
-        *reinterpret_cast<u32 *>(dst + 4 * i) = *reinterpret_cast<const u32 *>(&s_io[wave][4 * i]);
-    const u32 tail = words * 4 + lane;
+    const u32 q16 = total >> 4;
+    for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
+        *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
+    const u32 tail = q16 * 16 + lane;
     if (tail < total) dst[tail] = s_io[wave][tail];
 }
 
