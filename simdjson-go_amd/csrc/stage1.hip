@@ -580,66 +580,52 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // (one atomic per block), the next two while phase A of the first tile is already running.
     if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
-    u32 t_cur = uniform(s_ticket[0]);
-    if (t_cur >= num_tiles) {
+    const u32 t_first = uniform(s_ticket[0]);
+    if (t_first >= num_tiles) {
         block_done(st, aux, base + lead, len);
         return;
     }
-
-    // Two tiles in flight per block: phase A of the next tile runs before the look-back of the current
-    // one, which hides the wait for the slowest predecessor; the chunk loads run one pass ahead.  Per tile
-    // there is one block barrier; what is serial per tile (aggregate, ticket, look-back) is done by wave 0
-    // beside the other waves' work (see the loop).
     UnitRegs pf;
     {
-        const u64 un = tile_unit<UNITS>(tm, t_cur, wave);
+        const u64 un = tile_unit<UNITS>(tm, t_first, wave);
         if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
-    }
-    if (tid == 0) {
-        s_ticket[1] = atomicAdd(&st->tile_counter, 1u);
-        s_ticket[2] = atomicAdd(&st->tile_counter, 1u);
-    }
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 0);
-    phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_cur, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge);
-    trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 1);
-    __syncthreads();
-    u32 t_nxt = uniform(s_ticket[1]);
-    if (t_nxt < num_tiles) {
-        const u64 un = tile_unit<UNITS>(tm, t_nxt, wave);
-        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
-    }
-    u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // of the current tile; meaningful in wave 0 only
-    if (wave == 0) {
-        tile_aggregate<UNITS>(s_unit[0], lane, P0, T00, T01, pm0);
-        if (lane == 0) desc_store(&desc[t_cur], t_cur == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
     }
 
-    // One block barrier per tile.  Iteration i: phase A of T(i+1) (wave 0 at top priority, so it is through first);
-    // wave 0 then draws nothing new but resolves the look-back of T(i), whose aggregate it published an iteration ago,
-    // while the other waves are still in phase A; barrier; wave 0 aggregates and publishes T(i+1) (a few hundred
-    // cycles into its flatten); everybody flattens T(i).  Rings: tickets 4 (T(j) in slot j & 3, the new one is
-    // written before the barrier into the slot of T(i-1)), look-back results 2, unit state 3, masks 2 (per wave).
-    int ms = 0, us = 0;  // mask / unit slots of t_cur
+    // One loop, one copy of phase A and of the flatten in the instruction stream (a peeled first tile made every block
+    // fetch ~9 KB more code cold at the start of every launch).  Two tiles in flight per block and one block barrier
+    // per tile.  Iteration j: every wave runs phase A of T(j) (wave 0 at top priority, so it is through first); wave 0
+    // then resolves the look-back of T(j-1), whose aggregate went out an iteration ago, while the other waves are
+    // still in phase A, and leaves the next ticket; barrier; wave 0 aggregates and publishes T(j) (a few hundred cycles
+    // into its flatten); everybody flattens T(j-1).  Rings: tickets 4 (T(k) in slot k & 3; iteration j writes T(j+2)
+    // before the barrier -- iteration 0 also T(1) -- into slots whose tiles are done), look-back results 2, unit
+    // state 3, masks 2 (private per wave).
+    u32 t_prev = 0;                         // T(j-1): the tile that is flattened in iteration j
+    u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // its aggregates; meaningful in wave 0 only
     bool err = false;
-    for (u32 it = 0;; it++) {
-        const u32 t_nn = uniform(s_ticket[(it + 2u) & 3u]);  // the tile after t_nxt
-        const bool has_next = t_nxt < num_tiles;
-        const int us_n = us == 2 ? 0 : us + 1;
-        u32 tk = 0;  // the ticket after t_nn: drawn now, it returns while phase A runs
-        if (has_next && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
-        if (has_next) {
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 0);
-            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_nxt, t_nn, t_nn < num_tiles, lane, wave, pf, s_mask[ms ^ 1][wave],
-                                            s_pre[ms ^ 1][wave], s_unit[us_n], aux, edge, wave == 0);
-            trace_put<TRACE>(aux.trace, t_nxt, WAVES, wave, lane, 1);
+    for (u32 j = 0;; j++) {
+        const bool first = j == 0;
+        const u32 t_a = uniform(s_ticket[j & 3u]);                               // phase A runs on T(j)
+        const u32 t_an = first ? 0xffffffffu : uniform(s_ticket[(j + 1u) & 3u]);  // T(j+1): its first unit is loaded behind T(j)'s last
+        const bool has_a = t_a < num_tiles;
+        const int ma = (int)(j & 1u), ua = (int)(j % 3u);        // mask / unit slot of T(j)
+        const int mf = ma ^ 1, uf = ua == 0 ? 2 : ua - 1;        // ... of T(j-1)
+        u32 tk1 = 0, tk2 = 0;  // tickets drawn now (lane 0 of wave 0); they return while phase A runs
+        if (tid == 0) {
+            if (first) tk1 = atomicAdd(&st->tile_counter, 1u);
+            if (has_a) tk2 = atomicAdd(&st->tile_counter, 1u);
         }
-        u32 *res = s_res2[it & 1u];
+        if (has_a) {
+            trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
+            phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
+                                            s_pre[ma][wave], s_unit[ua], aux, edge, wave == 0 && !first);
+            trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
+        }
+        u32 *res = s_res2[j & 1u];
         if (wave == 0) {
             u32 G = 0;
             u64 BASE = 0;
-            if (t_cur != 0) {
-                LookBack lb = {(long long)t_cur - 1, 0, 0, 0};
+            if (!first && t_prev != 0) {
+                LookBack lb = {(long long)t_prev - 1, 0, 0, 0};
                 u64 win[4];
                 lookback_load(desc, lb.j, lane, win);
                 u32 spins = 0;
@@ -653,44 +639,51 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                     }
                     lookback_load(desc, lb.j, lane, win);
                 }
-                if (lane == 0) desc_store(&desc[t_cur], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
+                if (lane == 0) desc_store(&desc[t_prev], pack_prefix(G ^ P0, BASE + (G ? T01 : T00)));
             }
             if (lane == 0) {
-                res[0] = G;
-                res[1] = pm0;
-                res[2] = (u32)BASE;
-                res[3] = (u32)(BASE >> 32);
-                if (has_next) s_ticket[(it + 3u) & 3u] = tk;
-                if (t_cur == num_tiles - 1) __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!first) {
+                    res[0] = G;
+                    res[1] = pm0;
+                    res[2] = (u32)BASE;
+                    res[3] = (u32)(BASE >> 32);
+                    if (t_prev == num_tiles - 1)
+                        __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    s_ticket[1] = tk1;
+                }
+                if (has_a) s_ticket[(j + 2u) & 3u] = tk2;
             }
-            trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 2);
+            if (!first) trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 2);
         }
         __syncthreads();
-        u32 P1 = 0, T10 = 0, T11 = 0, pm1 = 0;
-        if (wave == 0 && has_next) {
-            tile_aggregate<UNITS>(s_unit[us_n], lane, P1, T10, T11, pm1);
-            if (lane == 0) desc_store(&desc[t_nxt], pack_agg(P1, T10, T11));
+        if (wave == 0 && has_a) {  // (only wave 0 keeps the aggregates: it resolves the tile in the next iteration)
+            tile_aggregate<UNITS>(s_unit[ua], lane, P0, T00, T01, pm0);
+            if (lane == 0) desc_store(&desc[t_a], t_a == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
         }
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 3);
-        const u32 G = uniform(res[0]), pm = uniform(res[1]);
-        const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
-        u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[ms][wave], s_stage[AUX ? wave : 0], s_pre[ms][wave], s_unit[us], pm, G, BASE, t_cur, lead, lane, wave, out_pos, pos_cap,
-                                       tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr, base + lead, s_klut);
-        if (t_cur == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        trace_put<TRACE>(aux.trace, t_cur, WAVES, wave, lane, 4);
-        if (TRACE && lane == 0)
-            aux.trace[((u64)t_cur * WAVES + wave) * TRACE_WORDS + 5] =
-                (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-        if (!has_next) break;
-        P0 = P1;
-        T00 = T10;
-        T01 = T11;
-        pm0 = pm1;
-        t_cur = t_nxt;
-        t_nxt = t_nn;
-        ms ^= 1;
-        us = us_n;
+        if (first) {  // phase A of the first tile did not know the second one: its first unit goes in flight here
+            const u32 t1 = uniform(s_ticket[1]);
+            if (t1 < num_tiles) {
+                const u64 un = tile_unit<UNITS>(tm, t1, wave);
+                if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
+            }
+        } else {
+            trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 3);
+            const u32 G = uniform(res[0]), pm = uniform(res[1]);
+            const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
+            u64 tile_end = 0;
+            err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
+                                           out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr,
+                                           base + lead, s_klut);
+            if (t_prev == num_tiles - 1 && tid == 0)
+                __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
+            if (TRACE && lane == 0)
+                aux.trace[((u64)t_prev * WAVES + wave) * TRACE_WORDS + 5] =
+                    (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+            if (!has_a) break;
+        }
+        t_prev = t_a;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
     block_done(st, aux, base + lead, len);
