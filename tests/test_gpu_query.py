@@ -124,3 +124,13 @@ def test_full_size_count(ctx):  # 116 per file -> 116 000 on configs[4]
     assert ctx.count_where(b"Make", b"HOND") == 116_000
     n, pj = ctx.filter_where(b"Make", b"HOND", fetch=False)
     assert n == 116_000
+    # the filtered (Tape, Strings.B) at full size (977 tiles of the record scans): the matching lines repeat with the
+    # file, so the oracle parses the 116 of one file x 1000
+    park = fixtures.load("parking-citations")
+    want = [l for l in park.split(b"\n") if l.strip() and host_matches(l.decode("utf-8"), "Make", "HOND")]
+    assert len(want) == 116
+    ref = O.parse(b"\n".join(want * 1000), ndjson=True, copy_strings=True)
+    assert ref.rc == 0
+    n, pj = ctx.filter_where(b"Make", b"HOND")
+    assert np.array_equal(pj.Tape, ref.tape)
+    assert np.array_equal(pj.Strings, ref.strings)
