@@ -85,26 +85,42 @@ __device__ u64 escaped_length(const u8 *s, u64 len) {
     for (; k < len; k++) n += escaped_size(s[k]);
     return n;
 }
-__device__ u8 *write_escaped(u8 *o, const u8 *s, u64 len) {
+__device__ __forceinline__ u8 *write_escaped_byte(u8 *o, u8 c) {
     const char *hex = "0123456789abcdef";
-    for (u64 k = 0; k < len; k++) {
-        const u8 c = s[k];
-        const u32 sz = escaped_size(c);
-        if (sz == 1) {
-            *o++ = c;
-        } else if (sz == 2) {
-            *o++ = '\\';
-            *o++ = c == '\b' ? 'b' : c == '\f' ? 'f' : c == '\n' ? 'n' : c == '\r' ? 'r' : c == '\t' ? 't' : c;
+    const u32 sz = escaped_size(c);
+    if (sz == 1) {
+        *o++ = c;
+    } else if (sz == 2) {
+        *o++ = '\\';
+        *o++ = c == '\b' ? 'b' : c == '\f' ? 'f' : c == '\n' ? 'n' : c == '\r' ? 'r' : c == '\t' ? 't' : c;
+    } else {
+        o[0] = '\\';
+        o[1] = 'u';
+        o[2] = '0';
+        o[3] = '0';
+        o[4] = (u8)hex[c >> 4];
+        o[5] = (u8)hex[c & 15];
+        o += 6;
+    }
+    return o;
+}
+__device__ u8 *write_escaped(u8 *o, const u8 *s, u64 len) {
+    u64 k = 0;
+    for (; k + 8 <= len; k += 8) {  // eight bytes at a time while nothing needs an escape (the test of escaped_length)
+        u64 w;
+        memcpy(&w, s + k, 8);
+        const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
+        const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;
+        const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);
+        if ((ctl | q) == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (u8)(w >> (8 * j));  // (the destination has no alignment: byte stores)
+            o += 8;
         } else {
-            o[0] = '\\';
-            o[1] = 'u';
-            o[2] = '0';
-            o[3] = '0';
-            o[4] = (u8)hex[c >> 4];
-            o[5] = (u8)hex[c & 15];
-            o += 6;
+            for (int j = 0; j < 8; j++) o = write_escaped_byte(o, (u8)(w >> (8 * j)));
         }
     }
+    for (; k < len; k++) o = write_escaped_byte(o, s[k]);
     return o;
 }
 
