@@ -46,6 +46,7 @@ struct MsView {
     unsigned long long *cnt_s;   // [tiles] string entries of the tile       -> exclusive prefix
     unsigned long long *totals;  // text bytes, string entries, error flag
     const u8 *keyflag;           // [string entries] 1: the string is an object key
+    u32 *slen;                   // [n] escaped length of the string whose tag word is tape[i] (counting pass -> writing pass)
     u8 *text;
 };
 
@@ -233,7 +234,14 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
         const u32 sep = (!last_entry && nt != '}' && nt != ']' && nt != 'r') ? 1u : 0u;
         u32 l = 0;
         if (t == '"') {
-            l = 2 + (u32)escaped_length(entry_string(p, w[k]), w[k + 1]) + sep;
+            u32 el;
+            if (EMIT) {
+                el = p.slen[i];  // measured by the counting pass: no second walk over the string
+            } else {
+                el = (u32)escaped_length(entry_string(p, w[k]), w[k + 1]);
+                p.slen[i] = el;
+            }
+            l = 2 + el + sep;
             nstr++;
         } else if (t == 'l' || t == 'u' || t == 'd') {
             u8 tmp[32];
@@ -349,7 +357,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     kv.tiles = (kv.n + 4095u) / 4096u;
     const size_t per = ((size_t)p.tiles * 8 + 255) / 256 * 256, perk = ((size_t)kv.tiles * 8 + 255) / 256 * 256;
     const size_t flags = ((size_t)kv.n + 255) / 256 * 256;
-    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 3 + perk + flags);
+    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 3 + perk + flags + (size_t)p.n * 4 + 256);
     if (rc) return rc;
     char *w = (char *)ctx->d_q.p;
     p.totals = (unsigned long long *)w;
@@ -363,7 +371,9 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     kv.cnt = (unsigned long long *)w;
     w += perk;
     kv.keyflag = (u8 *)w;
+    w += flags;
     p.keyflag = kv.keyflag;
+    p.slen = (u32 *)w;
     p.text = nullptr;
     HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
     // keys from the token array of the parse
