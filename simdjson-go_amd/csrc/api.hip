@@ -128,20 +128,29 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    // the last block of the kernel leaves the final state (and the last message byte) in pinned host memory: one
-    // stream synchronisation, no copy kernels behind the launch
-    Stage1State *hs = (Stage1State *)ctx->h_scratch;
-    hs->done = 0;
-    HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind, hs),
-           "stage1 launch");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
-    if (hs->done == 0) {  // (a message without tiles never launches the kernel)
-        memset(hs, 0, sizeof *hs);
-        if (!have_last && len > 0) {
-            uint8_t *hlast = ctx->h_scratch + 128;
-            HIPCHK(hipMemcpy(hlast, (const uint8_t *)d_msg + len - 1, 1, hipMemcpyDeviceToHost), "D2H last byte");
-            hs->last_byte = *hlast;
+    // the last block of the kernel leaves the packed result (count, flags, the last message byte) in one word of pinned
+    // host memory: one stream synchronisation, no copy kernels behind the launch.  (Polling the word instead of
+    // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
+    // would hand positions to other streams before they are visible there.)
+    Stage1State hs_v;
+    Stage1State *hs = &hs_v;
+    memset(hs, 0, sizeof *hs);
+    if (len > 0) {
+        volatile unsigned long long *hw = (volatile unsigned long long *)ctx->h_scratch;
+        *hw = 0;
+        HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
+                             (unsigned long long *)ctx->h_scratch),
+               "stage1 launch");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
+        const unsigned long long word = *hw;
+        if (!(word & S1_HOST_VALID)) {
+            ctx_set_error(ctx, "stage-1 kernel left no result");
+            return SJHIP_ERR_HIP;
         }
+        hs->total = word & S1_HOST_TOTAL_MASK;
+        hs->error = ((word & S1_HOST_ERROR) ? 1u : 0u) | ((word & S1_HOST_INTERNAL) ? 0x80000000u : 0u);
+        hs->ends_in_quote = (word & S1_HOST_IN_QUOTE) ? 1u : 0u;
+        hs->last_byte = (uint32_t)((word >> S1_HOST_LAST_SHIFT) & 0xffu);
     }
     if (!have_last) last_byte = (uint8_t)hs->last_byte;
     ctx->s1 = *hs;

@@ -18,6 +18,10 @@ struct Stage1State {
     uint32_t pad[9];
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
+// the packed result word the last block of stage 1 stores to pinned host memory
+static constexpr uint64_t S1_HOST_VALID = 1ull << 63, S1_HOST_INTERNAL = 1ull << 62, S1_HOST_ERROR = 1ull << 61,
+                          S1_HOST_IN_QUOTE = 1ull << 60, S1_HOST_TOTAL_MASK = (1ull << 40) - 1;
+static constexpr int S1_HOST_LAST_SHIFT = 48;  // 8 bits: msg[len - 1]
 
 // stage-2 totals and flags (zeroed before every launch)
 struct S2State {
@@ -83,14 +87,14 @@ inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr, Stage1State *h_state = nullptr);
+                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
-// h_state: pinned host memory (device-visible); the last block to finish leaves the final Stage1State there, so the
-// host needs a stream synchronisation but no copy
+// h_state: one 8-byte word of pinned host memory (device-visible, zeroed by the caller); the last block to finish stores
+// the packed result there (S1_HOST_*) in one store: the host needs a stream synchronisation but no copy
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                         Stage1State *h_state = nullptr);
+                         unsigned long long *h_state = nullptr);
 
 }  // namespace sj

@@ -37,7 +37,7 @@ struct S1Aux {
     u8 *unit_h;
     u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
-    Stage1State *host; // pinned host memory or null: the last block to finish copies the final state there
+    unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
 };
 // End of a block (after a block barrier: every wave has issued its last update of *st).  The block that finds all the
 // others finished publishes the state -- and the last message byte -- to the host record.
@@ -50,13 +50,16 @@ __device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, co
     if (threadIdx.x == 0) {
         const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d == gridDim.x - 1) {
-            Stage1State *h = aux.host;
-            h->error = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h->total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h->ends_in_quote = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h->tile_counter = __hip_atomic_load(&st->tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h->last_byte = len ? msg[len - 1] : 0u;
-            h->done = d + 1u;
+            // the whole result in ONE 8-byte store (the host polls this word; several stores would need a system-scope
+            // release, i.e. an L2 write-back, to arrive in order): S1_HOST_* in sj_device.h
+            const u32 err = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 eiq = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 word = S1_HOST_VALID | ((err & 0x80000000u) ? S1_HOST_INTERNAL : 0) | ((err & 1u) ? S1_HOST_ERROR : 0) |
+                             (eiq ? S1_HOST_IN_QUOTE : 0) | ((u64)(len ? msg[len - 1] : 0u) << S1_HOST_LAST_SHIFT) |
+                             (total & S1_HOST_TOTAL_MASK);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(aux.host), (unsigned long long)word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1039,7 +1042,7 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                                   hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
-                                  Stage1State *h_state) {
+                                  unsigned long long *h_state) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -1105,7 +1108,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 }
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf, u8 *d_kind, Stage1State *h_state) {
+                         hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state) {
     hipError_t e = stage1_prepare(d_msg, len, ws, stream);
     if (e != hipSuccess) return e;
     return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
