@@ -50,8 +50,8 @@ __device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, co
     if (threadIdx.x == 0) {
         const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d == gridDim.x - 1) {
-            // the whole result in ONE 8-byte store (the host polls this word; several stores would need a system-scope
-            // release, i.e. an L2 write-back, to arrive in order): S1_HOST_* in sj_device.h
+            // the whole result in ONE 8-byte store (several stores would need a system-scope release, i.e. an L2
+            // write-back, to be ordered among themselves): S1_HOST_* in sj_device.h
             const u32 err = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u64 total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 eiq = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -296,8 +296,9 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 // ---- phase A: everything that does not need the state in front of the tile ----------------
 // One pass = one 64-byte chunk per lane.  The two candidate structural masks of every chunk go to
 // the wave's private LDS window m[pass][outside|inside][lane], the lane's inclusive structural counts
-// to pre[pass][lane].  While pass k is being computed the loads of pass k+1 are in flight (issued as
-// soon as the chunk registers are dead).
+// to pre[pass][lane].  While pass k is being computed the loads of pass k+1 (or of pass 0 of the next tile) are in
+// flight: they are issued at the start of pass k, before its classification.  TOP: the wave keeps the highest issue
+// priority through the whole phase (wave 0 of the barrier kernels: it has the look-back to resolve afterwards).
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
