@@ -137,6 +137,9 @@ int sjhip_fetch_marshaled(sjhip_ctx *ctx, uint8_t *dst);
  *              fails returns its error code (SJHIP_ERR_STAGE1 / _STAGE2 / ...), which ends the stream like the
  *              reference's first Stream{Error}: later calls return SJHIP_ERR_STREAM_CLOSED.  SJHIP_STREAM_EMPTY when
  *              nothing is outstanding (the caller reports io.EOF once its reader is exhausted).
+ *   ready    : 1 if the oldest outstanding block has finished, i.e. sjhip_stream_next would return at once, else 0
+ *              (a single-threaded caller drains finished blocks with it before every blocking read of its input,
+ *              so that results are not withheld while the reader waits for more data)
  * One thread may submit while another takes results. */
 typedef struct sjhip_stream sjhip_stream;
 typedef struct sjhip_stream_result {
@@ -160,6 +163,7 @@ int sjhip_stream_submit(sjhip_stream *s, size_t len);
 int sjhip_stream_cancel(sjhip_stream *s); /* hand the acquired block back unused */
 int sjhip_stream_submit_copy(sjhip_stream *s, const uint8_t *block, size_t len);
 int sjhip_stream_next(sjhip_stream *s, sjhip_stream_result *out);
+int sjhip_stream_ready(sjhip_stream *s);
 int sjhip_stream_release(sjhip_stream *s);
 
 /* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------

@@ -119,6 +119,16 @@ static int stage1_verdict(const Stage1State &st, size_t len, uint8_t last_byte) 
     return last_byte == '}' || last_byte == ']';
 }
 
+// A stage-1-only call re-uses (and may re-allocate) the arenas a device-resident parse result lives in -- the message
+// copy, the positions with the token kinds behind them: queries, the serializer and MarshalJSON must not run on what
+// is left (they return SJHIP_ERR_ARG until the next parse).
+static void invalidate_result(sjhip_ctx *ctx) {
+    ctx->q_valid = ctx->ser_valid = ctx->ms_valid = 0;
+    ctx->pending = 0;
+    ctx->q_tape_len = ctx->q_strings_len = 0;
+    ctx->f_valid = 0;
+}
+
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                           uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind) {
     if (len >= 0xffffffc0ull) {
@@ -166,12 +176,14 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
 int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                         size_t *n, int *ok) {
     if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
+    invalidate_result(ctx);
     return stage1_run_device(ctx, d_msg, len, ndjson, d_pos, pos_cap, 0, 0, n, ok);
 }
 
 int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t pos_cap,
                  size_t *n, int *ok) {
     if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
+    invalidate_result(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_msg, len + 128);
     if (rc) return rc;
@@ -192,6 +204,7 @@ int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uin
 int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                       int iters, float *ms_per_launch) {
     if (!ctx || iters <= 0 || !ms_per_launch) return SJHIP_ERR_ARG;
+    invalidate_result(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
@@ -220,6 +233,7 @@ int sjhip_stage1_set_variant(int variant) { return stage1_set_variant(variant); 
 int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_pos, size_t pos_cap, uint64_t *trace_out,
                        size_t trace_cap_words, unsigned *tiles, int *waves, int *words) {
     if (!ctx || !trace_out || !tiles || !waves || !words) return SJHIP_ERR_ARG;
+    invalidate_result(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t lead = (size_t)(reinterpret_cast<uintptr_t>(d_msg) & 63);
     const size_t nw = stage1_trace_words(len, lead, tiles, waves);

@@ -345,6 +345,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->ser_valid = 0;  // shares d_q with the serializer and the filter
     ctx->q_tape_len = ctx->q_strings_len = 0;
+    ctx->f_valid = 0;
     MsView p;
     p.tape = (const u64 *)ctx->d_tape.p;
     p.n = ctx->tape_len;

@@ -27,6 +27,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->q_valid = 0;
     ctx->ser_valid = 0;
     ctx->ms_valid = 0;
+    ctx->f_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // One position (4 B) and one kind (1 B) per message byte is the worst case (every byte a structural): 5 bytes per

@@ -440,6 +440,7 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->ser_valid = 0;  // the serializer's columns live in the same arenas
     ctx->ms_valid = 0;
+    ctx->f_valid = 0;
     const size_t per = ((size_t)n * 4 + 255) / 256 * 256;
     const u32 tiles = (n + QTILE - 1) / QTILE;
     const size_t per_t = ((size_t)tiles * 8 + 255) / 256 * 256;
@@ -482,6 +483,7 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     HIPCHK(hipStreamSynchronize(ctx->stream), "filter sync");
     ctx->q_tape_len = (size_t)h[1];
     ctx->q_strings_len = (size_t)h[2];
+    ctx->f_valid = 1;
     if (n_records) *n_records = h[0];
     if (tape_len) *tape_len = ctx->q_tape_len;
     if (strings_len) *strings_len = ctx->q_strings_len;
@@ -494,6 +496,10 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
 
 int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
     if (!ctx) return SJHIP_ERR_ARG;
+    if (!ctx->f_valid) {  // no filter ran, or a later parse / serialize / marshal call re-used its arenas
+        ctx_set_error(ctx, "no filtered result on the device (sjhip_fetch_filtered follows sjhip_filter_where)");
+        return SJHIP_ERR_ARG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (ctx->q_tape_len && tape_dst)
         HIPCHK(hipMemcpyAsync(tape_dst, ctx->d_qtape.p, ctx->q_tape_len * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H filtered tape");

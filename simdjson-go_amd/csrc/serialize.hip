@@ -227,6 +227,7 @@ int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t
     ctx->ser_vals = (size_t)h[1];
     ctx->ser_valid = 1;
     ctx->q_tape_len = ctx->q_strings_len = 0;  // the filter result shared these arenas
+    ctx->f_valid = 0;
     // size of the framed stream (parsed_serialize.go:381-426)
     uint8_t tmp[16];
     const size_t sl = ctx->strings_len;

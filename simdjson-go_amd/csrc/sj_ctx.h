@@ -27,6 +27,7 @@ struct sjhip_ctx {
     int q_valid = 0;              // the device holds the whole result of an unsharded parse: queries are possible
     uint32_t q_records = 0;       // record-separating newline runs of that parse (records - 1)
     size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
+    int f_valid = 0;              // a filtered result is resident (sjhip_fetch_filtered)
     int ser_valid = 0;            // last sjhip_serialize (serialize.hip): column sizes, framed stream size
     size_t ser_tags = 0, ser_vals = 0, ser_rest = 0, ser_stream = 0;
     int ms_valid = 0;             // last sjhip_marshal_json (marshal.hip): the text is in d_qtape

@@ -94,9 +94,13 @@ static void worker_main(sjhip_stream *s, int k) {
                     rc = SJHIP_ERR_HIP;
                 sl.tape = (uint64_t *)tp;
                 sl.tape_cap = tc / sizeof(uint64_t);
-                if (rc == SJHIP_OK) rc = sjhip_fetch(sl.ctx, sl.tape, sl.strings);  // D2H into pinned memory
+                if (rc != SJHIP_OK) snprintf(sl.err, sizeof sl.err, "pinned result buffers (%zu tape words, %zu string bytes): allocation failed",
+                                             sl.tape_len, sl.strings_len);
+                else if ((rc = sjhip_fetch(sl.ctx, sl.tape, sl.strings)) != SJHIP_OK)  // D2H into pinned memory
+                    snprintf(sl.err, sizeof sl.err, "%s", sjhip_last_error(sl.ctx));
+            } else {
+                snprintf(sl.err, sizeof sl.err, "%s", sjhip_last_error(sl.ctx));
             }
-            if (rc != SJHIP_OK) snprintf(sl.err, sizeof sl.err, "%s", sjhip_last_error(sl.ctx));
         }
         lk.lock();
         if (rc != SJHIP_OK && rc != SJHIP_ERR_STREAM_CLOSED && sl.seq < s->fail_seq) s->fail_seq = sl.seq;
@@ -302,6 +306,16 @@ int sjhip_stream_next(sjhip_stream *s, sjhip_stream_result *out) {
     out->message_len = sl.msg_len;
     out->device = sl.device;
     return SJHIP_OK;
+}
+
+// would sjhip_stream_next return without waiting?
+int sjhip_stream_ready(sjhip_stream *s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->delivered >= 0) return 0;
+    if (s->failed) return 1;
+    if (s->next_deliver == s->next_submit) return 0;
+    return s->slots[(size_t)(s->next_deliver % s->slots.size())].state == DONE ? 1 : 0;
 }
 
 int sjhip_stream_release(sjhip_stream *s) {

@@ -207,28 +207,119 @@ func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 		}()
 		return
 	}
+	// Feeding and delivery are decoupled like in the reference (a reader goroutine queues blocks, results are sent as
+	// soon as their block is parsed, simdjson_amd64.go:131-216): the library allows one submitting and one taking
+	// thread.  `submitted` wakes the deliverer when a block was queued or the reader has finished, `freed` wakes the
+	// reader when a slot was released.
+	submitted := make(chan struct{}, 1)
+	freed := make(chan struct{}, 1)
+	stop := make(chan struct{}) // closed by the deliverer when the stream ends with an error
+	readDone := make(chan error, 1)
+	readerExited := make(chan struct{}) // the stream is destroyed only once the reader no longer touches it
+	notify := func(c chan struct{}) {
+		select {
+		case c <- struct{}{}:
+		default:
+		}
+	}
+
+	// reader: fills pinned blocks and submits them
+	go func() {
+		defer close(readerExited)
+		rd := bufio.NewReaderSize(r, blockSize)
+		for {
+			var blk *C.uint8_t
+			var capacity C.size_t
+			rc := C.sjhip_stream_acquire(st, &blk, &capacity)
+			if rc == C.SJHIP_STREAM_FULL { // every slot holds a block: wait for the deliverer to release one
+				select {
+				case <-freed:
+					continue
+				case <-stop:
+					return
+				}
+			}
+			if rc != C.SJHIP_OK { // SJHIP_ERR_STREAM_CLOSED after a failed block, or an internal error
+				readDone <- nil
+				notify(submitted)
+				return
+			}
+			buf := unsafe.Slice((*byte)(unsafe.Pointer(blk)), int(capacity))
+			n, rerr := io.ReadFull(rd, buf[:blockSize]) // straight into pinned memory (tmpPool's role)
+			if rerr == nil {                            // a full block: extend it to the end of the current record
+				rest, lerr := rd.ReadBytes('\n')
+				if n+len(rest) > int(capacity) { // a record longer than the reserve: a larger pinned block
+					if C.sjhip_stream_grow(st, C.size_t(n), C.size_t(n+len(rest)), &blk) != C.SJHIP_OK {
+						C.sjhip_stream_cancel(st)
+						readDone <- fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))
+						notify(submitted)
+						return
+					}
+					buf = unsafe.Slice((*byte)(unsafe.Pointer(blk)), n+len(rest))
+				}
+				copy(buf[n:], rest)
+				n += len(rest)
+				if lerr != nil {
+					rerr = lerr
+				}
+			} else if rerr == io.ErrUnexpectedEOF {
+				rerr = io.EOF
+			}
+			if n > 0 { // `if len(tmp) > 0`, :178
+				C.sjhip_stream_submit(st, C.size_t(n))
+			} else {
+				C.sjhip_stream_cancel(st)
+			}
+			if rerr != nil {
+				readDone <- rerr // io.EOF on a clean end
+				notify(submitted)
+				return
+			}
+			notify(submitted)
+		}
+	}()
+
+	// deliverer: takes results in submission order and sends them at once
 	go func() {
 		defer close(res)
-		defer C.sjhip_stream_destroy(st)
-		rd := bufio.NewReaderSize(r, blockSize)
-
-		// deliver takes the oldest outstanding result; false once the stream has ended with an error
-		deliver := func() bool {
+		defer func() {
+			go func() {
+				<-readerExited
+				C.sjhip_stream_destroy(st)
+			}()
+		}()
+		var finalErr error
+		finished := false
+		for {
 			var out C.sjhip_stream_result
-			rc := C.sjhip_stream_next(st, &out)
+			rc := C.sjhip_stream_next(st, &out) // waits for the oldest outstanding block
 			switch rc {
 			case C.SJHIP_OK:
 			case C.SJHIP_STREAM_EMPTY:
-				return true
+				if finished {
+					if finalErr != nil {
+						res <- Stream{Error: finalErr}
+					}
+					return
+				}
+				select { // nothing outstanding: wait for the reader
+				case <-submitted:
+				case finalErr = <-readDone:
+					finished = true
+				}
+				continue
 			case C.SJHIP_ERR_STAGE1:
+				close(stop)
 				res <- Stream{Error: fmt.Errorf("parsing input: %w", errors.New("Failed to find all structural indices for stage 1"))}
-				return false
+				return
 			case C.SJHIP_ERR_STAGE2:
+				close(stop)
 				res <- Stream{Error: fmt.Errorf("parsing input: %w", errors.New("Bad parsing while executing stage 2"))}
-				return false
+				return
 			default:
+				close(stop)
 				res <- Stream{Error: fmt.Errorf("parsing input: sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
-				return false
+				return
 			}
 			var pj ParsedJson
 			select { // `select { case v := <-reuse: ... default: }`, simdjson_amd64.go:181-190
@@ -264,57 +355,8 @@ func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 				copy(pj.Message, unsafe.Slice((*byte)(unsafe.Pointer(out.message)), ml))
 			}
 			C.sjhip_stream_release(st)
+			notify(freed)
 			res <- Stream{Value: &pj}
-			return true
-		}
-
-		for {
-			var blk *C.uint8_t
-			var capacity C.size_t
-			rc := C.sjhip_stream_acquire(st, &blk, &capacity)
-			if rc == C.SJHIP_STREAM_FULL { // every slot holds a block: deliver the oldest one first
-				if !deliver() {
-					return
-				}
-				continue
-			}
-			if rc != C.SJHIP_OK {
-				res <- Stream{Error: fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
-				return
-			}
-			buf := unsafe.Slice((*byte)(unsafe.Pointer(blk)), int(capacity))
-			n, rerr := io.ReadFull(rd, buf[:blockSize]) // straight into pinned memory (tmpPool's role)
-			if rerr == nil {                            // a full block: extend it to the end of the current record
-				rest, lerr := rd.ReadBytes('\n')
-				if n+len(rest) > int(capacity) { // a record longer than the reserve: a larger pinned block
-					if C.sjhip_stream_grow(st, C.size_t(n), C.size_t(n+len(rest)), &blk) != C.SJHIP_OK {
-						res <- Stream{Error: fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))}
-						return
-					}
-					buf = unsafe.Slice((*byte)(unsafe.Pointer(blk)), n+len(rest))
-				}
-				copy(buf[n:], rest)
-				n += len(rest)
-				if lerr != nil {
-					rerr = lerr
-				}
-			} else if rerr == io.ErrUnexpectedEOF {
-				rerr = io.EOF
-			}
-			if n > 0 { // `if len(tmp) > 0`, :178
-				C.sjhip_stream_submit(st, C.size_t(n))
-			} else {
-				C.sjhip_stream_cancel(st)
-			}
-			if rerr != nil {
-				for C.sjhip_stream_in_flight(st) > 0 { // drain in order; the first error ends the stream
-					if !deliver() {
-						return
-					}
-				}
-				res <- Stream{Error: rerr} // io.EOF on a clean end
-				return
-			}
 		}
 	}()
 }

@@ -57,6 +57,7 @@ SYMBOLS = {
     "sjhip_stream_cancel": (C.c_int, [C.c_void_p]),
     "sjhip_stream_submit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "sjhip_stream_next": (C.c_int, [C.c_void_p, C.POINTER(StreamResult)]),
+    "sjhip_stream_ready": (C.c_int, [C.c_void_p]),
     "sjhip_stream_release": (C.c_int, [C.c_void_p]),
     "sjhip_stage1_set_variant": (C.c_int, [C.c_int]),
     "sjhip_stage1_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

@@ -76,6 +76,10 @@ class Stream:
     def in_flight(self):
         return self._L.sjhip_stream_in_flight(self._h)
 
+    def ready(self):
+        """True if the oldest outstanding block has finished (take() would not wait)."""
+        return bool(self._L.sjhip_stream_ready(self._h))
+
     def feed(self, reader):
         """Reads one block from `reader` into a pinned block and submits it.  -> 'full' (take a result first),
         'eof' (nothing left; nothing submitted), 'last' (submitted, the reader is exhausted) or 'more'."""
@@ -152,6 +156,14 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
     try:
         more = True
         while more:
+            # Finished blocks are delivered before the next (possibly blocking) read of the input: the reference sends
+            # every Stream value as soon as its block is parsed (simdjson_amd64.go:193-203), so on a slow or unbounded
+            # reader results must not wait for the slots to fill up.
+            while st.ready():
+                pj = st.take(old())
+                if pj is None:
+                    return
+                yield pj
             state = st.feed(reader)
             if state == "full":  # every slot holds a block: deliver the oldest one
                 pj = st.take(old())
