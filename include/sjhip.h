@@ -84,6 +84,21 @@ int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
 int sjhip_parse_shard_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
                             size_t *strings_len);
 int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base);
+/* ---- ParseND over several GPUs in one call (simdjson_amd64.go:82-94 is one call in one process) -------------------
+ * A handle owns one context per entry of `devices` (NULL / 0 = every visible device; a device may be listed more than
+ * once: several shards on one GPU).  sjhip_parse_nd_multi cuts the HOST message at record boundaries into one shard per
+ * entry, runs the two-phase shard parse above on all of them in parallel (one host thread per shard; the sizes meet in
+ * a host prefix sum of 16 bytes per shard -- no device collective) and sjhip_fetch_multi copies every shard's piece
+ * straight into its slice of the caller's Tape / Strings.B: the result is bit for bit the ParsedJson of ParseND on
+ * the whole message.  A stage-1 failure of any shard wins over stage-2 failures (parse_json_amd64.go:97-105,123-126). */
+typedef struct sjhip_multi sjhip_multi;
+sjhip_multi *sjhip_multi_create(const int *devices, int n);
+void sjhip_multi_destroy(sjhip_multi *m);
+int sjhip_multi_shards(const sjhip_multi *m);
+const char *sjhip_multi_last_error(const sjhip_multi *m);
+int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len,
+                         size_t *strings_len, size_t *msg_off, size_t *msg_len);
+int sjhip_fetch_multi(sjhip_multi *m, uint64_t *tape_dst, uint8_t *strings_dst);
 /* bytes.TrimSpace exactly as parseMessage applies it (parse_json_amd64.go:55); for hosts that are not Go */
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len);
 

@@ -79,7 +79,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2,  &ctx->d_aux,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
+                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
@@ -130,7 +130,8 @@ static void invalidate_result(sjhip_ctx *ctx) {
 }
 
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind) {
+                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind, void *zero2,
+                          size_t zero2_bytes) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -149,7 +150,7 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
         volatile unsigned long long *hw = (volatile unsigned long long *)ctx->h_scratch;
         *hw = 0;
         HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
-                             (unsigned long long *)ctx->h_scratch),
+                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
                "stage1 launch");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
         const unsigned long long word = *hw;

@@ -33,7 +33,7 @@ static u32 peek_pseudo_pred(const u8 *msg, u64 p) {
 
 // optional per-chunk outputs (what the stage-1 kernel leaves for the string kernels; absolute in-string mask,
 // i.e. unit state 0)
-static uint64_t *g_qm = nullptr, *g_q = nullptr, *g_st = nullptr;
+static uint64_t *g_qm = nullptr, *g_q = nullptr, *g_st = nullptr, *g_slow = nullptr;
 
 extern "C" int sj_selftest_stage1(const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t cap,
                                   size_t *n_out, uint32_t *error, uint32_t *ends_in_quote) {
@@ -61,6 +61,7 @@ extern "C" int sj_selftest_stage1(const uint8_t *msg, size_t len, int ndjson, ui
             g_qm[off >> 6] = quote_mask;
             g_q[off >> 6] = quote_bits;
             g_st[off >> 6] = c.bs & ~escaped;
+            if ((escaped & ~c.esc1) != 0) g_slow[off >> 12] |= 1ull << ((off >> 6) & 63);
         }
         if (c.ctrl & quote_mask) err = 1;
         const u32 pp_in = peek_pseudo_pred(msg, off);
@@ -97,6 +98,7 @@ extern "C" void sj_selftest_classify(const uint8_t *in64, uint64_t *out6) {
     out6[3] = c.ws;
     out6[4] = c.ctrl;
     out6[5] = c.nl;
+    out6[6] = c.esc1;
 }
 extern "C" uint64_t sj_selftest_odd_backslash(uint64_t bs, uint32_t carry_in, uint32_t *carry_out) {
     return odd_backslash_ends(bs, carry_in, *carry_out);
@@ -179,14 +181,17 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     const size_t units = (len + 4095) / 4096 + 1, chunks = units * 64;
     std::vector<u64> v_qm(chunks, 0), v_q(chunks, 0), v_st(chunks, 0), v_em(chunks, 0), v_um(chunks, 0);
     std::vector<u8> v_h(units, 0);
+    std::vector<u64> v_slow(units, 0);
+    std::vector<u32> v_flags(chunks, 0);
     std::vector<uint16_t> v_pre(chunks, 0);
     std::vector<ChunkRec> v_rec(chunks);
     std::vector<u32> v_ucnt(units, 0);
     g_qm = v_qm.data();
     g_q = v_q.data();
     g_st = v_st.data();
+    g_slow = v_slow.data();
     sj_selftest_stage1(msg, len, ndjson, pos.data(), pos.size(), &n, &err, &inq);
-    g_qm = g_q = g_st = nullptr;
+    g_qm = g_q = g_st = g_slow = nullptr;
     if (len == 0 || err || inq || n == 0 || !(msg[len - 1] == '}' || msg[len - 1] == ']')) return 1;
     const MsgView mv{msg, len};
     // stage 2: the kernels of stage2.hip as loops, in launch order
@@ -194,16 +199,22 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     static constexpr ElementLut ELUT = make_element_lut();
     u32 bad = 0;
     // k_str_masks / k_str_scan (every string copied)
-    const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data()};
+    const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data(), v_slow.data()};
     const size_t used_units = (len + 4095) / 4096;
     u64 masks_total = 0;
     if (copy) {
         for (size_t c = 0; c < used_units * 64; c++)
         {
-            bool esc_flag, overflow;
-            if (!str_chunk_masks(sv, c, &v_em[c], &v_um[c], &esc_flag, &overflow)) bad = 1;
-            if (esc_flag != str_chunk_has_escapes(sv, c)) return 96;
+            bool overflow;
+            if (!str_chunk_masks_fast(sv, c, &v_em[c], &v_flags[c], &overflow)) bad = 1;
             if (overflow) force_copy = true;
+            {  // the fast path must agree with the general routine wherever it decides on its own
+                u64 em2, um2;
+                bool esc2, ov2;
+                const bool ok2 = str_chunk_masks(sv, c, &em2, &um2, &esc2, &ov2);
+                if (!ov2 && !str_chunk_needs_general(sv, c) && (!ok2 || em2 != v_em[c])) return 96;
+                if ((v_flags[c] & CHUNK_GENERAL) && esc2 != str_chunk_has_escapes(sv, c)) return 96;
+            }
         }
         if (force_copy) {  // S2_ERR_SERIAL_STRINGS: nothing of the mask pass is a verdict
             copy = false;
@@ -215,7 +226,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
                 v_pre[c] = (uint16_t)run;
-                v_rec[c] = ChunkRec{v_em[c], run | (str_chunk_has_escapes(sv, c) ? CHUNK_SLOW : 0u), 0u};
+                v_rec[c] = ChunkRec{v_em[c], run | v_flags[c], 0u};
                 run += (u32)popc64(v_em[c]);
             }
             v_ucnt[u] = (u32)masks_total;
@@ -278,6 +289,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     const u32 tlen = (u32)words + 2;  // + opening and closing root
     if (run.d != 0) bad = 1;
     const u32 tail_mask = is_bracket(kind[n - 1]) ? AM_ALL : am_value(run.am);
+    if (!context_allowed(tail_mask, CTX_ROOT)) bad = 1;  // k_scans: tokens behind the last bracket lie at depth 0
     u64 *tape = (u64 *)calloc(tlen + 2, sizeof(u64));
     u8 *strs = (u8 *)malloc(sbytes + 64);
     for (size_t i = 0; i < n; i++) {
@@ -309,7 +321,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             }
         }
     }
-    // k_min_level + k_brackets: min tree over the compact bracket view, partners, contexts, gap check
+    // k_min_level + k_br_match: min tree over the compact bracket view; partners, contexts, gap check, root words
     MinTree mt;
     std::vector<std::vector<i32>> levels;
     mt.lev[0] = br_depth.data();
@@ -328,23 +340,20 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         mt.nlev++;
     }
     const u32 n_br = (u32)br_off.size();
-    for (u32 c = 0; c < n_br; c++) {
-        const u8 ctx = bracket_resolve(mt, br_off.data(), br_info.data(), c, tape_base, tape);
-        const u32 next = c + 1 < n_br ? (u32)(br_info[c + 1] >> 4) : tail_mask;
-        if (!context_allowed(next, ctx)) bad = 1;
-        if (c == 0 && !context_allowed((u32)(br_info[0] >> 4), CTX_ROOT)) bad = 1;
-    }
+    for (u32 c = 0; c < n_br; c++)  // k_br_match: container of every gap, pair words, root words
+        if (!bracket_resolve(mt, br_off.data(), br_info.data(), c, tape_base, tape)) bad = 1;
     if (n_br == 0) bad = 1;  // unreachable: token 0 must be an open bracket
     if (copy && !bad)  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
         for (size_t c = 0; c < used_units * 64; c++) {
             if (v_em[c] == 0) continue;
             u8 chunk[64];
             for (u32 q = 0; q < 64; q++) chunk[q] = sv.at(c * 64 + q);
-            if (str_chunk_has_escapes(sv, c)) str_chunk_patch(sv, c, [&](u32 q, u8 v) { chunk[q] = v; });
+            if (v_flags[c] & CHUNK_GENERAL) str_chunk_patch(sv, c, [&](u32 q, u8 v) { chunk[q] = v; });
+            else if (v_flags[c] & CHUNK_SLOW)
+                str_chunk_patch_simple(sv, c, v_em[c], [&](u32 q) { return chunk[q]; }, [&](u32 q, u8 v) { chunk[q] = v; });
             u8 *dst = strs + v_ucnt[c >> 6] + v_pre[c];
             for (u64 r = v_em[c]; r != 0; r &= r - 1) *dst++ = chunk[ctz64(r)];
         }
-    for (u32 r = 0; r <= nl_off.size(); r++) emit_root(nl_off.data(), (u32)nl_off.size(), tlen, r, tape, tape_base);  // k_roots
     if (bad) {
         free(tape);
         free(strs);

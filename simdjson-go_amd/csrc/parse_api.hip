@@ -18,8 +18,30 @@ using namespace sj;
         if (e_ != hipSuccess) return ctx_hip_fail(ctx, e_, what); \
     } while (0)
 
-// Phase 1 (parse_begin): stage 1, then stage 2 up to the device-wide scan; reads back the sizes.
+// Phase 1 (parse_begin): stage 1, then stage 2 up to the device-wide scans; a shard reads back the sizes.
 // Phase 2 (parse_finish): the rest of stage 2 with the rebasing offsets, then the verdict.
+static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base) {
+    S2Args a = {};
+    a.d_msg = ctx->p_msg;
+    a.len = ctx->p_len;
+    a.d_pos = (const uint32_t *)ctx->d_pos.p;
+    a.d_kind = ctx->p_kind;
+    a.n = ctx->p_n;
+    a.flags = ctx->p_flags;
+    a.ws_zero = ctx->d_s2z.p;
+    a.ws = ctx->d_s2.p;
+    a.d_tape = (uint64_t *)ctx->d_tape.p;
+    a.tape_cap = 2 * ctx->p_n + 2;
+    a.d_strings = (uint8_t *)ctx->d_strings.p;
+    a.strings_cap = ctx->p_len + 64;
+    a.tape_base = tape_base;
+    a.strings_base = strings_base;
+    a.msg_base = msg_base;
+    a.str_aux = ctx->p_aux;
+    a.stream = ctx->stream;
+    return a;
+}
+
 static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte, int have_last,
                        size_t *tape_len, size_t *strings_len) {
     ctx->tape_len = ctx->strings_len = 0;
@@ -44,12 +66,15 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         aux = ctx->d_aux.p;
     }
     {
+        // the state and the scan slots of stage 2: zeroed by stage 1's preparation kernel (no memset launch of their own)
+        int rc = arena_reserve(ctx, ctx->d_s2z, stage2_zero_bytes());
+        if (rc) return rc;
         // positions, then the token kinds stage 1 writes next to them (1 byte each, 256-byte aligned)
-        int rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * (sizeof(uint32_t) + 1));
+        rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * (sizeof(uint32_t) + 1));
         if (rc) return rc;
         ctx->p_kind = (uint8_t *)ctx->d_pos.p + (pos_cap + 64) * sizeof(uint32_t);
         rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                               have_last, &n, &ok, aux, ctx->p_kind);
+                               have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
         if (rc) return rc;
     }
     if (!ok) return SJHIP_ERR_STAGE1;
@@ -59,29 +84,26 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_strings, len + 64);
     if (rc) return rc;
-    HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, flags, ctx->d_s2.p, ctx->stream,
-                                 aux),
-           "stage2 launch (measure)");
     ctx->p_aux = aux;
     ctx->pending = 1;
     ctx->p_msg = d_msg;
     ctx->p_len = len;
     ctx->p_n = n;
     ctx->p_flags = flags;
+    HIPCHK(stage2_launch_measure(s2_args(ctx, 0, 0, 0)), "stage2 launch (measure)");
     if (tape_len || strings_len) {  // only the sharded path needs the sizes before phase 2
-        S2State *hs = (S2State *)(ctx->h_scratch + 256);
-        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
+        S2State *hs = (S2State *)(ctx->h_scratch + 512);
+        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
         if (hs->err & S2_ERR_SERIAL_STRINGS) {  // pathological surrogate run: measure again with the per-string walks
             ctx->p_aux = nullptr;
-            HIPCHK(stage2_launch_measure(d_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, flags, ctx->d_s2.p,
-                                         ctx->stream, nullptr),
-                   "stage2 launch (measure, per-string)");
-            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
+            HIPCHK(hipMemsetAsync(ctx->d_s2z.p, 0, stage2_zero_bytes(), ctx->stream), "stage2 state reset");
+            HIPCHK(stage2_launch_measure(s2_args(ctx, 0, 0, 0)), "stage2 launch (measure, per-string)");
+            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
             HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
         }
         if (tape_len) *tape_len = (size_t)hs->tape_len;
-        if (strings_len) *strings_len = (size_t)hs->strings_len;
+        if (strings_len) *strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     }
     return SJHIP_OK;
 }
@@ -94,27 +116,29 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     }
     ctx->pending = 0;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    const size_t n = ctx->p_n, len = ctx->p_len;
-    HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags, ctx->d_s2.p,
-                              (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
-                              strings_base, msg_base, ctx->stream, ctx->p_aux),
-           "stage2 launch (emit)");
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
-    HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+    auto run = [&]() -> int {
+        const S2Args a = s2_args(ctx, tape_base, strings_base, msg_base);
+        HIPCHK(stage2_launch_emit(a), "stage2 launch (emit)");
+        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+        if (hs->bignum_count && !(hs->err & S2_ERR_SERIAL_STRINGS)) {  // rare: >19-digit mantissas that need the exact tie-break
+            HIPCHK(stage2_launch_bignum(a), "stage2 launch (bignum)");
+            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+        }
+        return SJHIP_OK;
+    };
+    int rc = run();
+    if (rc) return rc;
     if ((hs->err & S2_ERR_SERIAL_STRINGS) && ctx->p_aux) {
         // a run of > SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string path
         // gave up, nothing of this run is a verdict.  Stage 2 again with the per-string walks (linear in the run).
         ctx->p_aux = nullptr;
-        HIPCHK(stage2_launch_measure(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags,
-                                     ctx->d_s2.p, ctx->stream, nullptr),
-               "stage2 launch (measure, per-string)");
-        HIPCHK(stage2_launch_emit(ctx->p_msg, len, (const uint32_t *)ctx->d_pos.p, ctx->p_kind, n, ctx->p_flags, ctx->d_s2.p,
-                                  (uint64_t *)ctx->d_tape.p, 2 * n + 2, (uint8_t *)ctx->d_strings.p, len + 64, tape_base,
-                                  strings_base, msg_base, ctx->stream, nullptr),
-               "stage2 launch (emit, per-string)");
-        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
-        HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+        HIPCHK(hipMemsetAsync(ctx->d_s2z.p, 0, stage2_zero_bytes(), ctx->stream), "stage2 state reset");
+        HIPCHK(stage2_launch_measure(s2_args(ctx, tape_base, strings_base, msg_base)), "stage2 launch (measure, per-string)");
+        rc = run();
+        if (rc) return rc;
     }
     if (hs->err & 8u) {  // a bounded spin loop of a scan kernel ran out: internal error, never a verdict
         ctx_set_error(ctx, "stage-2 scan aborted (internal synchronisation timeout)");
@@ -126,7 +150,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
     ctx->tape_len = (size_t)hs->tape_len;
-    ctx->strings_len = (size_t)hs->strings_len;
+    ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
     ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
     if (tape_len) *tape_len = ctx->tape_len;

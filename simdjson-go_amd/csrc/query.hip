@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_q_copy(QView q, QRec o, u64 *out_tape, 
 
 namespace sj {
 // nl_off and the record count of the last stage-2 run in this workspace (stage2.hip)
-void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off, const S2State **st);
+void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off);
 }
 
 static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q,
@@ -389,8 +389,7 @@ static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint
         return SJHIP_ERR_ARG;
     }
     const uint32_t *nl = nullptr;
-    const S2State *st = nullptr;
-    stage2_records_view(ctx->d_s2.p, ctx->p_n, &nl, &st);
+    stage2_records_view(ctx->d_s2.p, ctx->p_n, &nl);
     q->tape = (const u64 *)ctx->d_tape.p;
     q->tape_len = ctx->tape_len;
     q->strings = (const u8 *)ctx->d_strings.p;

@@ -157,6 +157,8 @@ struct Classes {
     u64 ws;      // space \t \n \r
     u64 ctrl;    // byte <= 0x1f           (find_quote_mask_and_bits_amd64.s:67-78)
     u64 nl;      // '\n'                   (find_newline_delimiters_amd64.s:16-28)
+    u64 esc1;    // " \\ / b f n r t: the characters a simple escape may name (escape_map, parse_string_amd64.s:38-69);
+                 // only the whole-parse kernel reads it (dead code elsewhere)
 };
 
 // Every class is a conjunction of plane literals; the network below shares the common factors and
@@ -191,6 +193,15 @@ SJ_HD Classes classify(const u32 (&w)[16]) {
     c.ws = bitop3<(TA | (TB & TC))>(sp, w1, g);
     const u64 h = bitop3<(1u << 2)>(b2, b1, b0);               // xxxx x010
     c.nl = w1 & h;                                             // 0x0a
+    // " 22  \\ 5c  / 2f  b 62  f 66  n 6e  r 72  t 74
+    const u64 l1111 = bitop3<(TA & TB & TC)>(b3, b2, b1);
+    const u64 slash = bitop3<(TA & ~TB & TC)>(h001, b4, l1111) & b0;      // 0010 1111
+    const u64 h011 = bitop3<(~TA & TB & TC)>(b7, b6, b5);                 // 011x xxxx
+    const u64 s6 = bitop3<(TC & ~(TA & ~TB))>(b3, b2, b1);                // low nibble 0010 0110 1110 (b0 below)
+    const u64 s7 = bitop3<(~TA & (TB ^ TC))>(b3, b2, b1);                 // low nibble 0010 0100
+    const u64 t6 = bitop3<(TA & ~TB & TC)>(h011, b4, s6), t7 = bitop3<(TA & TB & TC)>(h011, b4, s7);
+    const u64 letters = bitop3<((TA | TB) & ~TC)>(t6, t7, b0);
+    c.esc1 = bitop3<(TA | TB | TC)>(c.quote, c.bs, slash) | letters;
     return c;
 }
 

@@ -19,7 +19,7 @@ struct sjhip_ctx {
     hipStream_t own_stream = nullptr;  // created with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
-    sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_aux;
+    sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
@@ -47,5 +47,6 @@ void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                      uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr);
+                      uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr,
+                      void *zero2 = nullptr, size_t zero2_bytes = 0);
 }  // namespace sj

@@ -43,17 +43,33 @@ static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 // path gives up and the host repeats stage 2 with the per-string walks (no verdict is taken from the first run)
 static constexpr uint32_t S2_ERR_SERIAL_STRINGS = 16u;
 
+// Everything a stage-2 launch needs.
+struct S2Args {
+    const void *d_msg;
+    size_t len;
+    const uint32_t *d_pos;
+    const uint8_t *d_kind;  // the token kinds stage 1 wrote next to the positions
+    size_t n;               // tokens
+    uint32_t flags;
+    void *ws_zero;          // stage2_zero_bytes(): zero before the measure phase (stage 1's preparation kernel does it)
+    void *ws;               // stage2_workspace_bytes(n)
+    uint64_t *d_tape;
+    size_t tape_cap;
+    uint8_t *d_strings;
+    size_t strings_cap;
+    uint64_t tape_base, strings_base, msg_base;
+    void *str_aux;          // string masks of stage 1 (str_aux_layout) or null: per-string walks
+    hipStream_t stream;
+};
+size_t stage2_zero_bytes();
 size_t stage2_workspace_bytes(size_t n_tokens);
-// d_kind: the token kinds stage 1 wrote next to the positions
-hipError_t stage2_launch_measure(const void *d_msg, size_t len, const uint32_t *d_pos, const uint8_t *d_kind, size_t n,
-                                 uint32_t flags, void *ws, hipStream_t stream, void *str_aux = nullptr);
-hipError_t stage2_launch_emit(const void *d_msg, size_t len, const uint32_t *d_pos, const uint8_t *d_kind, size_t n,
-                              uint32_t flags, void *ws, uint64_t *d_tape, size_t tape_cap, uint8_t *d_strings, size_t strings_cap,
-                              uint64_t tape_base, uint64_t strings_base, uint64_t msg_base, hipStream_t stream,
-                              void *str_aux = nullptr);
+hipError_t stage2_launch_measure(const S2Args &a);
+hipError_t stage2_launch_emit(const S2Args &a);
+hipError_t stage2_launch_bignum(const S2Args &a);
 
 size_t stage1_workspace_bytes(size_t len);
-hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream);
+// zero2 / zero2_bytes: a second region to zero in the same kernel (the stage-2 state) or null
+hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2 = nullptr, size_t zero2_bytes = 0);
 // String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / q / st / unit_h, the string
 // kernels of stage 2 add one 16-byte record per chunk (sj_strings.h ChunkRec) and unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
 // base of the message); everything is sized in whole 4 KiB units.
@@ -63,6 +79,7 @@ struct StrAux {
     void *rec;  // ChunkRec[chunks]
     uint32_t *unit_cnt;
     uint8_t *unit_h;
+    uint64_t *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (a \u or an invalid escape)
 };
 inline StrAux str_aux_layout(void *buf, size_t span) {
     StrAux a;
@@ -80,6 +97,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.rec = carve(a.chunks * 16);
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
+    a.unit_slow = reinterpret_cast<uint64_t *>(carve(a.units * 8));
     a.bytes = (size_t)(w - reinterpret_cast<char *>(buf));
     return a;
 }
@@ -95,6 +113,6 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // the packed result there (S1_HOST_*) in one store: the host needs a stream synchronisation but no copy
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                         unsigned long long *h_state = nullptr);
+                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0);
 
 }  // namespace sj

@@ -1,13 +1,15 @@
 // sj_ftoa.h -- number formatting for tape -> JSON text (Iter.MarshalJSONBuffer, parsed_json.go:401-556), host+device.
 //
-// Restates, for float64 only,
+// What has to match the reference byte for byte is the TEXT:
 //   appendFloat       parsed_json.go:1250-1272   ES6-style choice between %f and %e, "e-09" -> "e-9"
 //   appendFloatF/fmtF appendfloat_f.go:11-84     %f with the shortest precision
-//   ryuFtoaShortest   ftoaryu.go:22-118          shortest round-trip digits (Ryu; a copy of Go's strconv)
-//   computeBounds, ryuDigits, ryuDigits32, mult128bitPow10, divisibleByPower5   ftoaryu.go:139-367
 //   strconv %e        (Go standard library, fmtE): d.ddddde+XX with at least two exponent digits
-// and strconv.AppendInt / AppendUint.  The 128-bit powers of ten are tools/gen_pow10_table.py's output, verified
-// entry by entry against the table in ftoaryu.go:392-1089.
+//   strconv.AppendInt / AppendUint
+// over the shortest round-trip digits of the float64.  The reference gets those digits from its copy of Go's Ryu
+// (ftoaryu.go); any correct shortest-digits routine yields the same ones, and the one here is built for lanes that run
+// in lockstep: three 64 x 128-bit multiplications against one table entry and a fixed-shape digit emission
+// (shortest_decimal below; tests/test_host_ftoa.py checks > 250 000 doubles incl. the ends of every binade).  The
+// 128-bit powers of ten are tools/gen_pow10_table.py's output.
 #pragma once
 #include <stdint.h>
 
@@ -23,177 +25,101 @@ __device__ __constant__ static const u64 POW10_128[(POW10_MAX_Q - POW10_MIN_Q + 
 static const u64 POW10_128[(POW10_MAX_Q - POW10_MIN_Q + 1) * 2] = SJ_POW10_TABLE_INIT;
 #endif
 
-struct Digits {  // decimalSlice: value = 0.d[0]d[1]...d[nd-1] * 10^dp
+struct Digits {  // value = 0.d[0]d[1]...d[nd-1] * 10^dp, no trailing zeros (nd == 0: zero)
     u8 d[24];
     int nd, dp;
 };
 
-SJ_HD int mul_log2_log10(int x) { return (x * 78913) >> 18; }   // floor(x * log10(2)), |x| <= 1600 (ftoaryu.go:121)
-SJ_HD int mul_log10_log2(int x) { return (x * 108853) >> 15; }  // floor(x * log2(10)), |x| <= 500  (ftoaryu.go:131)
+// ---- shortest round-trip digits ----------------------------------------------------------------------------------
+// Any correct shortest-digits routine prints the same digits as the reference's copy of Go's strconv (the shortest
+// decimal that reads back as the same float64, the closest such one, ties to even).  This one works on the rounding
+// interval directly (Giulietti's "Schubfach" formulation): with v = c * 2^q, k = floor(log10(2^q)) and g = the 128-bit
+// power of ten 10^-k rounded up, the three products of 4c - 2 (or 4c - 1 below a power of two), 4c and 4c + 2 with g --
+// each one 64 x 128-bit multiplication whose discarded bits only survive as a sticky "odd" bit -- are the interval and v
+// itself scaled to integers; the answer is the multiple of 10 (if any) or of 1 inside the interval, closest to v.  One
+// multiplication per bound, no digit-by-digit loop: the lanes of a wave stay together.
+SJ_HD int floor_log10_pow2(int e) { return (e * 1262611) >> 22; }                       // |e| <= 1500
+SJ_HD int floor_log10_three_quarters_pow2(int e) { return (e * 1262611 - 524031) >> 22; }
+SJ_HD int floor_log2_pow10(int e) { return (e * 1741647) >> 19; }                       // |e| <= 1233
 
-// mult128bitPow10 (ftoaryu.go:330-352): m * 10^q as a 64-bit mantissa; *exact = no bit was dropped
-SJ_HD u64 mult128_pow10(u64 m, int *e2, int q, bool *exact) {
-    if (q == 0) {
-        *e2 -= 8;
-        *exact = true;
-        return m << 8;
-    }
-    u64 p0 = POW10_128[2 * (q - POW10_MIN_Q)], p1 = POW10_128[2 * (q - POW10_MIN_Q) + 1];
-    if (q < 0) p0 += 1;  // inverse powers of ten must be rounded up
-    *e2 += mul_log10_log2(q) - 127 + 119;
-    const U128 l = mul64(m, p0), h = mul64(m, p1);
-    const u64 mid = l.hi + h.lo;
-    const u64 h1 = h.hi + (mid < l.hi ? 1u : 0u);
-    *exact = (mid << 9) == 0 && l.lo == 0;
-    return (h1 << 9) | (mid >> 55);
+// floor(cp * g / 2^128) with the dropped bits folded into bit 0 ("round to odd"); g = {hi, lo}
+SJ_HD u64 mul_round_to_odd(u64 ghi, u64 glo, u64 cp) {
+    const U128 x = mul64(cp, glo), y = mul64(cp, ghi);
+    const u64 z = y.lo + x.hi;
+    const u64 y1 = y.hi + (z < y.lo ? 1u : 0u);
+    return y1 | (z > 1 ? 1u : 0u);
 }
 
-SJ_HD bool divisible_by_pow5(u64 m, int k) {  // ftoaryu.go:354-366
-    if (m == 0) return true;
-    for (int i = 0; i < k; i++) {
-        if (m % 5 != 0) return false;
-        m /= 5;
+// decimal significand and exponent of the shortest representation: value = *dec * 10^(*k10); c = binary significand
+// (hidden bit included), q = binary exponent of its unit, `narrow` = the interval below v is half as wide (c is a power of two)
+SJ_HD void shortest_decimal(u64 c, int q, bool narrow, u64 *dec, int *k10) {
+    const bool even = (c & 1u) == 0;  // the interval includes its ends iff the significand is even (round-half-even reading)
+    const u64 cbl = 4 * c - 2 + (narrow ? 1u : 0u), cb = 4 * c, cbr = 4 * c + 2;
+    const int k = narrow ? floor_log10_three_quarters_pow2(q) : floor_log10_pow2(q);
+    const int h = q + floor_log2_pow10(-k) + 1;  // 1 <= h <= 4
+    // 10^-k as a 128-bit mantissa, rounded UP (the table holds the rounded-down mantissas; 10^0 .. 10^55 are exact)
+    u64 glo = POW10_128[2 * (-k - POW10_MIN_Q)], ghi = POW10_128[2 * (-k - POW10_MIN_Q) + 1];
+    if (-k < 0 || -k > 55) {
+        glo += 1;
+        ghi += glo == 0 ? 1u : 0u;
     }
-    return true;
-}
-
-// ryuDigits32 (ftoaryu.go:213-287); d->d[0 .. d->nd) already holds the high part
-SJ_HD void ryu_digits32(Digits *d, u32 lower, u32 central, u32 upper, bool c0, bool cup, int endindex) {
-    if (upper == 0) {
-        d->dp = endindex + 1;
-        return;
-    }
-    int trimmed = 0, c_next = 0;
-    while (upper > 0) {
-        const u32 l = (lower + 9) / 10;
-        u32 c = central / 10, cdigit = central % 10;
-        const u32 u = upper / 10;
-        if (l > u) break;
-        if (l == c + 1 && c < u) {
-            c++;
-            cdigit = 0;
-            cup = false;
-        }
-        trimmed++;
-        c0 = c0 && c_next == 0;
-        c_next = (int)cdigit;
-        lower = l;
-        central = c;
-        upper = u;
-    }
-    if (trimmed > 0) cup = c_next > 5 || (c_next == 5 && !c0) || (c_next == 5 && c0 && (central & 1u) == 1u);
-    if (central < upper && cup) central++;
-    endindex -= trimmed;
-    u32 v = central;
-    int n = endindex;
-    while (n > d->nd) {
-        const u32 v1 = v / 100, v2 = v % 100;
-        d->d[n] = (u8)('0' + v2 % 10);
-        d->d[n - 1] = (u8)('0' + v2 / 10);
-        n -= 2;
-        v = v1;
-    }
-    if (n == d->nd) d->d[n] = (u8)(v + '0');
-    d->nd = endindex + 1;
-    d->dp = d->nd + trimmed;
-}
-
-// ryuDigits (ftoaryu.go:156-199).  `first` tracks the reference's re-slicing of d.d (d.d = d.d[n:]).
-SJ_HD void ryu_digits(Digits *d, u64 lower, u64 central, u64 upper, bool c0, bool cup) {
-    u32 lhi = (u32)(lower / 1000000000ull), llo = (u32)(lower % 1000000000ull);
-    const u32 chi = (u32)(central / 1000000000ull), clo = (u32)(central % 1000000000ull);
-    const u32 uhi = (u32)(upper / 1000000000ull), ulo = (u32)(upper % 1000000000ull);
-    d->nd = 0;
-    if (uhi == 0) {
-        ryu_digits32(d, llo, clo, ulo, c0, cup, 8);
-    } else if (lhi < uhi) {
-        if (llo != 0) lhi++;
-        c0 = c0 && clo == 0;
-        cup = (clo > 500000000u) || (clo == 500000000u && cup);
-        ryu_digits32(d, lhi, chi, uhi, c0, cup, 8);
-        d->dp += 9;
-    } else {
-        // emit the high part left-aligned, then the low nine digits behind it
-        u8 tmp[9];
-        int n = 9;
-        for (u32 v = chi; v > 0; v /= 10) tmp[--n] = (u8)(v % 10 + '0');
-        d->nd = 9 - n;
-        for (int k = 0; k < d->nd; k++) d->d[k] = tmp[n + k];
-        ryu_digits32(d, llo, clo, ulo, c0, cup, d->nd + 8);
-    }
-    while (d->nd > 0 && d->d[d->nd - 1] == '0') d->nd--;  // trailing zeros
-    int lead = 0;                                            // initial zeros
-    while (lead < d->nd && d->d[lead] == '0') lead++;
-    if (lead) {
-        for (int k = lead; k < d->nd; k++) d->d[k - lead] = d->d[k];
-        d->nd -= lead;
-        d->dp -= lead;
-    }
-}
-
-// ryuFtoaShortest (ftoaryu.go:22-118): shortest digits of mant * 2^exp
-SJ_HD void ryu_shortest(Digits *d, u64 mant, int exp) {
-    if (mant == 0) {
-        d->nd = d->dp = 0;
-        return;
-    }
-    if (exp <= 0) {  // an exact integer with fewer bits than the mantissa
-        int tz = 0;
-        while (tz < 64 && ((mant >> tz) & 1u) == 0) tz++;
-        if (tz >= -exp) {
-            mant >>= (u32)(-exp);
-            ryu_digits(d, mant, mant, mant, true, false);
+    const u64 vbl = mul_round_to_odd(ghi, glo, cbl << h);
+    const u64 vb = mul_round_to_odd(ghi, glo, cb << h);
+    const u64 vbr = mul_round_to_odd(ghi, glo, cbr << h);
+    const u64 lower = vbl + (even ? 0u : 1u), upper = vbr - (even ? 0u : 1u);
+    const u64 s = vb >> 2;  // floor(v * 10^-k)
+    if (s >= 10) {  // a multiple of 10 inside the interval is one digit shorter
+        const u64 sp = s / 10;
+        const bool up_inside = lower <= 40 * sp, wp_inside = 40 * sp + 40 <= upper;
+        if (up_inside != wp_inside) {
+            *dec = sp + (wp_inside ? 1u : 0u);
+            *k10 = k + 1;
             return;
         }
     }
-    // computeBounds (ftoaryu.go:139-154)
-    u64 ml, mc, mu;
-    int e2;
-    if (mant != (1ull << 52) || exp == -1023 + 1 - 52) {
-        ml = 2 * mant - 1;
-        mc = 2 * mant;
-        mu = 2 * mant + 1;
-        e2 = exp - 1;
-    } else {
-        ml = 4 * mant - 1;
-        mc = 4 * mant;
-        mu = 4 * mant + 2;
-        e2 = exp - 2;
-    }
-    if (e2 == 0) {
-        ryu_digits(d, ml, mc, mu, true, false);
+    const bool u_inside = lower <= 4 * s, w_inside = 4 * s + 4 <= upper;
+    *k10 = k;
+    if (u_inside != w_inside) {
+        *dec = s + (w_inside ? 1u : 0u);
         return;
     }
-    const int q = mul_log2_log10(-e2) + 1;  // 10^q larger than 2^-e2
-    bool dl0, dc0, du0;
-    int el = e2, ec = e2, eu = e2;
-    u64 dl = mult128_pow10(ml, &el, q, &dl0);
-    u64 dc = mult128_pow10(mc, &ec, q, &dc0);
-    u64 du = mult128_pow10(mu, &eu, q, &du0);
-    e2 = eu;
-    if (q > 55) dl0 = dc0 = du0 = false;  // large positive powers of ten are not exact
-    if (q < 0 && q >= -24) {               // division by a power of ten may be exact
-        if (divisible_by_pow5(ml, -q)) dl0 = true;
-        if (divisible_by_pow5(mc, -q)) dc0 = true;
-        if (divisible_by_pow5(mu, -q)) du0 = true;
-    }
-    const u32 extra = (u32)(-e2);
-    const u64 extra_mask = (1ull << extra) - 1;
-    const u64 fracl = dl & extra_mask, fracc = dc & extra_mask, fracu = du & extra_mask;
-    dl >>= extra;
-    dc >>= extra;
-    du >>= extra;
-    bool uok = !du0 || fracu > 0;
-    if (du0 && fracu == 0) uok = (mant & 1u) == 0;
-    if (!uok) du--;
-    bool cup;
-    if (dc0) cup = fracc > (1ull << (extra - 1)) || (fracc == (1ull << (extra - 1)) && (dc & 1u) == 1u);
-    else cup = (fracc >> (extra - 1)) == 1;
-    const bool lok = dl0 && fracl == 0 && (mant & 1u) == 0;
-    if (!lok) dl++;
-    const bool c0 = dc0 && fracc == 0;
-    ryu_digits(d, dl, dc, du, c0, cup);
-    d->dp -= q;
+    const u64 mid = 4 * s + 2;  // both (or neither) inside: the one closer to v, ties to even
+    const bool round_up = vb > mid || (vb == mid && (s & 1u) != 0);
+    *dec = s + (round_up ? 1u : 0u);
+}
+
+// eight decimal digits of x < 10^8, most significant first, without a loop (two four-digit halves, two two-digit quarters)
+SJ_HD void digits8(u32 x, u8 *out) {
+    const u32 hi = x / 10000u, lo = x - hi * 10000u;
+    const u32 a = hi / 100u, b = hi - a * 100u, c = lo / 100u, d = lo - c * 100u;
+    out[0] = (u8)('0' + a / 10u); out[1] = (u8)('0' + a % 10u);
+    out[2] = (u8)('0' + b / 10u); out[3] = (u8)('0' + b % 10u);
+    out[4] = (u8)('0' + c / 10u); out[5] = (u8)('0' + c % 10u);
+    out[6] = (u8)('0' + d / 10u); out[7] = (u8)('0' + d % 10u);
+}
+
+// the digits of mant * 2^exp2 (mant != 0 unless the value is zero; denormals come with their own exponent)
+SJ_HD void shortest_digits(Digits *d, u64 mant, int exp2, bool narrow) {
+    d->nd = 0;
+    d->dp = 0;
+    if (mant == 0) return;
+    u64 dec;
+    int k10;
+    shortest_decimal(mant, exp2, narrow, &dec, &k10);
+    // dec < 10^17: 1 + 8 + 8 digits into a fixed buffer, then the window between the first and the last non-zero digit
+    u8 buf[24];
+    const u64 top = dec / 100000000ull;           // < 10^9
+    const u32 low8 = (u32)(dec - top * 100000000ull);
+    const u32 top1 = (u32)(top / 100000000ull);   // the 17th digit
+    buf[0] = (u8)('0' + top1);
+    digits8((u32)(top - (u64)top1 * 100000000ull), buf + 1);
+    digits8(low8, buf + 9);
+    int first = 0, last = 16;
+    while (first < 16 && buf[first] == '0') first++;
+    while (last > first && buf[last] == '0') last--;
+    d->nd = last - first + 1;
+    for (int i = 0; i < d->nd; i++) d->d[i] = buf[first + i];
+    d->dp = k10 + (17 - first);  // dec has 17 - first digits: value = 0.d... * 10^(k10 + digits)
 }
 
 // appendFloat (parsed_json.go:1250-1272): `out` needs 32 bytes; returns the length, 0 for Inf / NaN (an error there)
@@ -206,7 +132,8 @@ SJ_HD u32 format_float(u64 bits, u8 *out) {
     else mant |= 1ull << 52;
     exp += -1023;
     Digits d;
-    ryu_shortest(&d, mant, exp - 52);
+    // below a power of two the interval's lower half is narrower (not for the smallest normal exponent and denormals)
+    shortest_digits(&d, mant, exp - 52, (bits & ((1ull << 52) - 1)) == 0 && ((bits >> 52) & 0x7ff) > 1);
     u32 n = 0;
     if (neg) out[n++] = '-';
     // abs >= 1e-6 && abs < 1e21, or zero  <=>  %f  (the comparisons are exact on the decimal exponent of the

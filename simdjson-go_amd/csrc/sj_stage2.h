@@ -507,43 +507,38 @@ SJ_HD u32 kind_window(const u8 *kind, u32 i, u32 n) {
     return ppk | (pk << 8) | ((u32)kind[i] << 16) | (nk << 24);
 }
 
-// ---- brackets: partners and contexts over the compact bracket view ----------------------------------------------
+// ---- brackets: partners, contexts and root words over the compact bracket view -------------------------------------
 // The c-th bracket token has depth br_depth[c] after it (level 0 of the min tree), its tape word at br_off[c]
 // and br_info[c] = kind | gap_mask << 4 (the gap that ends with it).  Non-bracket tokens never change the
 // depth, so previous-smaller-value queries over the compact view find the same brackets as over all tokens.
-// Returns the context AFTER bracket c; a close bracket also writes both tape words of its pair
-// (payloads: annotate_previousloc, stage2_build_tape_amd64.go:335-336).
-SJ_HD u8 bracket_resolve(const MinTree &mt, const u32 *br_off, const u8 *br_info, u32 c, u64 tape_base, u64 *tape) {
-    const u8 k = br_info[c] & 15u;
-    if (k == K_OPEN_OBJ) return CTX_OBJ;
-    if (k == K_OPEN_ARR) return CTX_ARR;
-    const i32 d = mt.lev[0][c] + 1;  // depth before the close
-    if (d <= 0) return CTX_ROOT;     // closes nothing: its gap mask rejects it (a close needs OBJ / ARR)
-    const i64 jc = psv(mt, (i64)c, d) + 1;  // the open bracket that raised the depth to d
-    const u8 jk = br_info[jc] & 15u;
-    tape[br_off[c]] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (tape_base + br_off[jc]);
-    tape[br_off[jc]] = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (tape_base + br_off[c] + 1);
-    if (d - 1 <= 0) return CTX_ROOT;
-    const i64 pc = psv(mt, jc, d - 1) + 1;  // the enclosing container's open bracket
-    return (br_info[pc] & 15u) == K_OPEN_OBJ ? CTX_OBJ : CTX_ARR;
-}
+// One rule for every bracket: the gap that ends with it lies at the depth in front of it, and the container that owns
+// that level is the bracket behind the last one in front with depth <= (depth in front - 1) -- the partner of a close,
+// the parent of an open; the type of that container (the root context if the depth in front is not positive) must be in
+// the set of contexts the gap allows.  A close also writes both tape words of its pair (payloads:
+// annotate_previousloc, stage2_build_tape_amd64.go:335-336), and a pair at depth 0 -- a record, or the whole document
+// -- the root words around it: the open-root word in front of the open bracket points behind the close-root word that
+// follows the close bracket, and that one back at the open-root word (startContinue :196-221, succeed :428-442).
+// Returns false on a context violation.
 SJ_HD bool context_allowed(u32 mask, u8 ctx) { return (mask >> ctx) & 1u; }
-
-// ---- root words -------------------------------------------------------------------------------------------
-// tape[0], tape[tape_len-1] and the close/open pair written by every record-separating newline run
-// (startContinue, :196-221; succeed, :428-442).  nl_off[r] = tape offset of the r-th such newline's pair;
-// R = number of them; B rebases the stored indexes (NDJSON shard).
-SJ_HD void emit_root(const u32 *nl_off, u32 R, u32 tape_len, u32 r_plus1, u64 *tape, u64 B) {
-    const u64 ROOT = (u64)'r' << 56;
-    if (r_plus1 == 0) {  // first and last word
-        tape[0] = ROOT | (B + (R == 0 ? tape_len : nl_off[0] + 1));
-        tape[tape_len - 1] = ROOT | (B + (R == 0 ? 0u : nl_off[R - 1] + 1));
-        return;
+SJ_HD bool bracket_resolve(const MinTree &mt, const u32 *br_off, const u8 *br_info, u32 c, u64 tape_base, u64 *tape) {
+    const u8 k = br_info[c] & 15u;
+    const u32 gap = (u32)(br_info[c] >> 4);
+    const bool close = is_close(k);
+    const i32 d = mt.lev[0][c];
+    const i32 q = close ? d : d - 2;  // depth in front of the bracket - 1
+    if (q < 0) return context_allowed(gap, CTX_ROOT);  // nothing is open in front of it (a close is rejected: it needs OBJ / ARR)
+    const i64 j = psv(mt, (i64)c, q + 1) + 1;  // the open bracket that raised the depth to q + 1
+    const u8 jk = br_info[j] & 15u;
+    if (close) {
+        const u64 oc = br_off[c], oj = br_off[j];
+        tape[oc] = ((u64)(k == K_CLOSE_OBJ ? '}' : ']') << 56) | (tape_base + oj);
+        tape[oj] = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (tape_base + oc + 1);
+        if (d == 0) {
+            tape[oj - 1] = ((u64)'r' << 56) | (tape_base + oc + 2);
+            tape[oc + 1] = ((u64)'r' << 56) | (tape_base + oj - 1);
+        }
     }
-    const u32 r = r_plus1 - 1;
-    const u32 o = nl_off[r];
-    tape[o] = ROOT | (B + (r == 0 ? 0u : nl_off[r - 1] + 1));                 // close root of record r
-    tape[o + 1] = ROOT | (B + (r + 1 == R ? tape_len : nl_off[r + 1] + 1));  // open root of record r+1
+    return context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
 }
 
 // ---- atoms and strings: tape words ---------------------------------------------------------------------------

@@ -32,6 +32,7 @@ struct StrView {
     u64 lead, end;   // the message occupies [lead, end) of it
     const u64 *qm, *q, *st;
     const u8 *unit_h;
+    const u64 *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
     // the 16 bytes at a .. a+15 as two little-endian words (two unaligned 8-byte loads away from the message ends)
     SJ_HD void window16(u64 a, u64 &w0, u64 &w1) const {
@@ -52,6 +53,8 @@ struct StrView {
     }
     // escaped characters of chunk c (characters that follow a starter)
     SJ_HD u64 esc(u64 c) const { return (st[c] << 1) | (c ? st[c - 1] >> 63 : 0); }
+    // does chunk c hold an escaped character that no simple escape names (hypothesis-free)?
+    SJ_HD bool nonsimple(u64 c) const { return (unit_slow[c >> 6] >> (c & 63)) & 1u; }
     SJ_HD bool is_starter(u64 a) const { return (st[a >> 6] >> (a & 63)) & 1u; }
     SJ_HD bool in_string(u64 a) const { return (sm(a >> 6) >> (a & 63)) & 1u; }
 };
@@ -160,7 +163,9 @@ struct alignas(16) ChunkRec {
     u32 pre;
     u32 abs;
 };
-static constexpr u32 CHUNK_PRE_MASK = 0x7fffu, CHUNK_SLOW = 0x8000u;
+// CHUNK_GENERAL: the chunk (or the one in front of it) holds an escaped character that no simple escape names: pass 2
+// patches it with the general routine; without it the escapes of a CHUNK_SLOW chunk are simple ones
+static constexpr u32 CHUNK_PRE_MASK = 0x7fffu, CHUNK_SLOW = 0x8000u, CHUNK_GENERAL = 0x10000u;
 SJ_HD bool str_chunk_has_escapes(const StrView &m, u64 c) {
     if ((m.esc(c) & m.sm(c)) != 0) return true;
     return c > 0 && ((m.esc(c - 1) & m.sm(c - 1)) >> 60) != 0;
@@ -221,6 +226,37 @@ SJ_HD bool str_chunk_masks(const StrView &m, u64 c, u64 *em_out, u64 *um_out, bo
     if (escapes_out) *escapes_out = escapes;
     if (overflow_out) *overflow_out = overflow;
     return ok;
+}
+
+// Pass 1 without touching the message: a chunk takes the general routine above only if it or the chunk in front of it
+// holds an escaped character that no simple escape names (a \u, whose bytes may reach into this chunk, or an invalid
+// escape).  Otherwise every escape of the chunk is a simple one -- valid by construction, the starter emits nothing, the
+// escaped character emits one byte at its own position -- and the emit mask is SM & ~st.
+SJ_HD bool str_chunk_needs_general(const StrView &m, u64 c) {
+    return (m.nonsimple(c) && (m.esc(c) & m.sm(c)) != 0) || (c > 0 && m.nonsimple(c - 1));
+}
+SJ_HD bool str_chunk_masks_fast(const StrView &m, u64 c, u64 *em_out, u32 *flags_out, bool *overflow_out) {
+    *overflow_out = false;
+    if (!str_chunk_needs_general(m, c)) {
+        const u64 sm = m.sm(c);
+        *em_out = sm & ~m.st[c];
+        *flags_out = (m.esc(c) & sm) != 0 ? CHUNK_SLOW : 0u;
+        return true;
+    }
+    u64 um;
+    bool escapes;
+    const bool ok = str_chunk_masks(m, c, em_out, &um, &escapes, overflow_out);
+    *flags_out = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+    return ok;
+}
+// Pass 2 for a chunk whose escapes are all simple (CHUNK_SLOW without CHUNK_GENERAL): the escaped characters inside
+// strings -- they are all emitted -- are translated in place.  put(p, v) as below; at(p) = the chunk's byte p.
+template <typename At, typename Put>
+SJ_HD void str_chunk_patch_simple(const StrView &m, u64 c, u64 em, At at, Put put) {
+    for (u64 r = m.esc(c) & em; r != 0; r &= r - 1) {
+        const u32 p = (u32)ctz64(r);
+        put(p, escape_value(at(p)));
+    }
 }
 
 // Pass 2, one chunk: Strings.B receives the bytes of chunk c selected by its emit mask, in order, after the

@@ -35,6 +35,7 @@ namespace sj {
 struct S1Aux {
     u64 *qm, *q, *st;  // null unless every string is copied (byte-parallel unescape)
     u8 *unit_h;
+    u64 *unit_slow;    // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
     u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
@@ -199,10 +200,12 @@ __device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, const u8
 }
 // Zeroes the Stage1State and the tile descriptors (must precede every launch) and builds the two edge units.
 __global__ __launch_bounds__(256) void k_s1_prepare(const u8 *__restrict__ base, u64 lead, u64 end, u32 nu, u8 *__restrict__ edge,
-                                                    u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words) {
+                                                    u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words,
+                                                    uint4 *__restrict__ zero2, u64 zero2_quads) {
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, gsz = (u64)gridDim.x * 256;
     if (gid < sizeof(Stage1State) / 8) state[gid] = 0;
     for (u64 i = gid; i < desc_words; i += gsz) desc[i] = 0;
+    for (u64 i = gid; i < zero2_quads; i += gsz) zero2[i] = make_uint4(0u, 0u, 0u, 0u);  // stage-2 state and chain descriptors
     if (blockIdx.x < 2 && nu != 0) {
         const u64 unit = blockIdx.x == 0 ? 0 : (u64)nu - 1;
         // 16 bytes per thread, all loads in flight together (byte loads: only message bytes are touched)
@@ -362,6 +365,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // If that chunk is not all backslashes this does not depend on ITS carry-in.
         u64 quote_bits = c.quote;
         u64 starters = 0;  // backslashes that begin an escape sequence
+        u64 nonsimple = 0; // escaped characters other than " \\ / b f n r t
         const u32 bs_any = (u32)c.bs | (u32)(c.bs >> 32);
         if (__ballot(bs_any != 0) != 0 || carry0 != 0) {  // wave-uniform: many waves see no backslash at all
             const bool all_bs = c.bs == ~0ull;
@@ -370,7 +374,10 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64, end);
             const u64 escaped = escaped_mask(c.bs, carry_in);
             quote_bits &= ~escaped;
-            if (AUX) starters = c.bs & ~escaped;
+            if (AUX) {
+                starters = c.bs & ~escaped;
+                nonsimple = escaped & ~c.esc1;
+            }
         }
 
         // ---- in-string mask relative to the start of the wave unit
@@ -397,6 +404,9 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.q[ci] = quote_bits;
             aux.st[ci] = starters;
+            // (hypothesis-free: an escape outside a string makes the document invalid anyway)
+            const u64 slow = __ballot(((u32)nonsimple | (u32)(nonsimple >> 32)) != 0);
+            if (lane == 0) aux.unit_slow[unit] = slow;
         }
         // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80), per hypothesis
         const u64 in_a = c.ctrl & qm, in_b = c.ctrl & ~qm;
@@ -1014,7 +1024,7 @@ size_t stage1_workspace_bytes(size_t len) {
 }
 
 // zero the Stage1State and the tile descriptors, copy the edge units (must precede every launch)
-hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream) {
+hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2, size_t zero2_bytes) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -1024,9 +1034,11 @@ hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t s
     u64 *desc = reinterpret_cast<u64 *>(edge + S1_EDGE_BYTES);
     // the state and the descriptors are not adjacent: two ranges, one kernel (state first: 8 words)
     const u64 desc_words = plan.tiles;
-    const u32 blocks = (u32)((desc_words + 255) / 256 < 2 ? 2 : ((desc_words + 255) / 256 > 64 ? 64 : (desc_words + 255) / 256));
+    const u64 zq = zero2 ? (u64)zero2_bytes / 16 : 0;  // (a multiple of 16 bytes, 16-byte aligned: stage2_zero_bytes)
+    const u64 work = (desc_words > zq / 4 ? desc_words : zq / 4);  // ~4 quads per thread
+    const u32 blocks = (u32)((work + 255) / 256 < 2 ? 2 : ((work + 255) / 256 > 256 ? 256 : (work + 255) / 256));
     hipLaunchKernelGGL(k_s1_prepare, dim3(blocks), dim3(256), 0, stream, base, lead, lead + (u64)len, plan.tm.nu, edge,
-                       reinterpret_cast<u64 *>(w), desc, desc_words);
+                       reinterpret_cast<u64 *>(w), desc, desc_words, reinterpret_cast<uint4 *>(zero2), zq);
     return hipGetLastError();
 }
 
@@ -1055,13 +1067,14 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state};
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state};
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = a.qm;
         aux.q = a.q;
         aux.st = a.st;
         aux.unit_h = a.unit_h;
+        aux.unit_slow = a.unit_slow;
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
@@ -1109,8 +1122,9 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 }
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state) {
-    hipError_t e = stage1_prepare(d_msg, len, ws, stream);
+                         hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
+                         size_t zero2_bytes) {
+    hipError_t e = stage1_prepare(d_msg, len, ws, stream, zero2, zero2_bytes);
     if (e != hipSuccess) return e;
     return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
 }

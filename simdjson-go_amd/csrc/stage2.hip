@@ -12,9 +12,9 @@
 //                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
 //                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
 //                    separate records leave their tape offset
-//   k_min_level, k_min_upper, k_br_match, k_br_check   previous-smaller-value over the compact bracket view: partners' tape
-//                    words, container contexts, and the grammar check of every gap against its context
-//   k_roots          root words
+//   k_numbers (second role), k_min_upper, k_br_match   64-ary min tree over the compact bracket view and
+//                    previous-smaller-value queries over it: partners' tape words, the grammar check of every gap
+//                    against the type of its container, root words
 // plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,8 +73,6 @@ struct S2Dev {
     i32 *br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
     u32 *br_off;   // [n]                       its tape offset
     u8 *br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
-    u32 *br_match; // [n]                       close: its partner (k_br_match)
-    u8 *br_pctx;   // [n]                       open: the context in front of it
     TileAgg *agg;  // [tiles] aggregates, then (k_s2_scan_tiles) exclusive prefixes
     u32 tiles;
     // min tree levels 1.. (level 0 is br_depth[])
@@ -99,10 +97,24 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
     const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (c >= p.units * 64) return;  // whole waves
-    u64 em, um;
-    bool escapes, overflow;
-    if (!str_chunk_masks(p.sv, c, &em, &um, &escapes, &overflow)) atomicOr(&p.st->err, 1u);
-    if (overflow) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+    // Without touching the message (sj_strings.h str_chunk_masks_fast is the per-chunk statement): a chunk takes the
+    // general routine only if it, or the chunk in front of it, holds an escaped character that no simple escape names.
+    const u64 unit = c >> 6;
+    const u64 qm = p.sv.qm[c], q = p.sv.q[c], st = p.sv.st[c];
+    const u64 stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+    const u64 slow_w = p.sv.unit_slow[unit];
+    const bool prev_slow = lane ? ((slow_w >> (lane - 1)) & 1u) != 0 : (unit ? (p.sv.unit_slow[unit - 1] >> 63) != 0 : false);
+    const u64 sm = (p.sv.unit_h[unit] ? ~qm : qm) & ~q;
+    const u64 e = ((st << 1) | stp) & sm;  // escaped characters inside strings
+    u64 em = sm & ~st;
+    u32 flags = e != 0 ? CHUNK_SLOW : 0u;
+    if ((((slow_w >> lane) & 1u) != 0 && e != 0) || prev_slow) {
+        u64 um;
+        bool escapes, overflow;
+        if (!str_chunk_masks(p.sv, c, &em, &um, &escapes, &overflow)) atomicOr(&p.st->err, 1u);
+        if (overflow) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+        flags = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+    }
     const u32 n = (u32)popc64(em);
     u32 incl = n;
 #pragma unroll
@@ -110,8 +122,7 @@ __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
         const u32 o = __shfl_up(incl, s, 64);
         if (lane >= s) incl += o;
     }
-    // (the 'u' mask is only an intermediate: pass 2 re-derives the escapes of flagged chunks)
-    p.rec[c] = ChunkRec{em, (incl - n) | (escapes ? CHUNK_SLOW : 0u), 0u};  // .abs: k_str_emit
+    p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
     if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
@@ -224,10 +235,10 @@ __device__ __forceinline__ void unit_round_load(const u32 *data, u64 i, u64 hi, 
         for (int q = 0; q < 16; q++) v[q] = i + q < hi ? data[i + q] : 0u;
     }
 }
-__global__ __launch_bounds__(1024) void k_str_scan(S2Dev p) {
+__device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
     __shared__ u32 s_wave[2][16];
     __shared__ unsigned long long s_sum[16], s_prefix;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 *data = p.unit_cnt;
     u64 lo, hi;
     seg_range(p.units, 1024, seg, lo, hi);
@@ -325,6 +336,7 @@ constexpr SelLut make_sel_lut() {
     return t;
 }
 __constant__ SelLut c_sel = make_sel_lut();
+__constant__ EscapeLut c_esc = make_escape_lut();
 
 // Pass 2 of the string path: one 4 KiB unit per wave, one 64-byte chunk per lane.  A chunk is compacted four
 // bytes at a time: v_perm_b32 squeezes the emitted bytes of a dword together and one unaligned LDS store
@@ -337,7 +349,9 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     // unit's unescaped bytes.
     __shared__ __attribute__((aligned(16))) u8 s_io[4][4096 + 16];
     __shared__ u32 s_sel[16];
+    __shared__ u8 s_esc[256];
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
+    s_esc[threadIdx.x] = c_esc.v[threadIdx.x];
     __syncthreads();
     const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const u64 em = rec.em;
     const u32 pre_raw = rec.pre;
     const u32 pre = pre_raw & CHUNK_PRE_MASK;
-    const bool patched = (pre_raw & CHUNK_SLOW) != 0;
+    const bool patched = (pre_raw & CHUNK_SLOW) != 0, general = (pre_raw & CHUNK_GENERAL) != 0;
     const u32 n = (u32)popc64(em);
     const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
     const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
@@ -371,7 +385,15 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         if (patched) {
 #pragma unroll
             for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
-            str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
+            if (general) {
+                str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
+            } else {  // simple escapes only: translated in place, nothing is read from the message
+                const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+                for (u64 r = ((stc << 1) | stp) & em; r != 0; r &= r - 1) {
+                    const u32 ix = byte_ix((u32)ctz64(r));
+                    in8[ix] = s_esc[in8[ix]];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; q++) w[q] = in32[q * 64 + lane];
         }
@@ -547,11 +569,11 @@ __device__ __forceinline__ Agg tile_chunk_sum(const S2Dev &p, u32 first, u32 K, 
     }
     return acc;
 }
-__global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
+__device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
     __shared__ Agg s_w[16];
     __shared__ unsigned long long s_w64[16], s_s64[16];
     __shared__ SegSum s_before;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), seg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     u64 lo64, hi64;
     seg_range(p.tiles, 64, seg, lo64, hi64);
     const u32 lo = (u32)lo64, hi = (u32)hi64;
@@ -597,13 +619,15 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
                 const unsigned long long words64 = before.w + w64, bytes64 = before.s + s64;
                 p.st->final_depth = tot.d;
                 p.st->tape_len = words64 + 2ull;  // + opening root + closing root
-                p.st->strings_len = p.sv.qm ? p.st->strings_len_masks : bytes64;
+                p.st->strings_len = bytes64;      // (every string copied: strings_len_masks, left by the unit scan, counts)
                 p.st->records = tot.nb;
                 p.st->n_br = tot.bc;
                 // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
                 p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am);
                 if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
                 if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
+                // tokens behind the last bracket lie at depth 0: the root context must allow them
+                if (!context_allowed(is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am), CTX_ROOT)) atomicOr(&p.st->err, 1u);
             }
         }
     }
@@ -640,6 +664,17 @@ __global__ __launch_bounds__(1024) void k_s2_scan_tiles(S2Dev p) {
         }
         carry = agg_combine(carry, round_total);
         __syncthreads();
+    }
+}
+
+// Both small scans in one launch: blocks 0 .. SCAN_SEGS-1 scan the unit byte counts (every string copied), the others
+// the tile aggregates (as two launches each cost its ~10 us of fixed latency).
+__global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
+    if (p.sv.qm) {
+        if (blockIdx.x < SCAN_SEGS) str_scan_body(p, (int)blockIdx.x);
+        else scan_tiles_body(p, (int)blockIdx.x - SCAN_SEGS);
+    } else {
+        scan_tiles_body(p, (int)blockIdx.x);
     }
 }
 
@@ -817,11 +852,49 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
 // ---- numbers (parseNumber, parse_number.go:65-135): one queued number per lane ------------------------------------
 // The first 32 bytes of each number go to LDS (two unaligned 16-byte loads instead of one dependent byte load
 // per digit); longer numbers fall back to the message itself.
-__global__ __launch_bounds__(256) void k_numbers(S2Dev p) {
+// The same launch builds levels 1 and 2 of the min tree over the bracket depths in its blocks from `nblocks` on (both
+// only need k_s2_emit's output; as launches of their own they cost 25 us): a block takes 4096 depths -- one level-2
+// entry -- at a time, one wave per 64 of them (a level-1 entry), and folds the 64 minima through LDS.
+__device__ __forceinline__ MinTree make_tree(const S2Dev &p);
+__global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
     __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
+    if (blockIdx.x >= nblocks) {
+        const MinTree mt = make_tree(p);
+        if (mt.nlev < 2) return;
+        i32 *s_min = reinterpret_cast<i32 *>(&s_nb[0][0]);  // [4]
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const u64 n2 = (mt.size[1] + 63) / 64;  // level-2 entries (also when the tree has no level 2: one pass)
+        for (u64 b = blockIdx.x - nblocks; b < n2; b += gridDim.x - nblocks) {
+            i32 wmin = 0x7fffffff;
+            for (int i = 0; i < 16; i++) {
+                const u64 g = b * 64 + (u64)wave * 16 + i;  // (wave-uniform)
+                if (g >= mt.size[1]) break;
+                const u64 k = g * 64 + lane;
+                i32 v = k < mt.size[0] ? p.br_depth[k] : 0x7fffffff;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const i32 o = __shfl_xor(v, sft, 64);
+                    v = o < v ? o : v;
+                }
+                if (lane == 0) p.lev[1][g] = v;
+                wmin = v < wmin ? v : wmin;
+            }
+            if (mt.nlev > 2) {  // (block-uniform)
+                __syncthreads();
+                if (lane == 0) s_min[wave] = wmin;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    i32 m = s_min[0];
+                    for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
+                    p.lev[2][b] = m;
+                }
+            }
+        }
+        return;
+    }
     const u32 cnt = p.st->num_count;
     bool bad = false;
-    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += nblocks * 256) {
         const uint2 q = p.numq[j];
         const u32 at = q.x;
         const u64 rest = p.len - at;
@@ -881,12 +954,6 @@ __device__ __forceinline__ void min_level_groups(const S2Dev &p, const MinTree &
         if (lane == 0) p.lev[l][g] = v;
     }
 }
-// levels 1 and 2 (n_br / 64 and n_br / 4096 entries): grid-stride
-__global__ __launch_bounds__(256) void k_min_level(S2Dev p, int l) {
-    const MinTree mt = make_tree(p);
-    if (l >= mt.nlev) return;
-    min_level_groups(p, mt, l, (u64)blockIdx.x * 4 + (threadIdx.x >> 6), (u64)gridDim.x * 4, threadIdx.x & 63);
-}
 // levels 3.. (n_br / 262144 entries and fewer): one block, level after level
 __global__ __launch_bounds__(1024) void k_min_upper(S2Dev p) {
     const MinTree mt = make_tree(p);
@@ -933,20 +1000,28 @@ __device__ i64 wave_psv_tree(const MinTree &mt, int L, u64 idx, i32 v, int lane)
     return (i64)h;
 }
 
-static constexpr u32 BR_NONE = 0xffffffffu;
+// One rule for every bracket: the container that owns the gap in front of it -- its partner if it closes, its parent if
+// it opens -- is the bracket behind the last one in front with depth <= (depth in front - 1); the type of that
+// container (the root context if the depth in front is not positive) must be in the set of contexts the gap allows.
+// A close writes both tape words of its pair; a pair at depth 0 is a record (or the document) and also writes the root
+// words around it: the open-root word in front of it points behind its close-root word and vice versa (startContinue
+// :196-221, succeed :428-442) -- the same lines of the tape, one 16-byte store each.
 __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
     const u32 n_br = p.st->n_br;
     const MinTree mt = make_tree(p);
     const int lane = threadIdx.x & 63;
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
     const u32 waves = gridDim.x * 4;
+    const bool store = p.st->tape_len <= p.tape_cap;  // (cannot fail: the launcher sizes the tape for 2n+2 words)
+    bool bad = false;
     for (u32 g = blockIdx.x * 4 + (threadIdx.x >> 6); (u64)g * 64 < n_br; g += waves) {  // wave-uniform
         const u32 c = g * 64 + (u32)lane;
         const bool valid = c < n_br;
         const i32 dep = valid ? p.br_depth[c] : 0x7fffffff;
-        const u8 kd = valid ? (u8)(p.br_info[c] & 15u) : (u8)K_BAD;
+        const u8 info = valid ? p.br_info[c] : (u8)K_BAD;
+        const u8 kd = info & 15u;
         const bool close = is_close(kd);
-        const i32 q = close ? dep : dep - 2;  // a close looks for its partner, an open for its parent
+        const i32 q = close ? dep : dep - 2;  // depth in front of the bracket - 1
         const bool need = valid && q >= 0;
         i64 res = -1;      // compact index of the bracket in front of the partner / parent
         bool pend = need;  // not answered yet
@@ -979,50 +1054,29 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
             }
         }
         if (!valid) continue;
+        const u32 gap = (u32)(info >> 4);  // contexts the gap that ends with this bracket allows
+        if (q < 0) {  // nothing is open in front of it: the root context (a close needs OBJ / ARR and is rejected)
+            bad |= !context_allowed(gap, CTX_ROOT);
+            continue;
+        }
         const u32 j = (u32)(res + 1);  // partner (close) / parent (open); bracket 0 if nothing was found
-        if (close) {
-            if (q >= 0) {  // payloads: annotate_previousloc (stage2_build_tape_amd64.go:335-336)
-                const u32 oc = p.br_off[c], oj = p.br_off[j];
-                const u8 jk = (u8)(p.br_info[j] & 15u);
-                p.tape[oc] = ((u64)(kd == K_CLOSE_OBJ ? '}' : ']') << 56) | (p.tape_base + oj);
-                p.tape[oj] = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
-                p.br_match[c] = j;
+        const u8 jk = (u8)(p.br_info[j] & 15u);
+        bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
+        if (close && store) {  // payloads: annotate_previousloc (stage2_build_tape_amd64.go:335-336)
+            const u32 oc = p.br_off[c], oj = p.br_off[j];
+            const u64 wc = ((u64)(kd == K_CLOSE_OBJ ? '}' : ']') << 56) | (p.tape_base + oj);
+            const u64 wj = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
+            if (dep == 0) {  // a record: the root word in front of its open bracket and the one behind its close bracket
+                const u64 ro = ((u64)'r' << 56) | (p.tape_base + oc + 2), rc = ((u64)'r' << 56) | (p.tape_base + oj - 1);
+                *reinterpret_cast<uint4 *>(p.tape + oj - 1) = make_uint4((u32)ro, (u32)(ro >> 32), (u32)wj, (u32)(wj >> 32));
+                *reinterpret_cast<uint4 *>(p.tape + oc) = make_uint4((u32)wc, (u32)(wc >> 32), (u32)rc, (u32)(rc >> 32));
             } else {
-                p.br_match[c] = BR_NONE;  // closes nothing: its gap mask rejects it (a close needs OBJ / ARR)
+                p.tape[oc] = wc;
+                p.tape[oj] = wj;
             }
-        } else {  // the context in front of an open bracket = the type of its parent
-            p.br_pctx[c] = q >= 0 ? ((p.br_info[j] & 15u) == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR) : (u8)CTX_ROOT;
         }
-    }
-}
-
-// the context behind every bracket against the allowed contexts of the gap that follows it
-__global__ __launch_bounds__(256) void k_br_check(S2Dev p) {
-    const u32 n_br = p.st->n_br;
-    bool bad = false;
-    for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n_br; c += gridDim.x * 256) {
-        const u8 info = p.br_info[c], kd = info & 15u;
-        u8 ctx;
-        if (kd == K_OPEN_OBJ) ctx = CTX_OBJ;
-        else if (kd == K_OPEN_ARR) ctx = CTX_ARR;
-        else {  // behind a close the context in front of its partner resumes
-            const u32 j = p.br_match[c];
-            ctx = j == BR_NONE ? (u8)CTX_ROOT : p.br_pctx[j];
-        }
-        const u32 next = c + 1 < n_br ? (u32)(p.br_info[c + 1] >> 4) : p.st->tail_mask;  // the gap behind bracket c
-        bad |= !context_allowed(next, ctx);
-        if (c == 0) bad |= !context_allowed((u32)(info >> 4), CTX_ROOT);
     }
     if (bad) atomicOr(&p.st->err, 1u);
-}
-
-// ---- root words --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_roots(S2Dev p) {
-    const u32 R = p.st->records;
-    const u64 tape_len = p.st->tape_len;
-    if (tape_len > p.tape_cap) return;
-    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r <= R; r += (u64)gridDim.x * 256)
-        emit_root(p.nl_off, R, (u32)tape_len, (u32)r, p.tape, p.tape_base);
 }
 
 // ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
@@ -1059,10 +1113,13 @@ __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
 // ---- launcher -----------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the zeroed region: S2State and the segment slots of the two scans (zeroed by stage 1's preparation kernel)
+size_t stage2_zero_bytes() { return (sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot) + 255) / 256 * 256; }
+
 size_t stage2_workspace_bytes(size_t n) {
-    size_t b = sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot) + 256;
-    b += align_up(n + 16, 256) * 2;                 // br_info br_pctx
-    b += align_up(n * 4, 256) * 10;                 // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off br_match
+    size_t b = 256;
+    b += align_up(n + 16, 256);                     // br_info
+    b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
@@ -1073,29 +1130,27 @@ size_t stage2_workspace_bytes(size_t n) {
     return b + 4096;
 }
 
-// carve the device view out of the workspace (deterministic: both phases rebuild the same view)
-static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags, void *ws, u64 *d_tape,
-                         size_t tape_cap, u8 *d_strings, size_t strings_cap, void *str_aux) {
+// carve the device view out of the workspaces (deterministic: both phases rebuild the same view)
+static S2Dev stage2_view(const S2Args &a) {
     S2Dev p;
-    char *w = reinterpret_cast<char *>(ws);
+    const size_t n = a.n;
+    char *w = reinterpret_cast<char *>(a.ws);
     auto carve = [&](size_t bytes) {
         char *r = w;
         w += align_up(bytes, 256);
         return r;
     };
-    p.st = reinterpret_cast<S2State *>(carve(sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot)));  // zeroed together
-    p.seg_units = reinterpret_cast<SegSlot *>(reinterpret_cast<char *>(p.st) + sizeof(S2State));
+    p.st = reinterpret_cast<S2State *>(a.ws_zero);
+    p.seg_units = reinterpret_cast<SegSlot *>(reinterpret_cast<char *>(a.ws_zero) + sizeof(S2State));
     p.seg_tiles = p.seg_units + SCAN_SEGS;
-    p.msg = reinterpret_cast<const u8 *>(d_msg);
-    p.len = len;
-    p.pos = d_pos;
+    p.msg = reinterpret_cast<const u8 *>(a.d_msg);
+    p.len = a.len;
+    p.pos = a.d_pos;
     p.n = (u32)n;
-    p.ndjson = flags & 1u;
-    p.copy_strings = (flags >> 1) & 1u;
-    p.kind = d_kind;
+    p.ndjson = a.flags & 1u;
+    p.copy_strings = (a.flags >> 1) & 1u;
+    p.kind = a.d_kind;
     p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
-    p.br_pctx = reinterpret_cast<u8 *>(carve(n + 16));
-    p.br_match = reinterpret_cast<u32 *>(carve(n * 4));
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
     p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
     p.nl_off = reinterpret_cast<u32 *>(carve(n * 4));
@@ -1117,85 +1172,86 @@ static S2Dev stage2_view(const void *d_msg, size_t len, const u32 *d_pos, const 
             p.nlev++;
         }
     }
-    p.tape = d_tape;
-    p.strings = d_strings;
-    p.tape_cap = tape_cap;
-    p.strings_cap = strings_cap;
-    p.tape_base = p.strings_base = p.msg_base = 0;
+    p.tape = a.d_tape;
+    p.strings = a.d_strings;
+    p.tape_cap = a.tape_cap;
+    p.strings_cap = a.strings_cap;
+    p.tape_base = a.tape_base;
+    p.strings_base = a.strings_base;
+    p.msg_base = a.msg_base;
     // byte-parallel strings: only when every string is copied and stage 1 left its masks
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_msg);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(a.d_msg);
     p.sv.base = reinterpret_cast<const u8 *>(addr & ~(uintptr_t)63);
     p.sv.lead = addr & 63;
-    p.sv.end = p.sv.lead + len;
+    p.sv.end = p.sv.lead + a.len;
     p.sv.qm = p.sv.q = p.sv.st = nullptr;
     p.sv.unit_h = nullptr;
+    p.sv.unit_slow = nullptr;
     p.rec = nullptr;
     p.unit_cnt = nullptr;
     p.units = 0;
-    if (str_aux && p.copy_strings) {
-        const StrAux a = str_aux_layout(str_aux, (size_t)p.sv.end);
-        p.sv.qm = a.qm;
-        p.sv.q = a.q;
-        p.sv.st = a.st;
-        p.sv.unit_h = a.unit_h;
-        p.rec = reinterpret_cast<ChunkRec *>(a.rec);
-        p.unit_cnt = a.unit_cnt;
+    if (a.str_aux && p.copy_strings) {
+        const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
+        p.sv.qm = x.qm;
+        p.sv.q = x.q;
+        p.sv.st = x.st;
+        p.sv.unit_h = x.unit_h;
+        p.sv.unit_slow = x.unit_slow;
+        p.rec = reinterpret_cast<ChunkRec *>(x.rec);
+        p.unit_cnt = x.unit_cnt;
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
     return p;
 }
 
-// nl_off (tape offsets of the record-separating root pairs) and the state of the last run in workspace `ws`: query.hip
-void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off, const S2State **st) {
-    const S2Dev p = stage2_view(nullptr, 0, nullptr, nullptr, n_tokens, 0, ws, nullptr, 0, nullptr, 0, nullptr);
+// nl_off (tape offsets of the record-separating root pairs) of the last run in workspace `ws`: query.hip
+void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
+    S2Args a = {};
+    a.n = n_tokens;
+    a.ws = ws;
+    const S2Dev p = stage2_view(a);
     *nl_off = p.nl_off;
-    *st = p.st;
 }
 
-// Phase 1: token kinds and the device-wide scan of the tile aggregates.  Afterwards S2State holds tape_len /
-// strings_len of this message (what an NDJSON shard exchanges with the other shards).
-hipError_t stage2_launch_measure(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,
-                                 void *ws, hipStream_t stream, void *str_aux) {
-    const S2Dev p = stage2_view(d_msg, len, d_pos, d_kind, n, flags, ws, nullptr, 0, nullptr, 0, str_aux);
-    hipError_t e = hipMemsetAsync(p.st, 0, sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot), stream);
-    if (e != hipSuccess) return e;
-    if (n == 0) return hipSuccess;
-    if (p.sv.qm) {
-        hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(k_str_scan, dim3(SCAN_SEGS), dim3(1024), 0, stream, p);
-    }
-    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, stream, p);
-    hipLaunchKernelGGL(k_s2_scan_tiles, dim3(SCAN_SEGS), dim3(1024), 0, stream, p);
+// Phase 1: string masks, tile aggregates and the two device-wide scans.  Afterwards S2State holds tape_len /
+// strings_len of this message (what an NDJSON shard exchanges with the other shards).  The zeroed region must be zero.
+hipError_t stage2_launch_measure(const S2Args &a) {
+    const S2Dev p = stage2_view(a);
+    if (a.n == 0) return hipSuccess;
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, a.stream, p);
+    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p);
+    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * SCAN_SEGS : SCAN_SEGS), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
 }
 
-// Phase 2: tape words, bracket matching with the grammar check, roots and Strings.B.  The three bases rebase
-// every index the tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message, the
-// exclusive prefix sums over the preceding shards for an NDJSON shard.
-hipError_t stage2_launch_emit(const void *d_msg, size_t len, const u32 *d_pos, const u8 *d_kind, size_t n, u32 flags,
-                              void *ws, u64 *d_tape, size_t tape_cap, u8 *d_strings, size_t strings_cap, u64 tape_base,
-                              u64 strings_base, u64 msg_base, hipStream_t stream, void *str_aux) {
-    S2Dev p = stage2_view(d_msg, len, d_pos, d_kind, n, flags, ws, d_tape, tape_cap, d_strings, strings_cap, str_aux);
-    p.tape_base = tape_base;
-    p.strings_base = strings_base;
-    p.msg_base = msg_base;
+// Phase 2: tape words, bracket matching with the grammar check and the root words, Strings.B.  The three bases
+// rebase every index the tape stores (tape positions, Strings.B offsets, Message offsets): 0 for a whole message,
+// the exclusive prefix sums over the preceding shards for an NDJSON shard.
+hipError_t stage2_launch_emit(const S2Args &a) {
+    const S2Dev p = stage2_view(a);
+    const size_t n = a.n;
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
     // the string bytes first: k_str_emit also leaves every chunk's absolute Strings.B offset for k_s2_emit
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, stream, p);
-    if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, stream, p);
-    hipLaunchKernelGGL(k_numbers, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    for (int l = 1; l < p.nlev && l <= 2; l++) {  // grid-stride: the kernels use the real bracket count
-        const u64 want = (p.lev_size[l] + 3) / 4;
-        hipLaunchKernelGGL(k_min_level, dim3((u32)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p, l);
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, a.stream, p);
+    if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count)
+        const u32 nblocks = gb < 2048 ? gb : 2048;
+        const u64 want = p.nlev > 1 ? (p.lev_size[1] + 63) / 64 : 0;  // one block per 4096 depths at a time
+        const u32 lblocks = (u32)(want < 2048 ? want : 2048);
+        hipLaunchKernelGGL(k_numbers, dim3(nblocks + lblocks), dim3(256), 0, a.stream, p, nblocks);
     }
-    if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_br_check, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_roots, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, stream, p);
-    if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, stream, p);
+    if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
+    if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
+    hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, a.stream, p);
+    return hipGetLastError();
+}
+
+// exact tie-break of the queued numbers (S2State::bignum_count != 0 after the emit phase: rare)
+hipError_t stage2_launch_bignum(const S2Args &a) {
+    const S2Dev p = stage2_view(a);
+    hipLaunchKernelGGL(k_bignum, dim3(64), dim3(64), 0, a.stream, p);
     return hipGetLastError();
 }
 

@@ -165,13 +165,86 @@ func Parse(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, erro
 	return parsed, nil
 }
 
-// ParseND will parse newline delimited JSON objects or arrays (simdjson_amd64.go:82).
+// multiPool holds handles that own one context per visible GPU (sjhip_multi_*): ParseND of a large message is cut at
+// record boundaries into one shard per device inside the library.
+var multiPool = sync.Pool{New: func() interface{} {
+	h := C.sjhip_multi_create(nil, 0)
+	if h == nil {
+		return (*hipMulti)(nil)
+	}
+	m := &hipMulti{h: h}
+	runtime.SetFinalizer(m, func(m *hipMulti) { C.sjhip_multi_destroy(m.h) })
+	return m
+}}
+
+type hipMulti struct{ h *C.sjhip_multi }
+
+// messages below this size stay on one device (a shard should keep a GPU busy for longer than its fixed costs)
+const multiMinBytes = 32 << 20
+
+// parseMessageMulti is parseMessage(msg, true) over every GPU of the node.
+func (pj *internalParsedJson) parseMessageMulti(msg []byte) error {
+	m, _ := multiPool.Get().(*hipMulti)
+	if m == nil {
+		return errors.New("Host CPU does not meet target specs")
+	}
+	defer multiPool.Put(m)
+	var flags C.uint32_t = C.SJHIP_FLAG_NDJSON
+	if pj.copyStrings {
+		flags |= C.SJHIP_FLAG_COPY_STRINGS
+	}
+	var tapeLen, stringsLen, msgOff, msgLen C.size_t
+	rc := C.sjhip_parse_nd_multi(m.h, (*C.uint8_t)(unsafe.Pointer(&msg[0])), C.size_t(len(msg)), flags, &tapeLen, &stringsLen, &msgOff, &msgLen)
+	runtime.KeepAlive(msg)
+	switch rc {
+	case C.SJHIP_OK:
+	case C.SJHIP_ERR_STAGE1:
+		return errors.New("Failed to find all structural indices for stage 1")
+	case C.SJHIP_ERR_STAGE2:
+		return errors.New("Bad parsing while executing stage 2")
+	default:
+		return fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_multi_last_error(m.h)))
+	}
+	pj.Message = msg[int(msgOff) : int(msgOff)+int(msgLen)]
+	if cap(pj.Tape) < int(tapeLen) {
+		pj.Tape = make([]uint64, int(tapeLen))
+	}
+	pj.Tape = pj.Tape[:int(tapeLen)]
+	if pj.Strings == nil {
+		pj.Strings = &TStrings{}
+	}
+	if cap(pj.Strings.B) < int(stringsLen) {
+		pj.Strings.B = make([]byte, int(stringsLen))
+	}
+	pj.Strings.B = pj.Strings.B[:int(stringsLen)]
+	var tp *C.uint64_t
+	var sp *C.uint8_t
+	if tapeLen > 0 {
+		tp = (*C.uint64_t)(unsafe.Pointer(&pj.Tape[0]))
+	}
+	if stringsLen > 0 {
+		sp = (*C.uint8_t)(unsafe.Pointer(&pj.Strings.B[0]))
+	}
+	if rc := C.sjhip_fetch_multi(m.h, tp, sp); rc != C.SJHIP_OK {
+		return fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_multi_last_error(m.h)))
+	}
+	return nil
+}
+
+// ParseND will parse newline delimited JSON objects or arrays (simdjson_amd64.go:82).  On a node with several GPUs a
+// large message is sharded over all of them at record boundaries (sjhip_parse_nd_multi); the result is the same
+// ParsedJson bit for bit.
 func ParseND(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, error) {
 	pj, err := newInternalParsedJson(reuse, opts)
 	if err != nil {
 		return nil, err
 	}
-	if err = pj.parseMessage(b, true); err != nil {
+	if len(b) >= multiMinBytes && int(C.sjhip_device_count()) > 1 {
+		err = pj.parseMessageMulti(b)
+	} else {
+		err = pj.parseMessage(b, true)
+	}
+	if err != nil {
 		return nil, err
 	}
 	return &pj.ParsedJson, nil

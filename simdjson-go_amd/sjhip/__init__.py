@@ -6,5 +6,5 @@ Mirrors the reference's backend symbol set (simdjson_other.go:29-76):
     ParseNDStream(r, res, reuse) -> parse_nd_stream(reader, ...)   (a generator instead of a channel)
 """
 from ._lib import SjhipMissing, lib  # noqa: F401
-from .api import (Context, ParsedJson, ParseError, parse, parse_nd, stage1, supported)  # noqa: F401
+from .api import (Context, MultiContext, ParsedJson, ParseError, parse, parse_nd, stage1, supported)  # noqa: F401
 from .stream import cut_blocks, parse_nd_stream  # noqa: F401

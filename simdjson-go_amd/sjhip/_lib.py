@@ -32,6 +32,12 @@ SYMBOLS = {
     "sjhip_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_parse_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_parse_shard_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "sjhip_multi_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int]),
+    "sjhip_multi_destroy": (None, [C.c_void_p]),
+    "sjhip_multi_shards": (C.c_int, [C.c_void_p]),
+    "sjhip_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "sjhip_parse_nd_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
+    "sjhip_fetch_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sjhip_trim_space": (None, [C.c_void_p, C.c_size_t, szp, szp]),
     "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
     "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,

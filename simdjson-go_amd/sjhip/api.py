@@ -181,6 +181,53 @@ class Context:
         return tape, strings
 
 
+class MultiContext:
+    """ParseND over several GPUs in one call (include/sjhip.h: sjhip_multi_*): one shard per entry of `devices`
+    (None = every visible device; a device may be listed more than once)."""
+
+    def __init__(self, devices=None):
+        L = _lib.lib()
+        if devices is None:
+            self._h = L.sjhip_multi_create(None, 0)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self._h = L.sjhip_multi_create(arr, len(devices))
+        if not self._h:
+            raise ParseError(ERR_NODEVICE, 3)
+        self.shards = L.sjhip_multi_shards(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.lib().sjhip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse_nd(self, data, copy_strings=True):
+        """ParseND(data): the merged ParsedJson of all shards (bit for bit what one context returns)."""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        L = _lib.lib()
+        rc = L.sjhip_parse_nd_multi(self._h, a.ctypes.data if a.size else None, a.size, FLAG_NDJSON | (FLAG_COPY_STRINGS if copy_strings else 0),
+                                    C.byref(tl), C.byref(sl), C.byref(mo), C.byref(ml))
+        if rc == 1:
+            raise ParseError(ERR_STAGE1, rc)
+        if rc == 2:
+            raise ParseError(ERR_STAGE2, rc)
+        if rc:
+            raise ParseError(f"sjhip error {rc}: {L.sjhip_multi_last_error(self._h).decode()}", rc)
+        tape = np.empty(tl.value, dtype=np.uint64)
+        strings = np.empty(sl.value, dtype=np.uint8)
+        rc = L.sjhip_fetch_multi(self._h, tape.ctypes.data, strings.ctypes.data)
+        if rc:
+            raise ParseError(f"sjhip error {rc}: {L.sjhip_multi_last_error(self._h).decode()}", rc)
+        return ParsedJson(a[mo.value: mo.value + ml.value].tobytes(), tape, strings)
+
+
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 

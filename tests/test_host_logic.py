@@ -112,3 +112,21 @@ def test_stream_block_cutter():
                 self.p += n
                 return n
         assert b"".join(cut_blocks(Raw(data), bs)) == data
+
+
+def test_classify_every_byte_value():
+    """classify() of sj_chunk.h (bit planes + three-input boolean networks) against the byte definitions of the
+    classes, every byte value at every position of a chunk; esc1 = the characters a simple escape may name
+    (escape_map, parse_string_amd64.s:38-69)."""
+    L = C.CDLL(G.build_selftest())
+    L.sj_selftest_classify.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+    want = {0: lambda b: b == 0x5c, 1: lambda b: b == 0x22, 2: lambda b: b in b"{}[]:,", 3: lambda b: b in b" \t\n\r",
+            4: lambda b: b < 0x20, 5: lambda b: b == 0x0a, 6: lambda b: b in b'"\\/bfnrt'}
+    out = (C.c_uint64 * 7)()
+    for base in range(0, 256, 64):
+        for rot in (0, 1, 17):
+            chunk = bytes(((base + (j + rot) % 64) & 0xff) for j in range(64))
+            L.sj_selftest_classify(chunk, out)
+            for k, f in want.items():
+                m = sum(1 << j for j in range(64) if f(chunk[j]))
+                assert out[k] == m, (k, base, rot, hex(out[k]), hex(m))
