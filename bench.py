@@ -202,6 +202,7 @@ def main():
             "algorithmic_bytes": algo_bytes,
             "input_GBps": round(n_bytes / (k_ms * 1e-3) / 1e9, 1),
             "input_frac": round(n_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_source_box": "committed profile (profiles/stage1_pmc.json), not this run: rocprofv3 PMC passes need their own runs",
             "note": "achieved = (N + 4*S) bytes / hipEvent kernel time of this run; traffic and read_frac use the HBM counters of "
                     "the committed rocprofv3 PMC passes (profiles/stage1_pmc.json: 2*FETCH_SIZE + WRITE_SIZE per launch)"}
     if pmc:
@@ -260,6 +261,40 @@ def main():
                                  "sjhip_parse_device (two host syncs included); per-kernel averages: profiles/r02_parse_kernels.json"}}
         del d_pos
 
+        # ---- Parse() of the single documents BASELINE.json names: configs[0] twitter.json, configs[2] canada.json
+        # (number-heavy), configs[3] twitterescaped.json (escape-heavy).  host_to_host: sjhip_parse + sjhip_fetch from a
+        # host buffer into host arrays (PCIe both ways, what the Go binding's Parse() costs); device: the same parse
+        # with the document resident in HBM and the result left there.
+        if rank == 0:
+            import fixtures
+            import numpy as np
+            singles = {}
+            for key, name in (("parse_c0_twitter", "twitter"), ("parse_c2_canada", "canada"), ("parse_c3_twitterescaped", "twitterescaped")):
+                raw = fixtures.load(name)
+                arr = np.frombuffer(raw, dtype=np.uint8)
+                pj = ctx.parse(arr)
+                reuse = pj
+                t_h2h = timed(lambda: ctx.parse(arr, reuse=reuse), 50)
+                d_one = device_doc(raw)
+                tl1 = sl1 = 0
+
+                def one():
+                    nonlocal tl1, sl1
+                    tl1, sl1 = ctx.parse_device(d_one.data_ptr(), len(raw), ndjson=False, copy_strings=True)
+                t_dev = timed(one, 50)
+                s_one = int(ctx.stage1(arr)[1].size)
+                algo = (len(raw) + 4 * s_one) + (4 * s_one + len(raw) + 8 * tl1 + sl1)
+                singles[key] = {"workload": f"Parse({name}.json), {len(raw)} B, every string copied", "structurals": s_one,
+                                "tape_words": tl1, "strings_bytes": sl1,
+                                "host_to_host_us": round(t_h2h * 1e6, 1), "host_to_host_GBps": round(len(raw) / t_h2h / 1e9, 2),
+                                "device_us": round(t_dev * 1e6, 1), "device_GBps": round(len(raw) / t_dev / 1e9, 2),
+                                "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / t_dev / 1e9, 1),
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / t_dev / 1e9 / HBM_PEAK_GBS, 5),
+                                             "note": "a document of this size is bound by launch and synchronisation latency, not by "
+                                                     "HBM: see DESIGN.md (fixed costs per call)"}}
+                del d_one
+            extra["single_documents"] = singles
+
         # ---- NDJSON (configs[4]): parking-citations x1000 sharded over the ranks at record boundaries.  Each rank runs
         # phase 1 (stage 1 + measure); the ranks all_gather (tape_len, strings_len, return code) over RCCL; phase 2
         # emits tape / Strings.B with the rebased indices (tests/test_ndshard_gloo.py, tests/test_gpu_parse.py).
@@ -268,28 +303,34 @@ def main():
         a, b = ndshard.record_cuts(nd_all, world)[rank]
         shard = nd_all[a:b].rstrip(b"\n")
         d_nd = device_doc(shard)
-        box = torch.zeros(3, dtype=torch.int64, device=dev)
         s_nd = shard.count(b"\n") + 1
+
+        def nd_begin():
+            nonlocal tl, sl
+            t_, s_ = C.c_size_t(0), C.c_size_t(0)
+            ctx._check(L.sjhip_parse_shard_begin(ctx._h, C.c_void_p(d_nd.data_ptr()), len(shard), 3, C.byref(t_), C.byref(s_)))
+            tl, sl = t_.value, s_.value
+            return tl, sl
+
+        def nd_finish(tape_base, strings_base, msg_base):
+            ctx._check(L.sjhip_parse_shard_finish(ctx._h, tape_base, strings_base, msg_base))
+            return None, None  # the tape / Strings.B stay in HBM (the bench measures the parse, not the fetch)
+
+        def nd_gather(vals):  # the only exchange of the data path: 8 bytes per value and rank (RCCL all_gather)
+            if not distributed:
+                return [tuple(vals)]
+            mine = torch.tensor(list(vals), dtype=torch.int64, device=dev)
+            got = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            return [tuple(int(x) for x in g) for g in got]
 
         def ndp():
             nonlocal tl, sl
-            t_, s_ = C.c_size_t(0), C.c_size_t(0)
-            rc = L.sjhip_parse_shard_begin(ctx._h, C.c_void_p(d_nd.data_ptr()), len(shard), 3, C.byref(t_), C.byref(s_))
-            tl, sl = t_.value, s_.value
-            tb = sb_ = 0
-            if distributed:  # the only exchange of the data path: 24 bytes per rank
-                box[0], box[1], box[2] = tl, sl, rc
-                gathered = [torch.zeros_like(box) for _ in range(world)]
-                dist.all_gather(gathered, box)
-                codes = [int(g[2]) for g in gathered]
-                if any(codes):
-                    raise ndshard.ShardError(1 if 1 in codes else next(c for c in codes if c), [r for r, c in enumerate(codes) if c])
-                for r in range(rank):
-                    tb += int(gathered[r][0])
-                    sb_ += int(gathered[r][1])
-            else:
-                ctx._check(rc)
-            ctx._check(L.sjhip_parse_shard_finish(ctx._h, tb, sb_, a))
+            if not distributed:  # one GPU: plain ParseND of the whole document, no shard phases
+                tl, sl = ctx.parse_device(d_nd.data_ptr(), len(shard), ndjson=True, copy_strings=True)
+            else:  # the control flow is sjhip.ndshard's (the one the 2-rank tests run); the shard is resident in HBM
+                ndshard.run_shard(rank, world, len(shard) == 0, nd_begin, nd_finish, nd_gather, a)
+
         if distributed:
             dist.barrier()
         t_nd = timed(ndp, reps)
@@ -368,6 +409,8 @@ def main():
         line = {
             "metric": METRIC,
             "value": round(value, 2),
+            "value_is": "stage 1 only (configs[1] as BASELINE.json names it); stage1+stage2 of the same document: value_stage1_stage2",
+            "value_stage1_stage2": (extra.get("full_parse") or {}).get("GBps"),
             "unit": "GB/s",
             "n_gpus": world,
             "steps": args.steps,

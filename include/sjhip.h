@@ -125,7 +125,21 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
  *   fetch_serialized : writes the framed stream into `dst` (>= stream_len bytes): header varints from the host, the
  *                      three columns straight from the device */
 int sjhip_serialize(sjhip_ctx *ctx, size_t *tags_len, size_t *values_len, size_t *strings_len, size_t *stream_len);
+/* SJHIP_SER_DEDUP: strings are de-duplicated like the reference's indexString (parsed_serialize.go:836-857) does -- a
+ * string equal to the first string of the document in its hash slot is stored once (2^20 slots; deterministic, where the
+ * reference's table is keyed by a per-process random hash) -- and the string column holds the kept strings only. */
+#define SJHIP_SER_DEDUP 1u
+int sjhip_serialize_ex(sjhip_ctx *ctx, uint32_t flags, size_t *tags_len, size_t *values_len, size_t *strings_len,
+                       size_t *stream_len);
 int sjhip_fetch_serialized(sjhip_ctx *ctx, uint8_t *dst, size_t cap, size_t *len);
+/* Serializer.Deserialize (parsed_serialize.go:466-695) of a stream whose blocks are uncompressed (what
+ * sjhip_fetch_serialized writes; S2 / zstd blocks are decompressed on the host first): the tape is rebuilt on the device
+ * from the tag and value columns (two prefix sums and one scatter pass; closing brackets from their openers).  Like the
+ * reference's result the strings point into pj.Message (= the string column) and Strings.B is what the stream carried
+ * (empty for version 3).  sjhip_fetch copies Tape / Strings.B, sjhip_fetch_message pj.Message (message_len bytes). */
+int sjhip_deserialize(sjhip_ctx *ctx, const uint8_t *stream, size_t len, size_t *tape_len, size_t *strings_len,
+                      size_t *message_len);
+int sjhip_fetch_message(sjhip_ctx *ctx, uint8_t *dst);
 
 /* ---- Iter.MarshalJSON on the device (parsed_json.go:401-556) ---------------------------------------------------------
  * The device-resident result of the last parse as compact JSON text, records separated by '\n' -- byte for byte what

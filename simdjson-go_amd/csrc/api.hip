@@ -79,7 +79,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
+                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
@@ -129,9 +129,13 @@ static void invalidate_result(sjhip_ctx *ctx) {
     ctx->f_valid = 0;
 }
 
-int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
-                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind, void *zero2,
-                          size_t zero2_bytes) {
+// stage 1 in two halves: enqueue (workspace, launch; the last block of the kernel leaves the packed result -- count,
+// flags, the last message byte -- in one word of pinned host memory: no copy kernels behind the launch) and, once the
+// stream has been synchronised, collect (the reference's end-of-document verdict).  (Polling the word instead of
+// synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
+// would hand positions to other streams before they are visible there.)
+int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
+                       uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -139,21 +143,21 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    // the last block of the kernel leaves the packed result (count, flags, the last message byte) in one word of pinned
-    // host memory: one stream synchronisation, no copy kernels behind the launch.  (Polling the word instead of
-    // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
-    // would hand positions to other streams before they are visible there.)
+    if (len > 0) {
+        *(volatile unsigned long long *)ctx->h_scratch = 0;
+        HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
+                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
+               "stage1 launch");
+    }
+    return SJHIP_OK;
+}
+
+int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok) {
     Stage1State hs_v;
     Stage1State *hs = &hs_v;
     memset(hs, 0, sizeof *hs);
     if (len > 0) {
-        volatile unsigned long long *hw = (volatile unsigned long long *)ctx->h_scratch;
-        *hw = 0;
-        HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
-                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
-               "stage1 launch");
-        HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
-        const unsigned long long word = *hw;
+        const unsigned long long word = *(volatile unsigned long long *)ctx->h_scratch;
         if (!(word & S1_HOST_VALID)) {
             ctx_set_error(ctx, "stage-1 kernel left no result");
             return SJHIP_ERR_HIP;
@@ -172,6 +176,15 @@ int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndj
     *n = (size_t)hs->total;
     *ok = stage1_verdict(*hs, len, last_byte);
     return SJHIP_OK;
+}
+
+int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
+                          uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind, void *zero2,
+                          size_t zero2_bytes) {
+    int rc = stage1_enqueue(ctx, d_msg, len, ndjson, d_pos, pos_cap, str_aux, d_kind, zero2, zero2_bytes);
+    if (rc) return rc;
+    if (len > 0) HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
+    return stage1_collect(ctx, len, last_byte, have_last, n, ok);
 }
 
 int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,

@@ -3,6 +3,8 @@
 // and the reference's error precedence (a stage-1 failure is reported even when stage 2 would
 // fail as well, :97-105 and :123-126).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/sjhip.h"
@@ -20,18 +22,28 @@ using namespace sj;
 
 // Phase 1 (parse_begin): stage 1, then stage 2 up to the device-wide scans; a shard reads back the sizes.
 // Phase 2 (parse_finish): the rest of stage 2 with the rebasing offsets, then the verdict.
+// documents up to this size are parsed with one host synchronisation (SJHIP_SMALL_BYTES overrides; 0 turns it off)
+static size_t small_document_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("SJHIP_SMALL_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)4 << 20;
+    }();
+    return v;
+}
+
 static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base) {
     S2Args a = {};
     a.d_msg = ctx->p_msg;
     a.len = ctx->p_len;
     a.d_pos = (const uint32_t *)ctx->d_pos.p;
     a.d_kind = ctx->p_kind;
-    a.n = ctx->p_n;
+    a.n = ctx->p_nlay;
+    a.n_dev = ctx->p_deferred ? (const unsigned long long *)((const char *)ctx->d_ws.p + offsetof(Stage1State, total)) : nullptr;
     a.flags = ctx->p_flags;
     a.ws_zero = ctx->d_s2z.p;
     a.ws = ctx->d_s2.p;
     a.d_tape = (uint64_t *)ctx->d_tape.p;
-    a.tape_cap = 2 * ctx->p_n + 2;
+    a.tape_cap = 2 * ctx->p_nlay + 2;
     a.d_strings = (uint8_t *)ctx->d_strings.p;
     a.strings_cap = ctx->p_len + 64;
     a.tape_base = tape_base;
@@ -73,8 +85,21 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 64) * (sizeof(uint32_t) + 1));
         if (rc) return rc;
         ctx->p_kind = (uint8_t *)ctx->d_pos.p + (pos_cap + 64) * sizeof(uint32_t);
-        rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                               have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
+        // A small document is not worth a host round trip in the middle: stage 2 is queued behind stage 1 with arenas
+        // and grids sized for the upper bound (a token is at least one byte), the kernels read the token count on the
+        // device, and stage 1's verdict is taken after the one synchronisation at the end.  (A shard needs its sizes first.)
+        ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes();
+        if (ctx->p_deferred) {
+            rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
+                                ctx->d_s2z.p, stage2_zero_bytes());
+            n = len;
+            ok = 1;
+            ctx->p_last = last_byte;
+            ctx->p_have_last = have_last;
+        } else {
+            rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
+                                   have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
+        }
         if (rc) return rc;
     }
     if (!ok) return SJHIP_ERR_STAGE1;
@@ -89,6 +114,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->p_msg = d_msg;
     ctx->p_len = len;
     ctx->p_n = n;
+    ctx->p_nlay = n;
     ctx->p_flags = flags;
     HIPCHK(stage2_launch_measure(s2_args(ctx, 0, 0, 0)), "stage2 launch (measure)");
     if (tape_len || strings_len) {  // only the sharded path needs the sizes before phase 2
@@ -131,6 +157,14 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     };
     int rc = run();
     if (rc) return rc;
+    if (ctx->p_deferred) {  // stage 1's verdict first, as in parseMessage (parse_json_amd64.go:97-105,123-126)
+        size_t n = 0;
+        int ok = 0;
+        rc = stage1_collect(ctx, ctx->p_len, ctx->p_last, ctx->p_have_last, &n, &ok);
+        if (rc) return rc;
+        if (!ok) return SJHIP_ERR_STAGE1;
+        ctx->p_n = n;  // (the arrays stay laid out for p_nlay)
+    }
     if ((hs->err & S2_ERR_SERIAL_STRINGS) && ctx->p_aux) {
         // a run of > SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string path
         // gave up, nothing of this run is a verdict.  Stage 2 again with the per-string walks (linear in the run).

@@ -389,7 +389,7 @@ static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint
         return SJHIP_ERR_ARG;
     }
     const uint32_t *nl = nullptr;
-    stage2_records_view(ctx->d_s2.p, ctx->p_n, &nl);
+    stage2_records_view(ctx->d_s2.p, ctx->p_nlay, &nl);
     q->tape = (const u64 *)ctx->d_tape.p;
     q->tape_len = ctx->tape_len;
     q->strings = (const u8 *)ctx->d_strings.p;

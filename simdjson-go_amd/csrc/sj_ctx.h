@@ -20,6 +20,7 @@ struct sjhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
+    sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
@@ -29,11 +30,17 @@ struct sjhip_ctx {
     size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
     int f_valid = 0;              // a filtered result is resident (sjhip_fetch_filtered)
     int ser_valid = 0;            // last sjhip_serialize (serialize.hip): column sizes, framed stream size
-    size_t ser_tags = 0, ser_vals = 0, ser_rest = 0, ser_stream = 0;
+    size_t ser_tags = 0, ser_vals = 0, ser_rest = 0, ser_stream = 0, ser_slen = 0;
+    int ser_dedup = 0;
+    size_t des_msg_len = 0;       // last sjhip_deserialize: length of pj.Message (in d_msg)
     int ms_valid = 0;             // last sjhip_marshal_json (marshal.hip): the text is in d_qtape
     size_t ms_len = 0;
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
+    int p_deferred = 0;   // stage 1's result has not been collected yet (small documents: one synchronisation per parse)
+    uint8_t p_last = 0;   // ... its caller-supplied last byte
+    int p_have_last = 0;
+    size_t p_nlay = 0;    // the token count the stage-2 arrays were laid out for (>= p_n)
     const void *p_msg = nullptr;
     size_t p_len = 0, p_n = 0;
     uint32_t p_flags = 0;
@@ -46,6 +53,9 @@ namespace sj {
 void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
+int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
+                   uint8_t *d_kind, void *zero2, size_t zero2_bytes);
+int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                       uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr,
                       void *zero2 = nullptr, size_t zero2_bytes = 0);

@@ -49,7 +49,8 @@ struct S2Args {
     size_t len;
     const uint32_t *d_pos;
     const uint8_t *d_kind;  // the token kinds stage 1 wrote next to the positions
-    size_t n;               // tokens
+    size_t n;               // tokens; with n_dev an upper bound (the arrays and grids are sized for it)
+    const unsigned long long *n_dev;  // null, or Stage1State::total on the device: the host did not wait for stage 1
     uint32_t flags;
     void *ws_zero;          // stage2_zero_bytes(): zero before the measure phase (stage 1's preparation kernel does it)
     void *ws;               // stage2_workspace_bytes(n)

@@ -39,7 +39,13 @@ struct S1Aux {
     u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
+    u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
 };
+#if defined(SJ_EXP)
+#define SJ_S1EXP(a, b) ((((a).exp >> (b)) & 1u) != 0)
+#else
+#define SJ_S1EXP(a, b) false
+#endif
 // End of a block (after a block barrier: every wave has issued its last update of *st).  The block that finds all the
 // others finished publishes the state -- and the last message byte -- to the host record.
 __device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len) {
@@ -399,7 +405,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
-        if (AUX && aux.qm && unit_off < end) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+        if (AUX && aux.qm && unit_off < end && !SJ_S1EXP(aux, 8)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.q[ci] = quote_bits;
@@ -496,7 +502,12 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
                 const u32 c4 = (fits ? cnt : 0u) & ~3u;
                 for (u32 i = (u32)lane * 4u; i < c4; i += 256u) {
                     const uint4 at = *reinterpret_cast<const uint4 *>(stage + i);
+#if defined(SJ_EXP)
+                    const bool ld = msg0 != nullptr;
+                    const u8 b0 = ld ? msg0[at.x] : (u8)'"', b1 = ld ? msg0[at.y] : (u8)'"', b2 = ld ? msg0[at.z] : (u8)'"', b3 = ld ? msg0[at.w] : (u8)'"';
+#else
                     const u8 b0 = msg0[at.x], b1 = msg0[at.y], b2 = msg0[at.z], b3 = msg0[at.w];
+#endif
                     *reinterpret_cast<uint4 *>(out_pos + gd + i) = at;
                     const u32 k4 = (u32)s_klut[b0] | ((u32)s_klut[b1] << 8) | ((u32)s_klut[b2] << 16) | ((u32)s_klut[b3] << 24);
                     *reinterpret_cast<u32 *>(kind_out + gd + i) = k4;
@@ -505,7 +516,11 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
                     if (fits || gd + i < pos_cap) {
                         const u32 at = stage[i];
                         out_pos[gd + i] = at;
+#if defined(SJ_EXP)
+                        kind_out[gd + i] = s_klut[msg0 ? msg0[at] : (u8)'"'];
+#else
                         kind_out[gd + i] = s_klut[msg0[at]];
+#endif
                     }
                 }
             } else if (fits) {
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             u64 tile_end = 0;
             err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
                                            out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr,
-                                           base + lead, s_klut);
+                                           SJ_S1EXP(aux, 7) ? nullptr : base + lead, s_klut);
             if (t_prev == num_tiles - 1 && tid == 0)
                 __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
@@ -1067,7 +1082,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state};
+    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state, 0u};
+#if defined(SJ_EXP)
+    if (const char *e = getenv("SJHIP_EXP")) aux.exp = (u32)strtoul(e, nullptr, 0);
+#endif
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = a.qm;

@@ -18,6 +18,7 @@
 // plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sj_bignum.h"
 #include "sj_chunk.h"
@@ -62,7 +63,9 @@ struct S2Dev {
     const u8 *msg;
     u64 len;
     const u32 *pos;
-    u32 n;
+    u32 n;         // tokens -- or, with n_dev, an upper bound the arrays are sized for
+    const unsigned long long *n_dev;  // null, or the token count on the device (Stage1State::total): the host has not
+                                      // waited for stage 1 (small documents: one synchronisation per parse)
     u32 ndjson, copy_strings;
     const u8 *kind;  // [n] token kinds (stage 1 writes them next to the positions)
     u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
@@ -90,40 +93,74 @@ struct S2Dev {
     ChunkRec *rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
     u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
     u64 units;
+    u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
 };
+#if defined(SJ_EXP)
+#define SJ_EXPBIT(p, b) ((((p).exp >> (b)) & 1u) != 0)
+#else
+#define SJ_EXPBIT(p, b) false
+#endif
+__device__ __forceinline__ u32 token_count(const S2Dev &p) { return p.n_dev ? (u32)*p.n_dev : p.n; }
 
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
 __global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
-    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if (c >= p.units * 64) return;  // whole waves
     // Without touching the message (sj_strings.h str_chunk_masks_fast is the per-chunk statement): a chunk takes the
     // general routine only if it, or the chunk in front of it, holds an escaped character that no simple escape names.
-    const u64 unit = c >> 6;
-    const u64 qm = p.sv.qm[c], q = p.sv.q[c], st = p.sv.st[c];
-    const u64 stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-    const u64 slow_w = p.sv.unit_slow[unit];
-    const bool prev_slow = lane ? ((slow_w >> (lane - 1)) & 1u) != 0 : (unit ? (p.sv.unit_slow[unit - 1] >> 63) != 0 : false);
-    const u64 sm = (p.sv.unit_h[unit] ? ~qm : qm) & ~q;
-    const u64 e = ((st << 1) | stp) & sm;  // escaped characters inside strings
-    u64 em = sm & ~st;
-    u32 flags = e != 0 ? CHUNK_SLOW : 0u;
-    if ((((slow_w >> lane) & 1u) != 0 && e != 0) || prev_slow) {
-        u64 um;
-        bool escapes, overflow;
-        if (!str_chunk_masks(p.sv, c, &em, &um, &escapes, &overflow)) atomicOr(&p.st->err, 1u);
-        if (overflow) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
-        flags = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
-    }
-    const u32 n = (u32)popc64(em);
-    u32 incl = n;
+    // Persistent waves: unit wave_id, wave_id + waves, ...; the masks of the next unit are requested before the current
+    // one is worked on.
+    const int lane = threadIdx.x & 63;
+    const u64 nwaves = (u64)gridDim.x * 4;
+    u64 unit = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= p.units) return;  // whole waves
+    struct In {
+        u64 qm, q, st, stp, slow_w, slow_p;
+        u8 h;
+    };
+    auto load = [&](u64 u) {
+        const u64 c = u * 64 + lane;
+        In r;
+        r.qm = p.sv.qm[c];
+        r.q = p.sv.q[c];
+        r.st = p.sv.st[c];
+        r.stp = c ? p.sv.st[c - 1] : 0ull;
+        r.slow_w = p.sv.unit_slow[u];
+        r.slow_p = u ? p.sv.unit_slow[u - 1] : 0ull;
+        r.h = p.sv.unit_h[u];
+        return r;
+    };
+    In in = load(unit);
+    for (;;) {
+        const u64 c = unit * 64 + lane;
+        const u64 next = unit + nwaves;
+        const bool more = next < p.units;  // wave-uniform
+        In in_n = in;
+        if (more) in_n = load(next);
+        const u64 stp = in.stp >> 63;
+        const bool prev_slow = lane ? ((in.slow_w >> (lane - 1)) & 1u) != 0 : (in.slow_p >> 63) != 0;
+        const u64 sm = (in.h ? ~in.qm : in.qm) & ~in.q;
+        const u64 e = ((in.st << 1) | stp) & sm;  // escaped characters inside strings
+        u64 em = sm & ~in.st;
+        u32 flags = e != 0 ? CHUNK_SLOW : 0u;
+        if ((((in.slow_w >> lane) & 1u) != 0 && e != 0) || prev_slow) {
+            u64 um;
+            bool escapes, overflow;
+            if (!str_chunk_masks(p.sv, c, &em, &um, &escapes, &overflow)) atomicOr(&p.st->err, 1u);
+            if (overflow) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+            flags = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+        }
+        const u32 n = (u32)popc64(em);
+        u32 incl = n;
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const u32 o = __shfl_up(incl, s, 64);
-        if (lane >= s) incl += o;
+        for (int s = 1; s < 64; s <<= 1) {
+            const u32 o = __shfl_up(incl, s, 64);
+            if (lane >= s) incl += o;
+        }
+        p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
+        if (lane == 63) p.unit_cnt[unit] = incl;
+        if (!more) break;
+        unit = next;
+        in = in_n;
     }
-    p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
-    if (lane == 63) p.unit_cnt[c >> 6] = incl;
 }
 
 // ---- wave scans of full-width aggregates (DPP) ------------------------------------------------------------------
@@ -343,6 +380,9 @@ __constant__ EscapeLut c_esc = make_escape_lut();
 // appends them; the up to four stale bytes such a store leaves behind the lane's data are repaired after a wave
 // barrier, when every lane rewrites the first four bytes of its own region (kept in a register).  Chunks with escapes (flagged by
 // k_str_masks) first patch the translated bytes into their LDS copy of the chunk (sj_strings.h).
+// Waves are persistent and software-pipelined: a wave walks over units wave_id, wave_id + waves, ...; while it compacts
+// unit i its loads of the 64-byte chunks of unit i+1 and of the records of unit i+2 are in flight (one unit per block
+// left two dependent memory round trips -- record, then chunk -- exposed in front of every 4 KiB).
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
@@ -352,84 +392,125 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     __shared__ u8 s_esc[256];
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
     s_esc[threadIdx.x] = c_esc.v[threadIdx.x];
-    __syncthreads();
-    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (c >= p.units * 64) return;
-    const u64 unit = c >> 6;
-    const ChunkRec rec = p.rec[c];
-    const u64 em = rec.em;
-    const u32 pre_raw = rec.pre;
-    const u32 pre = pre_raw & CHUNK_PRE_MASK;
-    const bool patched = (pre_raw & CHUNK_SLOW) != 0, general = (pre_raw & CHUNK_GENERAL) != 0;
-    const u32 n = (u32)popc64(em);
-    const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
-    const u64 g = (u64)p.unit_cnt[unit];  // exclusive prefix: Strings.B offset of the unit
-    // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
-    // two record loads instead of two records + two unit prefixes
-    p.rec[c].abs = (u32)g + pre;
-    if (total == 0) return;  // wave-uniform
-    u8 *out = &s_io[wave][pre];
-    u32 head = 0;
+    const u64 nwaves = (u64)gridDim.x * 4;
+    u64 unit = (u64)blockIdx.x * 4 + wave;
+    struct Rec {
+        ChunkRec r;
+        u32 g;  // Strings.B offset of the unit
+    };
+    auto load_rec = [&](u64 u) {
+        Rec x;
+        x.r = ChunkRec{0, 0, 0};
+        x.g = 0;
+        if (u < p.units) {
+            x.r = p.rec[u * 64 + lane];
+            x.g = p.unit_cnt[u];
+        }
+        return x;
+    };
+    auto load_chunk = [&](u64 u, u64 em, u32 (&w)[16]) {
+        if (u < p.units && em != 0 && !SJ_EXPBIT(p, 5)) {  // the chunk holds message bytes: its 64-byte line is readable
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + (u * 64 + lane) * 64);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = src[q];
+                w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+        }
+    };
+    Rec cur = load_rec(unit), nxt = load_rec(unit + nwaves);
+    __syncthreads();
+    if (unit >= p.units) return;
     u8 *in8 = &s_io[wave][0];
     u32 *in32 = reinterpret_cast<u32 *>(in8);
     auto byte_ix = [&](u32 q) { return ((q >> 2) * 64 + lane) * 4 + (q & 3); };
-    u32 w[16];
-    if (em != 0) {  // the chunk holds message bytes: its 64-byte line is readable
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + c * 64);
+    u32 w[16], w_n[16];
+    load_chunk(unit, cur.r.em, w);
+    for (;;) {
+        const u64 c = unit * 64 + lane;
+        const u64 next = unit + nwaves;
+        const bool more = next < p.units;  // wave-uniform
+        const Rec nn = load_rec(next + nwaves);   // two units ahead
+        load_chunk(next, nxt.r.em, w_n);          // one unit ahead (its record was requested an iteration ago)
+        const u64 em = cur.r.em;
+        const u32 pre_raw = cur.r.pre;
+        const u32 pre = pre_raw & CHUNK_PRE_MASK;
+        const bool patched = (pre_raw & CHUNK_SLOW) != 0, general = (pre_raw & CHUNK_GENERAL) != 0;
+        const u32 n = (u32)popc64(em);
+        const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
+        const u64 g = (u64)cur.g;  // exclusive prefix: Strings.B offset of the unit
+        // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
+        // two record loads instead of two records + two unit prefixes
+        if (!SJ_EXPBIT(p, 4)) p.rec[c].abs = (u32)g + pre;
+        if (total != 0) {  // wave-uniform
+            if (em != 0 && patched) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint4 v = src[q];
-            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-        }
-        if (patched) {
+                for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
+                if (general) {
+                    str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
+                } else {  // simple escapes only: translated in place, nothing is read from the message
+                    const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+                    for (u64 r = ((stc << 1) | stp) & em; r != 0; r &= r - 1) {
+                        const u32 ix = byte_ix((u32)ctz64(r));
+                        in8[ix] = s_esc[in8[ix]];
+                    }
+                }
 #pragma unroll
-            for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
-            if (general) {
-                str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
-            } else {  // simple escapes only: translated in place, nothing is read from the message
-                const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-                for (u64 r = ((stc << 1) | stp) & em; r != 0; r &= r - 1) {
-                    const u32 ix = byte_ix((u32)ctz64(r));
-                    in8[ix] = s_esc[in8[ix]];
+                for (int q = 0; q < 16; q++) w[q] = in32[q * 64 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // every lane has its chunk in registers: the window turns into the output
+            // The window is cleared and the lanes OR their bytes in at their byte offsets with ALIGNED 8-byte LDS atomics:
+            // eight message bytes at a time are squeezed together (two v_perm_b32), shifted to where they belong inside an
+            // aligned 8-byte slot and its successor, and ds_or_b64 merges them with what the neighbour lanes put there.
+            // (Unaligned ds_write_b32 did the placement before: the LDS executes those a lane at a time -- 19 LDS cycles
+            // per instruction on average, the LDS 92 % busy, 42 % of the wave-cycles stalled on LDS issue.)
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(&s_io[wave][0]) + lane * 4;
+                const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+                z[0] = zero; z[1] = zero; z[2] = zero; z[3] = zero;
+                if (lane == 0) reinterpret_cast<uint4 *>(&s_io[wave][4096])[0] = zero;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (em != 0) {
+                u32 o = pre;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const u32 nib0 = (u32)(em >> (8 * q)) & 15u, nib1 = (u32)(em >> (8 * q + 4)) & 15u;
+                    const u32 cd0 = __builtin_amdgcn_perm(0u, w[2 * q], s_sel[nib0]);
+                    const u32 cd1 = __builtin_amdgcn_perm(0u, w[2 * q + 1], s_sel[nib1]);
+                    const u32 n0 = (u32)__builtin_popcount(nib0), n1 = (u32)__builtin_popcount(nib1);
+                    const u64 piece = (u64)cd0 | ((u64)cd1 << (8u * n0));
+                    const u32 sh = 8u * (o & 7u);
+                    const u64 lo = piece << sh, hi = sh ? piece >> (64u - sh) : 0ull;
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(&s_io[wave][o & ~7u]);
+                    if (lo != 0) atomicOr(slot, (unsigned long long)lo);      // (a zero changes nothing)
+                    if (hi != 0) atomicOr(slot + 1, (unsigned long long)hi);
+                    o += n0 + n1;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 16; q++) w[q] = in32[q * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (g + total <= p.strings_cap && !SJ_EXPBIT(p, 6)) {
+                u8 *dst = p.strings + g;
+                const u32 q16 = total >> 4;
+                for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
+                    *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
+                const u32 tail = q16 * 16 + lane;
+                if (tail < total) dst[tail] = s_io[wave][tail];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the window is read out: the next unit may write it
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();  // every lane has its chunk in registers: the window turns into the output
-    if (em != 0) {
-        u32 o = 0;
+        if (!more) break;
+        unit = next;
+        cur = nxt;
+        nxt = nn;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const u32 nib = (u32)(em >> (4 * q)) & 15u;
-            const u32 cd = __builtin_amdgcn_perm(0u, w[q], s_sel[nib]);
-            *reinterpret_cast<u32 *>(out + o) = cd;
-            head |= (u32)((u64)cd << (8u * (o < 4u ? o : 4u)));  // the lane's first four bytes, kept for the repair
-            o += (u32)__builtin_popcount(nib);
-        }
+        for (int q = 0; q < 16; q++) w[q] = w_n[q];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // the first four bytes again: the lane in front may have left stale bytes there
-    if (n >= 4) {
-        *reinterpret_cast<u32 *>(out) = head;
-    } else {
-        if (n > 0) out[0] = (u8)head;
-        if (n > 1) out[1] = (u8)(head >> 8);
-        if (n > 2) out[2] = (u8)(head >> 16);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (g + total > p.strings_cap) return;
-    u8 *dst = p.strings + g;
-    const u32 q16 = total >> 4;
-    for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
-        *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
-    const u32 tail = q16 * 16 + lane;
-    if (tail < total) dst[tail] = s_io[wave][tail];
 }
 
 // ---- the token scan ----------------------------------------------------------------------------------------
@@ -492,22 +573,24 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
     __shared__ __attribute__((aligned(16))) u32 s_k[RD_BLOCK * 4 + 8];  // dword 4 + 4 * tid: the thread's kinds
     __shared__ PAgg s_w[RD_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 n = token_count(p);
+    if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     s_elut[tid] = c_elut.v[tid];
     s_elut[tid + 256] = c_elut.v[tid + 256];
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * RD_ITEMS;
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
-    if (base + RD_ITEMS <= p.n) {
+    if (base + RD_ITEMS <= n) {
         kv = *reinterpret_cast<const uint4 *>(p.kind + base);
-    } else if (base < p.n) {
+    } else if (base < n) {
         u32 d[4] = {NL4, NL4, NL4, NL4};
-        for (u32 j = 0; base + j < p.n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[base + j] << (8 * (j & 3)));
+        for (u32 j = 0; base + j < n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[base + j] << (8 * (j & 3)));
         kv = make_uint4(d[0], d[1], d[2], d[3]);
     }
     *reinterpret_cast<uint4 *>(&s_k[4 + 4 * tid]) = kv;
     if (tid == 0)  // the two tokens in front of the tile (K_NONE in front of the message)
         s_k[3] = t0 == 0 ? 0x01010101u * K_NONE : ((u32)p.kind[t0 - 2] << 16) | ((u32)p.kind[t0 - 1] << 24);
-    if (tid == 1) s_k[4 + 4 * RD_BLOCK] = (u64)t0 + S2_TILE < p.n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL;
+    if (tid == 1) s_k[4 + 4 * RD_BLOCK] = (u64)t0 + S2_TILE < n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL;
     // selective copy (WithCopyStrings(false)): a string goes to Strings.B only if unescaping changes it, so every
     // string is measured here (parseStringSimdValidateOnly); with copy_strings the emit masks give the lengths
     u32 copied[RD_ITEMS];
@@ -518,7 +601,7 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
         const MsgView mv{p.msg, p.len};
 #pragma unroll
         for (int k = 0; k < RD_ITEMS; k++) {
-            if (base + k >= p.n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
+            if (base + k >= n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
             u32 sl, dl, out;
             if (!string_walk(mv, p.pos[base + k], nullptr, &sl, &dl)) {
                 out = DLEN_INVALID;
@@ -539,7 +622,7 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
     for (int k = 0; k < RD_ITEMS; k++) {
         const int off = 2 + k;  // byte offset of ppk in the stream
         const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-        const PAgg e = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
+        const PAgg e = base + k < n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
         acc = pagg_comb<true>(acc, e);
     }
     const PAgg incl = pagg_wave_inclusive<true>(acc);
@@ -574,8 +657,9 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
     __shared__ unsigned long long s_w64[16], s_s64[16];
     __shared__ SegSum s_before;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 n = token_count(p), tiles = (u32)(((u64)n + S2_TILE - 1) / S2_TILE);
     u64 lo64, hi64;
-    seg_range(p.tiles, 64, seg, lo64, hi64);
+    seg_range(tiles, 64, seg, lo64, hi64);
     const u32 lo = (u32)lo64, hi = (u32)hi64;
     // pass 1: the segment's aggregate (32-bit fields wrap; the two sizes are also summed in 64 bits)
     Agg seg_acc = agg_identity();  // meaningful in every thread after the loop
@@ -623,11 +707,11 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
                 p.st->records = tot.nb;
                 p.st->n_br = tot.bc;
                 // the gap behind the last bracket (empty if the last token is a bracket, as in every accepted document)
-                p.st->tail_mask = is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am);
+                p.st->tail_mask = n == 0 || is_bracket(p.kind[n - 1]) ? AM_ALL : am_value(tot.am);
                 if (words64 + 2ull > 0xfffffff0ull || bytes64 > 0xfffffff0ull) atomicOr(&p.st->err, 4u);
                 if (tot.d != 0) atomicOr(&p.st->err, 1u);  // scopes still open at the end (succeed: :433-435)
                 // tokens behind the last bracket lie at depth 0: the root context must allow them
-                if (!context_allowed(is_bracket(p.kind[p.n - 1]) ? AM_ALL : am_value(tot.am), CTX_ROOT)) atomicOr(&p.st->err, 1u);
+                if (!context_allowed(p.st->tail_mask, CTX_ROOT)) atomicOr(&p.st->err, 1u);
             }
         }
     }
@@ -693,6 +777,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     __shared__ uint2 s_num[S2_TILE];  // (message offset, tape offset) of the tile's numbers
     __shared__ u32 s_cnt, s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 n = token_count(p);
+    if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
@@ -703,7 +789,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     u32 pp[S2_ITEMS];
     u32 kv[2] = {NL4, NL4};
-    if (base + S2_ITEMS <= p.n) {
+    if (base + S2_ITEMS <= n) {
         const uint4 a = *reinterpret_cast<const uint4 *>(p.pos + base), b = *reinterpret_cast<const uint4 *>(p.pos + base + 4);
         pp[0] = a.x; pp[1] = a.y; pp[2] = a.z; pp[3] = a.w;
         pp[4] = b.x; pp[5] = b.y; pp[6] = b.z; pp[7] = b.w;
@@ -714,7 +800,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
 #pragma unroll
         for (int k = 0; k < S2_ITEMS; k++) {
             pp[k] = endpos;
-            if (base + k < p.n) {
+            if (base + k < n) {
                 pp[k] = p.pos[base + k];
                 kv[k >> 2] = (kv[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((u32)p.kind[base + k] << (8 * (k & 3)));
             }
@@ -725,7 +811,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     *reinterpret_cast<uint2 *>(&s_kind[4 + tid * S2_ITEMS]) = make_uint2(kv[0], kv[1]);  // 4-byte aligned
     if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_NONE;
     if (tid == 2) {
-        const bool more = (u64)t0 + S2_TILE < p.n;
+        const bool more = (u64)t0 + S2_TILE < n;
         s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_NL;
         s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
     }
@@ -756,7 +842,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
         for (int k = 0; k < S2_ITEMS; k++) {
             const int off = 2 + k;  // byte offset of ppk in the stream
             const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-            e[k] = base + k < p.n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
+            e[k] = base + k < n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
         }
     }
     PAgg mine = e[0];
@@ -787,8 +873,8 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             cp0[j] = cp1[j] = 0;
             em0[j] = em1[j] = 0;
             nxt[j] = k + 1 < S2_ITEMS ? pp[k + 1] : s_pos[tid * S2_ITEMS + S2_ITEMS];
-            if (is_atom[k]) aw[j] = load8_guarded(mv, pp[k]);
-            if (MASKS && is_str[k]) {
+            if (is_atom[k] && !SJ_EXPBIT(p, 1)) aw[j] = load8_guarded(mv, pp[k]);
+            if (MASKS && is_str[k] && !SJ_EXPBIT(p, 0)) {
                 const u64 a0 = (u64)pp[k] + p.sv.lead + 1, a1 = (u64)nxt[j] + p.sv.lead;
                 const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
                 cp0[j] = r0.abs;  // absolute Strings.B offset of the chunk (k_str_emit)
@@ -820,13 +906,14 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
                 w1 = dl[k] & ~DLEN_COPY;
             }
             if (is_atom[k]) bad |= !atom_valid_word(aw[j], p.len - pp[k], kd[k]);  // skipped by waves without atoms
-            if (two) {  // both words of a string with one 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
+            if (SJ_EXPBIT(p, 2)) {
+            } else if (two) {  // both words of a string with one 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
                 *reinterpret_cast<uint4 *>(p.tape + o) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
                 if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
             } else if (is_atom[k]) {
                 p.tape[o] = w0;
             }
-            if ((u32)(kd[k] - K_OPEN_OBJ) < 4u) {
+            if ((u32)(kd[k] - K_OPEN_OBJ) < 4u && !SJ_EXPBIT(p, 3)) {
                 const u32 lbc = lp.x >> 14;
                 const u32 c = tp.bc + lbc;  // brackets in front of this one
                 const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
@@ -834,7 +921,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
                 p.br_off[c] = o;
                 p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
             }
-            if (kd[k] == K_NUM) s_num[slot++] = make_uint2(pp[k], o);
+            if (kd[k] == K_NUM && !SJ_EXPBIT(p, 9)) s_num[slot++] = make_uint2(pp[k], o);
             if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
             lp = pagg_comb<!MASKS>(lp, e[k]);
         }
@@ -1082,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
 // ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
 __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+    if (i >= token_count(p)) return;
     if (p.kind[i] != K_STRING) return;
     const u32 dl = p.dlen[i];
     if (dl == DLEN_INVALID || !(dl & DLEN_COPY)) return;
@@ -1112,6 +1199,18 @@ __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
 
 // ---- launcher -----------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// grid of the kernels whose waves walk over their work items: as many 256-thread blocks as the device holds at once
+// (8 per CU), fewer if there is less work
+template <typename K>
+static u32 persistent_blocks(K kernel, u64 want) {
+    int dev = 0, cus = 256, per_cu = 4;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    const u64 cap = (u64)cus * (u64)per_cu;
+    return (u32)(want < 1 ? 1 : (want < cap ? want : cap));
+}
 
 // the zeroed region: S2State and the segment slots of the two scans (zeroed by stage 1's preparation kernel)
 size_t stage2_zero_bytes() { return (sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot) + 255) / 256 * 256; }
@@ -1147,6 +1246,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.len = a.len;
     p.pos = a.d_pos;
     p.n = (u32)n;
+    p.n_dev = a.n_dev;
     p.ndjson = a.flags & 1u;
     p.copy_strings = (a.flags >> 1) & 1u;
     p.kind = a.d_kind;
@@ -1190,6 +1290,10 @@ static S2Dev stage2_view(const S2Args &a) {
     p.rec = nullptr;
     p.unit_cnt = nullptr;
     p.units = 0;
+    p.exp = 0;
+#if defined(SJ_EXP)
+    if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
+#endif
     if (a.str_aux && p.copy_strings) {
         const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
         p.sv.qm = x.qm;
@@ -1218,7 +1322,7 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
 hipError_t stage2_launch_measure(const S2Args &a) {
     const S2Dev p = stage2_view(a);
     if (a.n == 0) return hipSuccess;
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_masks, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, a.stream, p);
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_masks, dim3(persistent_blocks(k_str_masks, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p);
     hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * SCAN_SEGS : SCAN_SEGS), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
@@ -1233,7 +1337,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
     // the string bytes first: k_str_emit also leaves every chunk's absolute Strings.B offset for k_s2_emit
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3((u32)((p.units * 64 + 255) / 256)), dim3(256), 0, a.stream, p);
+    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
     else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
     {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count)

@@ -48,6 +48,9 @@ SYMBOLS = {
     "sjhip_filter_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p, szp, szp]),
     "sjhip_fetch_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sjhip_serialize": (C.c_int, [C.c_void_p, szp, szp, szp, szp]),
+    "sjhip_serialize_ex": (C.c_int, [C.c_void_p, C.c_uint32, szp, szp, szp, szp]),
+    "sjhip_deserialize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, szp, szp, szp]),
+    "sjhip_fetch_message": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sjhip_fetch_serialized": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, szp]),
     "sjhip_marshal_json": (C.c_int, [C.c_void_p, szp]),
     "sjhip_fetch_marshaled": (C.c_int, [C.c_void_p, C.c_void_p]),

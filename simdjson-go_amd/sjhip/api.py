@@ -149,18 +149,32 @@ class Context:
         self._check(L.sjhip_fetch_filtered(self._h, tape.ctypes.data, strings.ctypes.data))
         return n.value, ParsedJson(b"", tape, strings)
 
-    def serialize(self, fetch=True):
+    def serialize(self, fetch=True, dedup=False):
         """Serializer.Serialize (format v3, CompressNone) of the device-resident result of the last parse.
-        -> the framed stream as a uint8 array (what the reference's Deserialize reads), or its sizes with fetch=False."""
+        -> the framed stream as a uint8 array (what the reference's Deserialize reads), or its sizes with fetch=False.
+        dedup: de-duplicate the strings like the reference's indexString (the plain form is byte-identical to the
+        oracle's stream without de-duplication)."""
         L = _lib.lib()
         tl, vl, sl, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-        self._check(L.sjhip_serialize(self._h, C.byref(tl), C.byref(vl), C.byref(sl), C.byref(n)))
+        self._check(L.sjhip_serialize_ex(self._h, 1 if dedup else 0, C.byref(tl), C.byref(vl), C.byref(sl), C.byref(n)))
         if not fetch:
             return {"tags": tl.value, "values": vl.value, "strings": sl.value, "stream": n.value}
         out = np.empty(n.value, dtype=np.uint8)
         got = C.c_size_t(0)
         self._check(L.sjhip_fetch_serialized(self._h, out.ctypes.data, out.size, C.byref(got)))
         return out[: got.value]
+
+    def deserialize(self, stream):
+        """Serializer.Deserialize of a stream with uncompressed blocks, on the device -> ParsedJson (strings point into
+        Message = the string column, like the reference's result)."""
+        L = _lib.lib()
+        a = np.frombuffer(stream, dtype=np.uint8) if not isinstance(stream, np.ndarray) else stream
+        tl, sl, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(L.sjhip_deserialize(self._h, a.ctypes.data, a.size, C.byref(tl), C.byref(sl), C.byref(ml)))
+        tape, strings = self.fetch(tl.value, sl.value)
+        msg = np.empty(ml.value, dtype=np.uint8)
+        self._check(L.sjhip_fetch_message(self._h, msg.ctypes.data))
+        return ParsedJson(msg.tobytes(), tape, strings)
 
     def marshal_json(self, fetch=True):
         """pj.Iter().MarshalJSON() of the device-resident result of the last parse: compact JSON text, records

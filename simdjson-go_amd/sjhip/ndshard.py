@@ -92,12 +92,18 @@ def parse_shard(data: bytes, rank: int, world: int, trim: Callable, begin: Calla
     start, end = record_cuts(data, world)[rank]
     shard = data[start:end]
     off, ln = trim(shard)
-    empty = ln == 0
     window = shard[off:off + ln]
+    return run_shard(rank, world, ln == 0, lambda: begin(window), finish, all_gather, start + off - g_off)
+
+
+def run_shard(rank: int, world: int, empty: bool, begin: Callable, finish: Callable, all_gather: Callable, msg_base: int):
+    """The control flow of one rank once its shard is known (parse_shard above; bench.py calls it with the shard
+    already resident on the device): phase 1, exchange of (tape_len, strings_len, return code), bases, phase 2,
+    exchange of the return codes.  begin() -> (tape_len, strings_len); finish(tape_base, strings_base, msg_base)."""
     sizes, rc = (0, 0), 0
     if not empty:
         try:
-            sizes = begin(window)
+            sizes = begin()
         except Exception as e:  # noqa: BLE001 -- the code is exchanged, the error re-raised on all ranks
             rc = _code_of(e)
     gathered = [tuple(g) for g in all_gather((int(sizes[0]), int(sizes[1]), int(rc)))]
@@ -105,7 +111,6 @@ def parse_shard(data: bytes, rank: int, world: int, trim: Callable, begin: Calla
     tape_base, strings_base = bases_from_sizes([g[:2] for g in gathered])[rank]
     tape, strings, rc2 = np.empty(0, np.uint64), np.empty(0, np.uint8), 0
     if not empty:
-        msg_base = start + off - g_off
         try:
             tape, strings = finish(tape_base, strings_base, msg_base)
         except Exception as e:  # noqa: BLE001

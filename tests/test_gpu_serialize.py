@@ -75,3 +75,82 @@ def test_full_size(ctx):
     import workloads
     for doc, nd in ((workloads.c2_twitter_array(426), False), (workloads.c5_parking_nd(1000), True)):
         check_serialize(ctx, doc, nd, "full-size")
+
+
+# ---- de-duplicated string column and Deserialize on the device ------------------------------------------------------------
+def check_round_trip(ctx, data, nd, what, expect_smaller=False):
+    """The property the reference's tests pin (parsed_serialize_test.go:220-340): Deserialize(Serialize(pj)) marshals to the
+    same JSON.  Here: device Serialize with and without de-duplication -> oracle Deserialize and device Deserialize ->
+    the oracle's MarshalJSON of the result equals the oracle's MarshalJSON of the parse."""
+    ref = O.parse(data, ndjson=nd, copy_strings=True)
+    assert ref.rc == 0, what
+    msg = bytes(data[ref.msg_off:ref.msg_off + ref.msg_len])
+    rc, want = O.marshal_json(ref.tape, ref.strings, msg)
+    assert rc == 0, what
+    streams, cols = {}, {}
+    for dedup in (False, True):
+        ctx.parse(data, ndjson=nd, copy_strings=True)
+        cols[dedup] = ctx.serialize(fetch=False, dedup=dedup)["strings"]
+        streams[dedup] = ctx.serialize(dedup=dedup)
+    if expect_smaller:  # the string column holds every distinct string about once
+        assert cols[True] < cols[False] * 0.2, (what, cols)
+    assert cols[True] <= cols[False] and len(streams[True]) <= len(streams[False]), what
+    for dedup, stream in streams.items():
+        rc, tape2, strs2, msg2 = O.deserialize(stream)          # the oracle reads the device's stream
+        assert rc == 0, (what, dedup)
+        rc, got = O.marshal_json(tape2, strs2, bytes(msg2))
+        assert rc == 0 and got == want, (what, dedup, "oracle Deserialize")
+        pj = ctx.deserialize(stream)                            # the device reads it
+        assert len(pj.Tape) == len(ref.tape), (what, dedup)
+        assert np.array_equal(pj.Tape, tape2), (what, dedup, "device tape differs from the oracle's Deserialize")
+        assert pj.Message == bytes(msg2) and len(pj.Strings) == len(strs2), (what, dedup)
+        rc, got = O.marshal_json(pj.Tape, pj.Strings, pj.Message)
+        assert rc == 0 and got == want, (what, dedup, "device Deserialize")
+
+
+@pytest.mark.parametrize("name", fixtures.ALL)
+def test_round_trip_fixtures(ctx, name):
+    check_round_trip(ctx, fixtures.load(name), name == "parking-citations", name)
+
+
+def test_round_trip_dedup_shrinks_repeated_records(ctx):
+    park = fixtures.load("parking-citations")
+    check_round_trip(ctx, park * 40, True, "parking x40", expect_smaller=True)
+    doc = ("[" + ",".join('{"key":"value","tag":"%s","n":%d,"empty":""}' % ("abc" * (i % 5), i) for i in range(20000)) + "]").encode()
+    check_round_trip(ctx, doc, False, "repeated keys", expect_smaller=True)
+
+
+def test_round_trip_tables_and_lookalikes(ctx):
+    corp = GU.load("corpus")
+    for c in corp["pass_cases"]:
+        check_round_trip(ctx, bytes.fromhex(c["js_hex"]), False, c["name"])
+    from test_gpu_parse import _random_records
+    rnd, lines = _random_records(77, 1 << 20)
+    check_round_trip(ctx, "\n".join(lines).encode("utf-8"), True, "random-nd")
+
+
+def test_deserialize_rejects_corrupt_streams(ctx):
+    import sjhip
+    ctx.parse(fixtures.load("twitter"))
+    sizes = ctx.serialize(fetch=False, dedup=True)
+    stream = ctx.serialize(dedup=True)
+
+    def varint_len(v):
+        n = 1
+        while v >= 0x80:
+            v >>= 7
+            n += 1
+        return n
+    vl, tl = sizes["values"], sizes["tags"]
+    tags_at = len(stream) - vl - (varint_len(vl) + varint_len(vl + 1) + 1) - tl  # first byte of the tag column
+    assert stream[tags_at] == ord("r")
+    bad_tag = stream.copy()
+    bad_tag[tags_at + 5] = ord("N")                      # a TagNop entry
+    swapped = stream.copy()
+    swapped[tags_at + 1] = ord("t")                      # the root object became an atom: the columns no longer add up
+    version = stream.copy()
+    version[0] = 9
+    for bad in (stream[:len(stream) // 2], stream[:3], bad_tag, swapped, version):
+        with pytest.raises(sjhip.ParseError):
+            ctx.deserialize(np.ascontiguousarray(bad))
+    ctx.deserialize(stream)  # the context is still usable
