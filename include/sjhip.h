@@ -179,6 +179,7 @@ typedef struct sjhip_stream_result {
     const uint8_t *message; /* TrimSpace'd block (inside the pinned input block) */
     size_t message_len;
     int device;
+    uint64_t records;       /* filtered streams (sjhip_stream_set_filter): matching records of the block, else 0 */
 } sjhip_stream_result;
 sjhip_stream *sjhip_stream_create(int first_device, int n_devices, size_t block_bytes, int slots, uint32_t flags);
 void sjhip_stream_destroy(sjhip_stream *s);
@@ -193,6 +194,11 @@ int sjhip_stream_cancel(sjhip_stream *s); /* hand the acquired block back unused
 int sjhip_stream_submit_copy(sjhip_stream *s, const uint8_t *block, size_t len);
 int sjhip_stream_next(sjhip_stream *s, sjhip_stream_result *out);
 int sjhip_stream_ready(sjhip_stream *s);
+/* Compose the stream with sjhip_filter_where: every block is parsed and filtered on the device and only the matching
+ * records' (Tape, Strings.B) -- identical to ParseND of the block's matching lines -- cross PCIe; result.records counts
+ * them (a block without matches delivers the empty result: tape_len 0).  Set before the first block is submitted;
+ * klen = 0 turns the filter off. */
+int sjhip_stream_set_filter(sjhip_stream *s, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen);
 int sjhip_stream_release(sjhip_stream *s);
 
 /* ---- stage 1 only: replaces findStructuralIndices (stage1_find_marks_amd64.go:41-148) --------

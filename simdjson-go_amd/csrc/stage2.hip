@@ -774,8 +774,10 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
     __shared__ PAgg s_w[S2_WAVES];
-    __shared__ uint2 s_num[S2_TILE];  // (message offset, tape offset) of the tile's numbers
-    __shared__ u32 s_cnt, s_base;
+    // the tile's strings (from the front) and its atoms and numbers (from the back) in one array -- a tile has 4096
+    // tokens, so the two never meet: token index | tape offset inside the tile << 12 | kind << 26
+    __shared__ u32 s_q[S2_TILE];
+    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
     s_elut[tid] = c_elut.v[tid];
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) s_cnt = s_scnt = s_dcnt = s_fill = 0;
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
@@ -851,89 +853,87 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
     PAgg total;
     PAgg lp = pagg_block_exclusive<!MASKS, S2_WAVES>(mine, s_w, lane, wave, total);  // prefix inside the tile
     bool bad = false;
-    u32 nnum = 0;  // numbers of this thread
+    // Queues.  A thread's eight tokens are of any kind, so a loop over them runs the code of EVERY kind eight times with
+    // most lanes masked off, and the kernel is bound by VALU issue (70 % busy; a wave64 instruction holds a SIMD for
+    // four cycles).  Only what is cheap per token stays in that loop; strings (every string copied: two record gathers,
+    // two 64-bit popcounts), atoms and numbers are entered into queues in LDS (token index | tape offset inside the tile
+    // << 12) and worked on afterwards with the lanes packed densely: a kind costs ceil(count / 512) passes instead of 8.
+    u32 nnum = 0, nstr = 0, natom = 0;
 #pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) nnum += kd[k] == K_NUM ? 1u : 0u;
-    u32 slot = 0;
-    if (nnum) slot = atomicAdd(&s_cnt, nnum);
-    // ---- two batches of four tokens: everything a batch needs from memory (the 8 bytes of an atom, the emit-mask
-    // words of a string) is requested before its first use
+    for (int k = 0; k < S2_ITEMS; k++) {
+        nnum += kd[k] == K_NUM ? 1u : 0u;
+        nstr += (MASKS && is_str[k]) ? 1u : 0u;
+        natom += is_atom[k] ? 1u : 0u;
+    }
+    u32 sslot = 0, dslot = 0;
+    if (nnum) atomicAdd(&s_cnt, nnum);
+    if (nstr) sslot = atomicAdd(&s_scnt, nstr);
+    if (natom + nnum) dslot = atomicAdd(&s_dcnt, natom + nnum);
+    const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
 #pragma unroll
-    for (int h = 0; h < S2_ITEMS; h += 4) {
-        u64 aw[4];           // atoms: the 8 message bytes at the token
-        u32 cp0[4];          // strings (masks): the two words of E(a0) and of E(a1)
-        u64 em0[4];
-        u32 cp1[4];
-        u64 em1[4];
-        u32 nxt[4];          // position of the next token
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = h + j;
-            aw[j] = 0;
-            cp0[j] = cp1[j] = 0;
-            em0[j] = em1[j] = 0;
-            nxt[j] = k + 1 < S2_ITEMS ? pp[k + 1] : s_pos[tid * S2_ITEMS + S2_ITEMS];
-            if (is_atom[k] && !SJ_EXPBIT(p, 1)) aw[j] = load8_guarded(mv, pp[k]);
-            if (MASKS && is_str[k] && !SJ_EXPBIT(p, 0)) {
-                const u64 a0 = (u64)pp[k] + p.sv.lead + 1, a1 = (u64)nxt[j] + p.sv.lead;
-                const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
-                cp0[j] = r0.abs;  // absolute Strings.B offset of the chunk (k_str_emit)
-                em0[j] = r0.em;
-                cp1[j] = r1.abs;
-                em1[j] = r1.em;
+    for (int k = 0; k < S2_ITEMS; k++) {
+        const u32 lo = lp.x & 0x3fffu;  // tape words of the tile in front of this token
+        const u32 o = T0 + lo;
+        const u32 qe = (u32)(tid * S2_ITEMS + k) | (lo << 12);
+        bad |= am_value(e[k].z) == 0;  // legal in no context at all
+        if (MASKS) {
+            if (is_str[k]) s_q[sslot++] = qe;
+        } else if (is_str[k]) {  // selective copy: the lengths were measured by k_s2_reduce, the scan carries the offsets
+            const bool cp = (dl[k] & DLEN_COPY) != 0;
+            if (dl[k] != DLEN_INVALID) {
+                const u64 w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1), w1 = dl[k] & ~DLEN_COPY;
+                *reinterpret_cast<uint4 *>(p.tape + o) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                p.str_off[base + k] = tp.s + lp.s;
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = h + j;
-            const u32 o = tp.w + (lp.x & 0x3fffu) + 1u;  // word 0 is the opening root (write_tape(0,'r'), :172)
-            bad |= am_value(e[k].z) == 0;                // legal in no context at all
-            // strings and atoms: first word under one predicate, computed without control flow
-            u64 w0 = atom_word(kd[k]), w1 = 0;
-            bool two = false;
-            if (MASKS) {
-                const u32 b0 = (u32)(((u64)pp[k] + p.sv.lead + 1) & 63u);
-                const u32 b1 = (u32)(((u64)nxt[j] + p.sv.lead) & 63u);
-                const u64 so = (u64)cp0[j] + (u64)popc64(em0[j] & ~(~0ull << b0));
-                const u64 se = (u64)cp1[j] + (u64)popc64(em1[j] & ~(~0ull << b1));
-                if (is_str[k]) w0 = string_word(true, p.strings_base + so, 0);
-                w1 = se - so;
-                two = is_str[k];
+        if (is_atom[k] || (kd[k] == K_NUM && !SJ_EXPBIT(p, 9))) s_q[S2_TILE - 1 - dslot++] = qe | ((u32)kd[k] << 26);
+        if ((u32)(kd[k] - K_OPEN_OBJ) < 4u && !SJ_EXPBIT(p, 3)) {
+            const u32 lbc = lp.x >> 14;
+            const u32 c = tp.bc + lbc;  // brackets in front of this one
+            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
+            p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
+            p.br_off[c] = o;
+            p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
+        }
+        if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
+        lp = pagg_comb<!MASKS>(lp, e[k]);
+    }
+    __syncthreads();  // the queues are complete
+    // ---- strings: Strings.B offset and unescaped length from the emit masks (sj_strings.h), both tape words in one
+    // 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
+    if (MASKS && !SJ_EXPBIT(p, 0)) {
+        const u32 ns = s_scnt;
+        for (u32 j = (u32)tid; j < ns; j += S2_BLOCK) {
+            const u32 v = s_q[j], idx = v & 0xfffu;
+            const u64 a0 = (u64)s_pos[idx] + p.sv.lead + 1, a1 = (u64)s_pos[idx + 1] + p.sv.lead;
+            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
+            const u32 b0 = (u32)a0 & 63u, b1 = (u32)a1 & 63u;
+            const u64 so = (u64)r0.abs + (u64)popc64(r0.em & ~(~0ull << b0));  // absolute Strings.B offset of the chunk (k_str_emit) + inside
+            const u64 se = (u64)r1.abs + (u64)popc64(r1.em & ~(~0ull << b1));
+            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
+            if (!SJ_EXPBIT(p, 2))
+                *reinterpret_cast<uint4 *>(p.tape + T0 + (v >> 12)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+        }
+    }
+    // ---- atoms: validated from the 8 message bytes at the token; numbers move to the global queue (k_numbers parses
+    // them with the lanes packed densely; the order of the queue does not matter)
+    {
+        const u32 nd = s_dcnt, cnt = s_cnt;
+        if (cnt != 0 && tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
+        if (cnt != 0) __syncthreads();  // (block-uniform)
+        const u32 qb = s_base;
+        for (u32 j = (u32)tid; j < nd; j += S2_BLOCK) {
+            const u32 v = s_q[S2_TILE - 1 - j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x3fffu);
+            const u8 ak = (u8)(v >> 26);
+            if (ak == K_NUM) {
+                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(at, o);
             } else {
-                const bool cp = (dl[k] & DLEN_COPY) != 0;
-                two = is_str[k] & (dl[k] != DLEN_INVALID);
-                if (is_str[k]) w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1);
-                w1 = dl[k] & ~DLEN_COPY;
+                bad |= !atom_valid_word(SJ_EXPBIT(p, 1) ? 0ull : load8_guarded(mv, at), p.len - at, ak);
+                if (!SJ_EXPBIT(p, 2)) p.tape[o] = atom_word(ak);
             }
-            if (is_atom[k]) bad |= !atom_valid_word(aw[j], p.len - pp[k], kd[k]);  // skipped by waves without atoms
-            if (SJ_EXPBIT(p, 2)) {
-            } else if (two) {  // both words of a string with one 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
-                *reinterpret_cast<uint4 *>(p.tape + o) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-                if (!MASKS) p.str_off[base + k] = tp.s + lp.s;
-            } else if (is_atom[k]) {
-                p.tape[o] = w0;
-            }
-            if ((u32)(kd[k] - K_OPEN_OBJ) < 4u && !SJ_EXPBIT(p, 3)) {
-                const u32 lbc = lp.x >> 14;
-                const u32 c = tp.bc + lbc;  // brackets in front of this one
-                const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
-                p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
-                p.br_off[c] = o;
-                p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
-            }
-            if (kd[k] == K_NUM && !SJ_EXPBIT(p, 9)) s_num[slot++] = make_uint2(pp[k], o);
-            if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
-            lp = pagg_comb<!MASKS>(lp, e[k]);
         }
     }
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
-    // the tile's numbers move to the global queue (coalesced; the order of the queue does not matter)
-    const u32 cnt = s_cnt;
-    if (cnt == 0) return;
-    if (tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
-    __syncthreads();
-    const u32 qb = s_base;
-    for (u32 j = (u32)tid; j < cnt; j += S2_BLOCK) p.numq[qb + j] = s_num[j];
 }
 
 // ---- numbers (parseNumber, parse_number.go:65-135): one queued number per lane ------------------------------------
@@ -1104,8 +1104,12 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
     for (u32 g = blockIdx.x * 4 + (threadIdx.x >> 6); (u64)g * 64 < n_br; g += waves) {  // wave-uniform
         const u32 c = g * 64 + (u32)lane;
         const bool valid = c < n_br;
+        // everything that does not depend on the answer is requested together: the group's depths, kinds and tape
+        // offsets, and the depths of the group in front (where most questions that leave the group end)
         const i32 dep = valid ? p.br_depth[c] : 0x7fffffff;
         const u8 info = valid ? p.br_info[c] : (u8)K_BAD;
+        const u32 oc = valid ? p.br_off[c] : 0u;
+        const i32 pd = g > 0 ? p.br_depth[(u64)(g - 1) * 64 + lane] : 0x7fffffff;
         const u8 kd = info & 15u;
         const bool close = is_close(kd);
         const i32 q = close ? dep : dep - 2;  // depth in front of the bracket - 1
@@ -1126,7 +1130,6 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
         // the group in front, then the tree: one question per distinct q that is still open
         u64 pm = __ballot(pend);
         if (pm != 0 && g > 0) {
-            const i32 pd = p.br_depth[(u64)(g - 1) * 64 + lane];
             while (pm != 0) {
                 const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pm));
                 const u64 at = __ballot(pd <= v);
@@ -1150,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
         const u8 jk = (u8)(p.br_info[j] & 15u);
         bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
         if (close && store) {  // payloads: annotate_previousloc (stage2_build_tape_amd64.go:335-336)
-            const u32 oc = p.br_off[c], oj = p.br_off[j];
+            const u32 oj = p.br_off[j];
             const u64 wc = ((u64)(kd == K_CLOSE_OBJ ? '}' : ']') << 56) | (p.tape_base + oj);
             const u64 wj = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
             if (dep == 0) {  // a record: the root word in front of its open bracket and the one behind its close bracket

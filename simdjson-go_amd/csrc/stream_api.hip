@@ -38,6 +38,7 @@ struct Slot {
     uint8_t *strings = nullptr;
     size_t strings_cap = 0;
     size_t tape_len = 0, strings_len = 0, msg_off = 0, msg_len = 0;
+    uint64_t records = 0;  // filtered streams: matching records of the block
     int rc = 0;
     char err[256] = {0};
     SlotState state = FREE;
@@ -57,6 +58,10 @@ struct sjhip_stream {
     int filling = -1;                            // slot handed out by acquire
     int delivered = -1;                          // slot handed out by next
     bool failed = false, quit = false;
+    // optional filter (sjhip_stream_set_filter): every block is parsed, filtered on the device, and only the matching
+    // records' (Tape, Strings.B) cross PCIe
+    bool filter = false;
+    std::vector<uint8_t> fkey, fval;
     uint64_t fail_seq = ~0ull;  // lowest sequence number of a block that failed: nothing behind it needs parsing
     char err[256] = {0};
 };
@@ -86,6 +91,10 @@ static void worker_main(sjhip_stream *s, int k) {
             // parseMessage on the block: TrimSpace + H2D from the pinned block + stage 1 + stage 2 (parse_api.hip)
             rc = sjhip_parse(sl.ctx, sl.in, sl.in_len, s->flags | SJHIP_FLAG_NDJSON, &sl.tape_len, &sl.strings_len, &sl.msg_off,
                              &sl.msg_len);
+            sl.records = 0;
+            if (rc == SJHIP_OK && s->filter)  // countWhere / filter on the device-resident tape (query.hip)
+                rc = sjhip_filter_where(sl.ctx, s->fkey.data(), s->fkey.size(), s->fval.data(), s->fval.size(), &sl.records,
+                                        &sl.tape_len, &sl.strings_len);
             if (rc == SJHIP_OK) {
                 size_t tc = sl.tape_cap * sizeof(uint64_t);
                 void *tp = sl.tape;
@@ -96,7 +105,8 @@ static void worker_main(sjhip_stream *s, int k) {
                 sl.tape_cap = tc / sizeof(uint64_t);
                 if (rc != SJHIP_OK) snprintf(sl.err, sizeof sl.err, "pinned result buffers (%zu tape words, %zu string bytes): allocation failed",
                                              sl.tape_len, sl.strings_len);
-                else if ((rc = sjhip_fetch(sl.ctx, sl.tape, sl.strings)) != SJHIP_OK)  // D2H into pinned memory
+                else if ((rc = s->filter ? sjhip_fetch_filtered(sl.ctx, sl.tape, sl.strings)
+                                         : sjhip_fetch(sl.ctx, sl.tape, sl.strings)) != SJHIP_OK)  // D2H into pinned memory
                     snprintf(sl.err, sizeof sl.err, "%s", sjhip_last_error(sl.ctx));
             } else {
                 snprintf(sl.err, sizeof sl.err, "%s", sjhip_last_error(sl.ctx));
@@ -305,6 +315,24 @@ int sjhip_stream_next(sjhip_stream *s, sjhip_stream_result *out) {
     out->message = sl.in + sl.msg_off;
     out->message_len = sl.msg_len;
     out->device = sl.device;
+    out->records = sl.records;
+    return SJHIP_OK;
+}
+
+// Compose the stream with the query of query.hip: from now on every block's result is the (Tape, Strings.B) of the
+// records whose root object has `key` with the string value `value` (sjhip_filter_where) -- what ParseND returns for the
+// document made of the block's matching lines -- and sjhip_stream_result::records counts them.  Set before the first
+// block is submitted (klen = 0 turns the filter off).
+int sjhip_stream_set_filter(sjhip_stream *s, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen) {
+    if (!s || (klen && !key) || (vlen && !value)) return SJHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->next_submit != s->next_deliver || s->filling >= 0) {
+        snprintf(s->err, sizeof s->err, "sjhip_stream_set_filter: blocks are in flight");
+        return SJHIP_ERR_ARG;
+    }
+    s->filter = klen != 0;
+    s->fkey.assign(key, key + klen);
+    s->fval.assign(value, value + vlen);
     return SJHIP_OK;
 }
 

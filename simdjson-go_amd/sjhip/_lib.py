@@ -16,7 +16,7 @@ intp = C.POINTER(C.c_int)
 class StreamResult(C.Structure):
     """sjhip_stream_result (include/sjhip.h)"""
     _fields_ = [("tape", C.c_void_p), ("tape_len", C.c_size_t), ("strings", C.c_void_p), ("strings_len", C.c_size_t),
-                ("message", C.c_void_p), ("message_len", C.c_size_t), ("device", C.c_int)]
+                ("message", C.c_void_p), ("message_len", C.c_size_t), ("device", C.c_int), ("records", C.c_uint64)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/sjhip.h
@@ -67,6 +67,7 @@ SYMBOLS = {
     "sjhip_stream_submit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "sjhip_stream_next": (C.c_int, [C.c_void_p, C.POINTER(StreamResult)]),
     "sjhip_stream_ready": (C.c_int, [C.c_void_p]),
+    "sjhip_stream_set_filter": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "sjhip_stream_release": (C.c_int, [C.c_void_p]),
     "sjhip_stage1_set_variant": (C.c_int, [C.c_int]),
     "sjhip_stage1_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

@@ -245,7 +245,7 @@ class MultiContext:
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 
-    __slots__ = ("Message", "Tape", "Strings", "_tape_buf", "_str_buf")
+    __slots__ = ("Message", "Tape", "Strings", "_tape_buf", "_str_buf", "records")
 
     def __init__(self, message, tape, strings, tape_buf=None, str_buf=None):
         self.Message = message
@@ -253,6 +253,7 @@ class ParsedJson:
         self.Strings = strings
         self._tape_buf = tape if tape_buf is None else tape_buf  # capacity behind Tape / Strings (reuse)
         self._str_buf = strings if str_buf is None else str_buf
+        self.records = 0  # filtered streams: matching records of the block
 
 
 _DEFAULT = {}

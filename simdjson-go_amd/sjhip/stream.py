@@ -76,6 +76,14 @@ class Stream:
     def in_flight(self):
         return self._L.sjhip_stream_in_flight(self._h)
 
+    def set_filter(self, key, value):
+        """From now on every block delivers only the records whose root object has `key` with the string value `value`
+        (sjhip_filter_where on the device-resident tape); ParsedJson.records counts them."""
+        k, v = bytes(key), bytes(value)
+        rc = self._L.sjhip_stream_set_filter(self._h, k, len(k), v, len(v))
+        if rc:
+            raise ParseError(f"sjhip_stream_set_filter: {self._L.sjhip_stream_last_error(self._h).decode()}", rc)
+
     def ready(self):
         """True if the oldest outstanding block has finished (take() would not wait)."""
         return bool(self._L.sjhip_stream_ready(self._h))
@@ -129,10 +137,12 @@ class Stream:
             msg = C.string_at(r.message, r.message_len) if r.message_len else b""
         finally:
             L.sjhip_stream_release(self._h)
-        return ParsedJson(msg, tape_buf[:tl], str_buf[:sl], tape_buf, str_buf)
+        pj = ParsedJson(msg, tape_buf[:tl], str_buf[:sl], tape_buf, str_buf)
+        pj.records = int(r.records)
+        return pj
 
 
-def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=None, n_devices=1):
+def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=None, n_devices=1, where=None):
     """Generator over the ParsedJson of every block, in stream order.
 
     Mirrors `ParseNDStream(r, res, reuse)`: a block that fails to parse raises `ParseError` after all earlier
@@ -144,6 +154,8 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
     """
     reader = _buffered(reader, block_size)
     st = Stream(block_size, slots=max(0, int(inflight)), first_device=device, n_devices=n_devices)
+    if where is not None:  # (key, value): only the matching records of every block cross PCIe
+        st.set_filter(*where)
 
     def old():
         if reuse is None:

@@ -134,3 +134,29 @@ def test_full_size_count(ctx):  # 116 per file -> 116 000 on configs[4]
     n, pj = ctx.filter_where(b"Make", b"HOND")
     assert np.array_equal(pj.Tape, ref.tape)
     assert np.array_equal(pj.Strings, ref.strings)
+
+
+def test_filtered_stream():
+    """ParseNDStream composed with the filter (sjhip_stream_set_filter): every block delivers ParseND of its matching lines
+    only; countWhere of the reference's test (ndjson_test.go:250-267: 116 matches per file) adds up over the blocks."""
+    import io
+    import sjhip
+    park = fixtures.load("parking-citations")
+    stream = park * 9
+    bs = 1 << 20
+    blocks = list(sjhip.cut_blocks(io.BytesIO(stream), bs))
+    got = list(sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=3, where=(b"Make", b"HOND")))
+    assert len(got) == len(blocks)
+    assert sum(pj.records for pj in got) == 116 * 9
+    for pj, blk in zip(got, blocks):
+        lines = [ln for ln in blk.split(b"\n") if b'"Make":"HOND"' in ln]
+        assert pj.records == len(lines)
+        if not lines:
+            assert len(pj.Tape) == 0
+            continue
+        ref = O.parse(b"\n".join(lines), ndjson=True, copy_strings=True)
+        assert ref.rc == 0
+        assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
+    # without a match anywhere
+    none = list(sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=2, where=(b"Make", b"no such make")))
+    assert len(none) == len(blocks) and all(pj.records == 0 and len(pj.Tape) == 0 for pj in none)
