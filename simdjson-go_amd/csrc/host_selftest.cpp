@@ -99,6 +99,7 @@ extern "C" void sj_selftest_classify(const uint8_t *in64, uint64_t *out6) {
     out6[4] = c.ctrl;
     out6[5] = c.nl;
     out6[6] = c.esc1;
+    for (int j = 0; j < 4; j++) out6[7 + j] = c.kp[j];
 }
 extern "C" uint64_t sj_selftest_odd_backslash(uint64_t bs, uint32_t carry_in, uint32_t *carry_out) {
     return odd_backslash_ends(bs, carry_in, *carry_out);

@@ -159,6 +159,9 @@ struct Classes {
     u64 nl;      // '\n'                   (find_newline_delimiters_amd64.s:16-28)
     u64 esc1;    // " \\ / b f n r t: the characters a simple escape may name (escape_map, parse_string_amd64.s:38-69);
                  // only the whole-parse kernel reads it (dead code elsewhere)
+    u64 kp[4];   // bit planes of the token kind a byte starts (sj_stage2.h Kind: { 1 [ 2 } 3 ] 4 : 5 , 6 " 7 number 8
+                 // t 9 f 10 n 11; 0 = no token can start here; '\n' is left out: the NDJSON kernel ORs c.nl into
+                 // planes 2 and 3 for kind 12); whole-parse kernel only
 };
 
 // Every class is a conjunction of plane literals; the network below shares the common factors and
@@ -202,6 +205,24 @@ SJ_HD Classes classify(const u32 (&w)[16]) {
     const u64 t6 = bitop3<(TA & ~TB & TC)>(h011, b4, s6), t7 = bitop3<(TA & TB & TC)>(h011, b4, s7);
     const u64 letters = bitop3<((TA | TB) & ~TC)>(t6, t7, b0);
     c.esc1 = bitop3<(TA | TB | TC)>(c.quote, c.bs, slash) | letters;
+    // token kinds as bit planes (the byte of a structural decides its kind; stage 2 reads them instead of the message)
+    const u64 colon = c2 & ~b0;                                            // 0x3a
+    const u64 base = bitop3<(TA & TB & ~TC)>(h011, b2, b0);                // 011x x1x0: t 74  f 66  n 6e
+    const u64 tx = bitop3<(TA & ~TB & ~TC)>(b4, b3, b1);                   // b4 & ~b3 & ~b1
+    const u64 kt = base & tx;                                              // t
+    const u64 fn = bitop3<(TA & ~TB & TC)>(base, b4, b1);                  // f, n
+    const u64 kn = fn & b3;                                                // n
+    const u64 le9 = bitop3<(~TA | (~TB & ~TC))>(b3, b2, b1);               // low nibble <= 9
+    const u64 digit = bitop3<(TA & TB & TC)>(h001, b4, le9);               // 0x30 .. 0x39
+    const u64 minus = bitop3<(TA & ~TB & TC)>(h001, b4, m110) & b0;        // 0x2d = 0010 1101
+    const u64 curly = brackets & b5;                                       // { }
+    const u64 k0a = bitop3<(TA | TB | TC)>(curly, colon, c.quote);
+    c.kp[0] = bitop3<(TA | TB | TC)>(k0a, kt, kn);                         // { } : " t n
+    const u64 k1a = bitop3<(TA & ~(TB ^ TC))>(brackets, b5, b2);           // [ (b5 = 0, b2 = 0)  } (1, 1)
+    c.kp[1] = bitop3<(TA | TB | TC)>(k1a, comma, c.quote) | fn;            // [ } , " f n
+    const u64 k2a = bitop3<(TA & ~TB & TC)>(brackets, b5, b2);             // ]
+    c.kp[2] = bitop3<(TA | TB | TC)>(k2a, colon, comma) | c.quote;         // ] : , "
+    c.kp[3] = bitop3<(TA | TB | TC)>(digit, minus, kt) | fn;               // number t f n
     return c;
 }
 

@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sj_chunk.h"
 #include "sj_device.h"
 #include "sj_stage2.h"
@@ -79,7 +81,6 @@ template <bool TRACE>
 __device__ __forceinline__ void trace_put(u64 *trace, u32 tile, int waves, int wave, int lane, int k) {
     if (TRACE && lane == 0) trace[((u64)tile * waves + wave) * TRACE_WORDS + k] = __builtin_readcyclecounter();
 }
-__constant__ KindLut c_s1_klut = make_kind_lut();
 
 // ---- tiles ---------------------------------------------------------------------------------
 // A tile is UNITS = WAVES * CH wave units of 4 KiB.  A document rarely is a whole number of rounds of (blocks x tiles):
@@ -313,7 +314,7 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
-                                        const S1Aux &aux, const u8 *__restrict__ edge, bool TOP = false) {
+                                        const S1Aux &aux, const u8 *__restrict__ edge, u64 (&kp)[CH][4], bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
 #if defined(SJ_S1_ROLL)
@@ -331,6 +332,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             m[(k * 2 + 1) * 64 + lane] = 0;
             pre[k * 64 + lane] = 0;
             if (lane == 0) s_unit[k * WAVES + wave] = 0;
+            kp[k][0] = kp[k][1] = kp[k][2] = kp[k][3] = 0;
             if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
             continue;
         }
@@ -362,6 +364,12 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         if (k == 0 || TOP) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
         const Classes c = classify(w);
+        if (AUX) {  // the kind of the token a byte would start, as four bit planes (flatten_tile looks them up per structural)
+            kp[k][0] = c.kp[0];
+            kp[k][1] = c.kp[1];
+            kp[k][2] = NDJSON ? c.kp[2] | c.nl : c.kp[2];  // '\n' is a token (kind 12) only in NDJSON
+            kp[k][3] = NDJSON ? c.kp[3] | c.nl : c.kp[3];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (TOP) __builtin_amdgcn_s_setprio(3);
         else if (k == 0) __builtin_amdgcn_s_setprio(2);
@@ -446,15 +454,22 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 // Each wave expands its own units: lanes scatter their positions into the wave's LDS staging buffer, then the
 // wave copies the buffer out with coalesced 256-byte stores.  A unit with more positions than the buffer holds
 // (512: the window that held the masks; 1024 in the whole-parse kernel) takes several rounds.
-static constexpr u32 S1_STAGE_CAP = 1024;
-template <int BLOCK, int CH, bool BIG, u32 BIGCAP = S1_STAGE_CAP>
-__device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
+// The whole-parse kernel (KIND) also writes the KIND of every token (sj_stage2.h) next to its position.  The kind is a
+// function of the token's first byte, and phase A has the bit planes of that function for every chunk (Classes::kp):
+// they wait in LDS (kpl, 32 bytes per chunk), the staged entries are 16-bit offsets inside the unit, and the copy-out
+// looks the four plane bits of an entry up -- no load from the message.  (The first version gathered the byte of every
+// structural from the message and translated it through a table: 17 us of 160 on configs[1], 100 us of 316 on
+// configs[4], whose 78 M tokens are one gather each.)
+template <int BLOCK, int CH, bool KIND>
+__device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
-                                             u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out, const u8 *msg0,
-                                             const u8 *s_klut) {
+                                             u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
-    constexpr u32 CAP = BIG ? BIGCAP : (u32)CH * 256u;
+    // the window that held the masks (CH * 2 * 64 u64) stages the positions of a unit: 32-bit positions, or (KIND)
+    // 16-bit offsets inside the unit; denser units take several rounds
+    constexpr u32 CAP = KIND ? (u32)CH * 512u : (u32)CH * 256u;
+    typedef typename std::conditional<KIND, uint16_t, u32>::type Staged;
     static_assert(UNITS <= 64, "one unit per lane in the prefix");
     // per-unit counts under the now known state, prefix over the units (lane u <-> unit u)
     const u32 v = lane < UNITS ? s_unit[lane] : 0u;
@@ -488,39 +503,33 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
         const u32 lo0 = (u32)s, hi0 = (u32)(s >> 32);
         const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
         const u32 loc = upto[k] - n;  // offset of this lane's first position inside the unit
-        u32 pos0 = (u32)(tile_unit<UNITS>(tm, t, u) * 4096 + (u64)lane * 64 - lead);  // (unused for a void unit: no bits)
-        __builtin_amdgcn_wave_barrier();  // the staging buffers are free: all masks are in registers / already copied out
-        // up to 512 positions fit the window that held the masks; the whole-parse kernel has a larger buffer for
-        // denser units (its copy-out is the expensive one: it also writes the token kinds)
-        u32 *stage = (!BIG || C <= (u32)CH * 256u) ? reinterpret_cast<u32 *>(m) : stage_big;
-        // copies the first cnt staged positions to out_pos[gd ...] (and their kinds to kind_out)
+        const u32 ubase = (u32)(tile_unit<UNITS>(tm, t, u) * 4096 - lead);  // (unused for a void unit: no bits)
+        u32 pos0 = KIND ? (u32)lane * 64u : ubase + (u32)lane * 64u;        // what a lane stages: position, or offset in the unit
+        __builtin_amdgcn_wave_barrier();  // the staging window is free: all masks are in registers / already copied out
+        Staged *stage = reinterpret_cast<Staged *>(m);
+        const u32 *k32 = reinterpret_cast<const u32 *>(kpl + (KIND ? k * 4 * 64 : 0));  // the four kind planes of this pass
+        auto kind_of = [&](u32 e) -> u32 {  // e = chunk << 6 | bit
+            const u32 w = ((e >> 6) << 1) + ((e >> 5) & 1u), b = e & 31u;
+            const u32 k0 = k32[w], k1 = k32[128 + w], k2 = k32[256 + w], k3 = k32[384 + w];
+            return ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2) | (((k3 >> b) & 1u) << 3);
+        };
+        // copies the first cnt staged entries to out_pos[gd ...] (and their kinds to kind_out)
         auto copy_out = [&](u32 cnt, u64 gd) {
-            if (kind_out) {  // whole parse: the kind of every token next to its position (sj_stage2.h)
-                // four consecutive positions per lane: one 16-byte LDS read, four gathers in flight (the tile's bytes
-                // are still in L2), one 16-byte store of the positions and one 4-byte store of their kinds (neither is
-                // aligned to its size in memory: fine on gfx950)
+            if (KIND) {
+                // four consecutive entries per lane: one 8-byte LDS read, sixteen plane words, one 16-byte store of the
+                // positions and one 4-byte store of their kinds (neither is aligned to its size in memory: fine on gfx950)
                 const u32 c4 = (fits ? cnt : 0u) & ~3u;
                 for (u32 i = (u32)lane * 4u; i < c4; i += 256u) {
-                    const uint4 at = *reinterpret_cast<const uint4 *>(stage + i);
-#if defined(SJ_EXP)
-                    const bool ld = msg0 != nullptr;
-                    const u8 b0 = ld ? msg0[at.x] : (u8)'"', b1 = ld ? msg0[at.y] : (u8)'"', b2 = ld ? msg0[at.z] : (u8)'"', b3 = ld ? msg0[at.w] : (u8)'"';
-#else
-                    const u8 b0 = msg0[at.x], b1 = msg0[at.y], b2 = msg0[at.z], b3 = msg0[at.w];
-#endif
-                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = at;
-                    const u32 k4 = (u32)s_klut[b0] | ((u32)s_klut[b1] << 8) | ((u32)s_klut[b2] << 16) | ((u32)s_klut[b3] << 24);
-                    *reinterpret_cast<u32 *>(kind_out + gd + i) = k4;
+                    const uint2 e2 = *reinterpret_cast<const uint2 *>(stage + i);
+                    const u32 e0 = e2.x & 0xffffu, e1 = e2.x >> 16, e3 = e2.y >> 16, e2v = e2.y & 0xffffu;
+                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = make_uint4(ubase + e0, ubase + e1, ubase + e2v, ubase + e3);
+                    *reinterpret_cast<u32 *>(kind_out + gd + i) = kind_of(e0) | (kind_of(e1) << 8) | (kind_of(e2v) << 16) | (kind_of(e3) << 24);
                 }
                 for (u32 i = c4 + (u32)lane; i < cnt; i += 64) {  // the last <= 3 (or, without room for all, everything)
                     if (fits || gd + i < pos_cap) {
-                        const u32 at = stage[i];
-                        out_pos[gd + i] = at;
-#if defined(SJ_EXP)
-                        kind_out[gd + i] = s_klut[msg0 ? msg0[at] : (u8)'"'];
-#else
-                        kind_out[gd + i] = s_klut[msg0[at]];
-#endif
+                        const u32 e = (u32)stage[i];
+                        out_pos[gd + i] = ubase + e;
+                        kind_out[gd + i] = (u8)kind_of(e);
                     }
                 }
             } else if (fits) {
@@ -528,21 +537,21 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
                 const u32 c4 = cnt & ~3u;
                 for (u32 i = (u32)lane * 4u; i < c4; i += 256u)
                     *reinterpret_cast<uint4 *>(out_pos + gd + i) = *reinterpret_cast<const uint4 *>(stage + i);
-                if (c4 + (u32)lane < cnt) out_pos[gd + c4 + lane] = stage[c4 + lane];
+                if (c4 + (u32)lane < cnt) out_pos[gd + c4 + lane] = (u32)stage[c4 + lane];
             } else {
                 for (u32 i = lane; i < cnt; i += 64)
-                    if (gd + i < pos_cap) out_pos[gd + i] = stage[i];
+                    if (gd + i < pos_cap) out_pos[gd + i] = (u32)stage[i];
             }
         };
         if (C <= CAP) {
             // two positions per iteration, the lowest and the highest set bit of the word (an odd last bit is
             // simply written twice to the same slot)
             const u32 nlo = (u32)__builtin_popcount(lo0);
-            u32 *p = stage + loc, *q = p + nlo - 1;
+            Staged *p = stage + loc, *q = p + nlo - 1;
             for (u32 x = lo0; x != 0;) {
                 const u32 top = 31u - (u32)__builtin_clz(x);
-                *p++ = pos0 + (u32)__builtin_ctz(x);
-                *q-- = pos0 + top;
+                *p++ = (Staged)(pos0 + (u32)__builtin_ctz(x));
+                *q-- = (Staged)(pos0 + top);
                 x = bitop3<(TA & TB & ~TC)>(x, x - 1u, 1u << top);
             }
             pos0 += 32;
@@ -550,8 +559,8 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
             q = p + (n - nlo) - 1;
             for (u32 x = hi0; x != 0;) {
                 const u32 top = 31u - (u32)__builtin_clz(x);
-                *p++ = pos0 + (u32)__builtin_ctz(x);
-                *q-- = pos0 + top;
+                *p++ = (Staged)(pos0 + (u32)__builtin_ctz(x));
+                *q-- = (Staged)(pos0 + top);
                 x = bitop3<(TA & TB & ~TC)>(x, x - 1u, 1u << top);
             }
             __builtin_amdgcn_wave_barrier();
@@ -562,7 +571,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, u32 *stage_big,
             for (u32 r0 = 0; r0 < C; r0 += CAP) {
                 const u32 lim = r0 + CAP;
                 while (r != 0 && l < lim) {
-                    stage[l - r0] = pos0 + (u32)ctz64(r);
+                    stage[l - r0] = (Staged)(pos0 + (u32)ctz64(r));
                     r &= r - 1;
                     l++;
                 }
@@ -593,17 +602,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_res2[2][4];  // look-back result of tile T(i) in slot i & 1: G, pre_mask, BASE (lo, hi)
     __shared__ u64 s_mask[2][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[2][WAVES][CH * 64];  // per chunk: inclusive structural counts of its unit, both hypotheses
-    __shared__ u32 s_stage[AUX ? WAVES : 1][AUX ? S1_STAGE_CAP : 4];  // whole parse: positions of one dense unit
-    __shared__ u8 s_klut[AUX ? 256 : 4];
+    // whole parse: the kind planes of the tile that is flattened next (4 x u64 per chunk); a wave keeps the planes of the
+    // tile it has just classified in registers until it has flattened the tile in front, then parks them here
+    __shared__ u64 s_kpl[AUX ? WAVES : 1][AUX ? CH * 4 * 64 : 1];
 
     const int tid = threadIdx.x;
-    if (AUX && tid < 256) {  // '\n' is a token only in NDJSON
-        const u8 k = c_s1_klut.v[tid];
-        s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
-    }
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
+    u64 kp[CH][4];
 
     // At launch every block of the grid queues up on the ticket counter: the first ticket is drawn alone
     // (one atomic per block), the next two while phase A of the first tile is already running.
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
-                                            s_pre[ma][wave], s_unit[ua], aux, edge, wave == 0 && !first);
+                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, wave == 0 && !first);
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
         }
         u32 *res = s_res2[j & 1u];
@@ -701,9 +708,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             const u32 G = uniform(res[0]), pm = uniform(res[1]);
             const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
             u64 tile_end = 0;
-            err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
-                                           out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr,
-                                           SJ_S1EXP(aux, 7) ? nullptr : base + lead, s_klut);
+            err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_kpl[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
+                                           out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr);
             if (t_prev == num_tiles - 1 && tid == 0)
                 __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
@@ -711,6 +717,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                 aux.trace[((u64)t_prev * WAVES + wave) * TRACE_WORDS + 5] =
                     (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
             if (!has_a) break;
+        }
+        if (AUX && has_a) {  // the planes of T(j) wait in LDS for its flatten in the next iteration (this wave's window only)
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) s_kpl[wave][(k * 4 + q) * 64 + lane] = kp[k][q];
         }
         t_prev = t_a;
     }
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     constexpr u32 D = DEPTH - 1;
     static_assert(UNITS <= 32, "pre_mask is a u32");
     static_assert(DEPTH >= 2 && DEPTH <= 3, "rings of 8 and 4");
-    constexpr u32 STAGE_CAP = AUX ? (DEPTH == 2 ? S1_STAGE_CAP : 512u) : 4u;
+    static_assert(!AUX, "the whole parse runs the barrier kernel (one set of kind planes in flight)");
     __shared__ u32 s_tk[8];         // T(j) in slot j & 7
     __shared__ u32 s_tkn;           // T(0) .. T(s_tkn - 1) are in s_tk
     __shared__ u32 s_unit[8][UNITS];
@@ -756,14 +768,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     __shared__ u32 s_resflag[4];    // j + 1 once s_res[j & 3] holds the result of T(j)
     __shared__ u64 s_mask[DEPTH][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[DEPTH][WAVES][CH * 64];
-    __shared__ u32 s_stage[AUX ? WAVES : 1][STAGE_CAP];
-    __shared__ u8 s_klut[AUX ? 256 : 4];
 
     const int tid = threadIdx.x;
-    if (AUX && tid < 256) {  // '\n' is a token only in NDJSON
-        const u8 k = c_s1_klut.v[tid];
-        s_klut[tid] = (!NDJSON && k == K_NL) ? (u8)K_BAD : k;
-    }
+    u64 kp[CH][4];  // (unused: plain stage 1)
     if (tid < 8) {
         s_arrive[tid] = 0;
         s_ready[tid] = 0;
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     }
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge);
+                                    aux, edge, kp);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();
     {
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
-                                            s_unit[ua], aux, edge, wave == 0);
+                                            s_unit[ua], aux, edge, kp, wave == 0);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             u32 arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -938,9 +945,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u32 G = uniform(res[0]), pm = uniform(res[1]);
         const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
         u64 tile_end = 0;
-        err |= flatten_tile<BLOCK, CH, AUX, STAGE_CAP>(tm, s_mask[mf][wave], s_stage[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
-                                       wave, out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len,
-                                       AUX ? aux.kind : nullptr, base + lead, s_klut);
+        err |= flatten_tile<BLOCK, CH, false>(tm, s_mask[mf][wave], nullptr, s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
+                                              wave, out_pos, pos_cap, tile_end, nullptr, len, nullptr);
         if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
@@ -1113,19 +1119,18 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     } while (0)
 #define S1_LAUNCH_NB(B, C, D, W)                                                            \
     do {                                                                                   \
-        const bool ax = aux_buf || d_kind;                                                 \
         if (d_trace) {                                                                     \
-            if (nd || ax) return hipErrorInvalidValue;                                     \
+            if (nd) return hipErrorInvalidValue;                                           \
             S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false, true>), B);             \
         } else if (nd) {                                                                   \
-            if (ax) S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, true, true>), B);             \
-            else S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, true, false>), B);               \
+            S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, true, false>), B);                    \
         } else {                                                                           \
-            if (ax) S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, true>), B);            \
-            else S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false>), B);              \
+            S1_LAUNCHK((stage1_kernel_nb<B, C, D, W, false, false>), B);                   \
         }                                                                                  \
     } while (0)
-    if (v.depth) {
+    if (aux_buf || d_kind) {  // the whole parse: the barrier kernel in its default shape (the variants are for plain stage 1)
+        S1_LAUNCH(stage1_kernel, 1024, 2, 4);
+    } else if (v.depth) {
         if (v.depth == 2) S1_LAUNCH_NB(1024, 2, 2, 4);
         else S1_LAUNCH_NB(1024, 2, 3, 4);
     } else {

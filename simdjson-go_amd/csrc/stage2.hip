@@ -103,14 +103,14 @@ struct S2Dev {
 __device__ __forceinline__ u32 token_count(const S2Dev &p) { return p.n_dev ? (u32)*p.n_dev : p.n; }
 
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
-__global__ __launch_bounds__(256) void k_str_masks(S2Dev p) {
+__device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nblocks) {
     // Without touching the message (sj_strings.h str_chunk_masks_fast is the per-chunk statement): a chunk takes the
     // general routine only if it, or the chunk in front of it, holds an escaped character that no simple escape names.
     // Persistent waves: unit wave_id, wave_id + waves, ...; the masks of the next unit are requested before the current
     // one is worked on.
     const int lane = threadIdx.x & 63;
-    const u64 nwaves = (u64)gridDim.x * 4;
-    u64 unit = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 nwaves = (u64)nblocks * 4;
+    u64 unit = (u64)block * 4 + (threadIdx.x >> 6);
     if (unit >= p.units) return;  // whole waves
     struct In {
         u64 qm, q, st, stp, slow_w, slow_p;
@@ -568,16 +568,16 @@ static constexpr int KIND_LDS = S2_TILE + 8;
 // 256 threads x 16 tokens: a thread reads its 16 kinds with one 16-byte load; the neighbours' kinds come from LDS.
 static constexpr int RD_BLOCK = 256, RD_ITEMS = S2_TILE / RD_BLOCK;
 static_assert(RD_ITEMS == 16, "one uint4 of kinds per thread");
-__global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
+__device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
     __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u32 s_k[RD_BLOCK * 4 + 8];  // dword 4 + 4 * tid: the thread's kinds
     __shared__ PAgg s_w[RD_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
-    if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
+    if ((u64)block * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     s_elut[tid] = c_elut.v[tid];
     s_elut[tid + 256] = c_elut.v[tid + 256];
-    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * RD_ITEMS;
+    const u32 t0 = block * S2_TILE, base = t0 + (u32)tid * RD_ITEMS;
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
     if (base + RD_ITEMS <= n) {
@@ -631,8 +631,16 @@ __global__ __launch_bounds__(RD_BLOCK) void k_s2_reduce(S2Dev p) {
     if (tid == 0) {
         PAgg tot = s_w[0];
         for (int w = 1; w < RD_BLOCK / 64; w++) tot = pagg_comb<true>(tot, s_w[w]);
-        p.agg[blockIdx.x].a = pagg_unpack(tot);
+        p.agg[block].a = pagg_unpack(tot);
     }
+}
+
+// Both measuring passes in one launch (they are independent and neither fills the device on its own): blocks below
+// `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
+// to its scan aggregate.
+__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
+    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks);
+    else s2_reduce_body(p, blockIdx.x - mblocks);
 }
 
 // ---- pass 2: exclusive scan over the tile aggregates (in place) + totals: SCAN_SEGS blocks ---------------------
@@ -1325,8 +1333,10 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
 hipError_t stage2_launch_measure(const S2Args &a) {
     const S2Dev p = stage2_view(a);
     if (a.n == 0) return hipSuccess;
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_masks, dim3(persistent_blocks(k_str_masks, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
-    hipLaunchKernelGGL(k_s2_reduce, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p);
+    {
+        const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
+        hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
+    }
     hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * SCAN_SEGS : SCAN_SEGS), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
 }

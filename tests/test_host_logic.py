@@ -122,7 +122,11 @@ def test_classify_every_byte_value():
     L.sj_selftest_classify.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
     want = {0: lambda b: b == 0x5c, 1: lambda b: b == 0x22, 2: lambda b: b in b"{}[]:,", 3: lambda b: b in b" \t\n\r",
             4: lambda b: b < 0x20, 5: lambda b: b == 0x0a, 6: lambda b: b in b'"\\/bfnrt'}
-    out = (C.c_uint64 * 7)()
+    # kind planes: the token kind a byte starts (sj_stage2.h Kind), '\n' left to the NDJSON kernel
+    kinds = {ord("{"): 1, ord("["): 2, ord("}"): 3, ord("]"): 4, ord(":"): 5, ord(","): 6, ord('"'): 7, ord("-"): 8,
+             ord("t"): 9, ord("f"): 10, ord("n"): 11}
+    kinds.update({d: 8 for d in range(0x30, 0x3a)})
+    out = (C.c_uint64 * 11)()
     for base in range(0, 256, 64):
         for rot in (0, 1, 17):
             chunk = bytes(((base + (j + rot) % 64) & 0xff) for j in range(64))
@@ -130,3 +134,6 @@ def test_classify_every_byte_value():
             for k, f in want.items():
                 m = sum(1 << j for j in range(64) if f(chunk[j]))
                 assert out[k] == m, (k, base, rot, hex(out[k]), hex(m))
+            for j in range(64):
+                kind = sum(((out[7 + b] >> j) & 1) << b for b in range(4))
+                assert kind == kinds.get(chunk[j], 0), (chunk[j], kind)
