@@ -71,6 +71,14 @@ sjhip_ctx *sjhip_ctx_create(int device) {
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    // second stream of the parse (optional: without it the kernels simply run one behind the other)
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+        ctx->side_stream = nullptr;
+    }
     return ctx;
 }
 
@@ -85,6 +93,12 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -18,6 +18,8 @@ struct sjhip_ctx {
     hipStream_t stream = nullptr;      // stream all work is queued on
     hipStream_t own_stream = nullptr;  // created with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side_stream = nullptr; // the string bytes of a parse run here, beside the tape kernels (parse_api.hip)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table

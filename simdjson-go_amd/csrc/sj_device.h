@@ -61,7 +61,14 @@ struct S2Args {
     uint64_t tape_base, strings_base, msg_base;
     void *str_aux;          // string masks of stage 1 (str_aux_layout) or null: per-string walks
     hipStream_t stream;
+    // null, or a second stream + two events: the string bytes (k_str_emit) run beside the tape kernels (stage2_launch_emit)
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
 };
+// S2Args::flags bit: k_s2_emit takes a chunk's Strings.B offset from unit_cnt + ChunkRec::pre instead of ChunkRec::abs
+// (k_str_emit then does not have to run in front of it, and does not write abs)
+constexpr uint32_t S2_FLAG_NO_ABS = 1u << 8;
+constexpr uint32_t S2_FLAG_FORK_LATE = 1u << 9;  // the side stream starts behind k_s2_emit (beside numbers and brackets)
 size_t stage2_zero_bytes();
 size_t stage2_workspace_bytes(size_t n_tokens);
 hipError_t stage2_launch_measure(const S2Args &a);

@@ -66,7 +66,7 @@ struct S2Dev {
     u32 n;         // tokens -- or, with n_dev, an upper bound the arrays are sized for
     const unsigned long long *n_dev;  // null, or the token count on the device (Stage1State::total): the host has not
                                       // waited for stage 1 (small documents: one synchronisation per parse)
-    u32 ndjson, copy_strings;
+    u32 ndjson, copy_strings, no_abs;
     const u8 *kind;  // [n] token kinds (stage 1 writes them next to the positions)
     u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     u32 *str_off;  // [n] selective copy only: Strings.B offset of a copied string
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         const u64 g = (u64)cur.g;  // exclusive prefix: Strings.B offset of the unit
         // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
         // two record loads instead of two records + two unit prefixes
-        if (!SJ_EXPBIT(p, 4)) p.rec[c].abs = (u32)g + pre;
+        if (!p.no_abs) p.rec[c].abs = (u32)g + pre;
         if (total != 0) {  // wave-uniform
             if (em != 0 && patched) {
 #pragma unroll
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
 // MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
 // lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
 template <bool MASKS>
-__global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
+__global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
     __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
@@ -916,8 +916,11 @@ __global__ __launch_bounds__(S2_BLOCK) void k_s2_emit(S2Dev p) {
             const u64 a0 = (u64)s_pos[idx] + p.sv.lead + 1, a1 = (u64)s_pos[idx + 1] + p.sv.lead;
             const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
             const u32 b0 = (u32)a0 & 63u, b1 = (u32)a1 & 63u;
-            const u64 so = (u64)r0.abs + (u64)popc64(r0.em & ~(~0ull << b0));  // absolute Strings.B offset of the chunk (k_str_emit) + inside
-            const u64 se = (u64)r1.abs + (u64)popc64(r1.em & ~(~0ull << b1));
+            // absolute Strings.B offset of the chunk (left by k_str_emit, or unit prefix + bytes of the unit in front) + inside
+            const u64 c0 = p.no_abs ? (u64)p.unit_cnt[a0 >> 12] + (r0.pre & CHUNK_PRE_MASK) : (u64)r0.abs;
+            const u64 c1 = p.no_abs ? (u64)p.unit_cnt[a1 >> 12] + (r1.pre & CHUNK_PRE_MASK) : (u64)r1.abs;
+            const u64 so = c0 + (u64)popc64(r0.em & ~(~0ull << b0));
+            const u64 se = c1 + (u64)popc64(r1.em & ~(~0ull << b1));
             const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
             if (!SJ_EXPBIT(p, 2))
                 *reinterpret_cast<uint4 *>(p.tape + T0 + (v >> 12)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
@@ -1260,6 +1263,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.n_dev = a.n_dev;
     p.ndjson = a.flags & 1u;
     p.copy_strings = (a.flags >> 1) & 1u;
+    p.no_abs = (a.flags & S2_FLAG_NO_ABS) ? 1u : 0u;
     p.kind = a.d_kind;
     p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
     p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
@@ -1349,10 +1353,30 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     const size_t n = a.n;
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
-    // the string bytes first: k_str_emit also leaves every chunk's absolute Strings.B offset for k_s2_emit
-    if (p.sv.qm) hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    // The string bytes: in front of the tape kernels (k_str_emit then leaves every chunk's absolute Strings.B offset
+    // for k_s2_emit), or, with S2_FLAG_NO_ABS and a side stream, beside them: k_str_emit streams at HBM speed while
+    // k_br_match / k_min_upper / k_numbers wait on dependent loads, so the two chains fill each other's gaps.
+    const bool beside = p.sv.qm && a.side && (a.flags & S2_FLAG_NO_ABS);
+    const bool late = beside && (a.flags & S2_FLAG_FORK_LATE);  // the side stream starts behind k_s2_emit
+    auto fork_strings = [&]() -> hipError_t {
+        hipError_t e = hipEventRecord(a.ev_fork, a.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(a.side, a.ev_fork, 0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.side, p);
+        return hipEventRecord(a.ev_join, a.side);
+    };
+    if (beside && !late) {
+        const hipError_t e = fork_strings();
+        if (e != hipSuccess) return e;
+    } else if (p.sv.qm && !beside) {
+        hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    }
     if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
     else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    if (late) {
+        const hipError_t e = fork_strings();
+        if (e != hipSuccess) return e;
+    }
     {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count)
         const u32 nblocks = gb < 2048 ? gb : 2048;
         const u64 want = p.nlev > 1 ? (p.lev_size[1] + 63) / 64 : 0;  // one block per 4096 depths at a time
@@ -1362,6 +1386,10 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, a.stream, p);
+    if (beside) {
+        const hipError_t e = hipStreamWaitEvent(a.stream, a.ev_join, 0);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 
