@@ -238,6 +238,11 @@ def main():
                                "input_GBps": round(nb / ms_b / 1e6, 1), "achieved": round((nb + 4 * sb) / ms_b / 1e6, 1),
                                "frac": round((nb + 4 * sb) / ms_b / 1e6 / HBM_PEAK_GBS, 4),
                                "input_frac": round(nb / ms_b / 1e6 / HBM_PEAK_GBS, 4)}
+            pmc_big = _profile("stage1_pmc_1GiB.json")
+            if pmc_big:  # 2*FETCH_SIZE of the committed PMC pass on this document over this run's kernel time
+                roof["at_1GiB"]["read_frac"] = round(2 * pmc_big["FETCH_SIZE_KB"] * 1024 / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["at_1GiB"]["traffic"] = int(pmc_big["hbm_bytes_per_launch"])
+                roof["at_1GiB"]["traffic_source_box"] = "committed profile (profiles/stage1_pmc_1GiB.json), not this run"
             del d_big, p_big
             torch.cuda.empty_cache()
 
