@@ -275,7 +275,7 @@ def main():
             import numpy as np
             singles = {}
             for key, name in (("parse_c0_twitter", "twitter"), ("parse_c2_canada", "canada"), ("parse_c3_twitterescaped", "twitterescaped")):
-                raw = fixtures.load(name)
+                raw = fixtures.load(name).strip(b" \t\r\n")  # sjhip_parse_device takes the message as Parse() trims it
                 arr = np.frombuffer(raw, dtype=np.uint8)
                 pj = ctx.parse(arr)
                 reuse = pj
@@ -299,6 +299,27 @@ def main():
                                                      "HBM: see DESIGN.md (fixed costs per call)"}}
                 del d_one
             extra["single_documents"] = singles
+
+            # ---- many small documents in one launch set (sjhip_parse_batch_device): 256 x twitter.json resident in HBM
+            one_doc = fixtures.load("twitter").strip(b" \t\r\n")
+            nb_docs = 256
+            blob = one_doc * nb_docs
+            d_blob = device_doc(blob)
+            offs_b = [k * len(one_doc) for k in range(nb_docs)]
+            lens_b = [len(one_doc)] * nb_docs
+            tlb = slb = 0
+
+            def batch():
+                nonlocal tlb, slb
+                tlb, slb = ctx.parse_batch_device(d_blob.data_ptr(), offs_b, lens_b)
+            t_batch = timed(batch, 10)
+            extra["batch"] = {"workload": f"sjhip_parse_batch_device: {nb_docs} x twitter.json ({len(one_doc)} B each) resident in one "
+                                          "device buffer, packed + parsed as one ND message, result left in HBM",
+                              "documents": nb_docs, "bytes": len(blob), "ms": round(t_batch * 1e3, 3),
+                              "GBps": round(len(blob) / t_batch / 1e9, 1), "us_per_document": round(t_batch * 1e6 / nb_docs, 2),
+                              "tape_words": tlb, "strings_bytes": slb,
+                              "vs_one_parse_per_document": round(singles["parse_c0_twitter"]["device_us"] * nb_docs / (t_batch * 1e6), 1)}
+            del d_blob, blob
 
         # ---- NDJSON (configs[4]): parking-citations x1000 sharded over the ranks at record boundaries.  Each rank runs
         # phase 1 (stage 1 + measure); the ranks all_gather (tape_len, strings_len, return code) over RCCL; phase 2

@@ -99,6 +99,18 @@ const char *sjhip_multi_last_error(const sjhip_multi *m);
 int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len,
                          size_t *strings_len, size_t *msg_off, size_t *msg_len);
 int sjhip_fetch_multi(sjhip_multi *m, uint64_t *tape_dst, uint8_t *strings_dst);
+/* ---- many documents, one launch set (the goroutine-per-Parse shape of benchmarks_test.go:60-75, batched) ------------
+ * The documents are packed into one device message -- each trimmed like Parse() trims it (parse_json_amd64.go:55),
+ * separated by '\n', a raw '\n' INSIDE a document replaced by '\r' (whitespace either way outside strings, the same
+ * stage-1 error inside one; "1\n2" stays the error it is in Parse()) -- and parsed as one ND document.  The result is
+ * what ParseND of that message returns: document i is root i of the tape (Iter.Advance walks them), all string words
+ * point into one Strings.B; sjhip_fetch and every query / serializer call work on it.  An empty document or any invalid
+ * one fails the whole batch with that document's code (stage 1 before stage 2).  Needs SJHIP_FLAG_COPY_STRINGS.
+ * sjhip_parse_batch_device: the documents lie in ONE device buffer at offs[i] (lens[i] bytes, taken untrimmed). */
+int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *lens, size_t n, uint32_t flags,
+                      size_t *tape_len, size_t *strings_len);
+int sjhip_parse_batch_device(sjhip_ctx *ctx, const void *d_buf, const size_t *offs, const size_t *lens, size_t n,
+                             uint32_t flags, size_t *tape_len, size_t *strings_len);
 /* bytes.TrimSpace exactly as parseMessage applies it (parse_json_amd64.go:55); for hosts that are not Go */
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len);
 

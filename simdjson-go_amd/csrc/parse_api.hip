@@ -219,6 +219,12 @@ static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32
     return parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
 }
 
+// batch_api.hip: the whole parse of the message it packed into the context's message arena
+int sj::parse_packed(sjhip_ctx *ctx, size_t len, uint32_t flags, uint8_t last_byte, int have_last, size_t *tape_len,
+                     size_t *strings_len) {
+    return parse_on_device(ctx, ctx->d_msg.p, len, flags, last_byte, have_last, tape_len, strings_len);
+}
+
 int sjhip_parse_shard_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
                             size_t *strings_len) {
     if (!ctx || !tape_len || !strings_len) return SJHIP_ERR_ARG;

@@ -55,6 +55,8 @@ namespace sj {
 void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
+int parse_packed(sjhip_ctx *ctx, size_t len, uint32_t flags, uint8_t last_byte, int have_last, size_t *tape_len,
+                 size_t *strings_len);  // parse_api.hip
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                    uint8_t *d_kind, void *zero2, size_t zero2_bytes);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);

@@ -151,6 +151,77 @@ func (pj *internalParsedJson) parseMessage(msg []byte, ndjson bool) error {
 	return nil
 }
 
+// ParseBatch parses many documents with one launch set (sjhip_parse_batch): the returned ParsedJson holds document i
+// as root i -- iterate with pj.Iter() / Advance() as over a ParseND result.  It replaces the goroutine-per-Parse shape
+// of benchmarks_test.go:60-75 where the documents are small: a GPU parse has a fixed cost per call.  One invalid
+// document fails the batch with that document's error.  Strings are always copied (Message stays empty).
+func ParseBatch(docs [][]byte, reuse *ParsedJson) (*ParsedJson, error) {
+	pj, err := newInternalParsedJson(reuse, nil)
+	if err != nil {
+		return nil, err
+	}
+	c, _ := ctxPool.Get().(*hipCtx)
+	if c == nil {
+		return nil, errors.New("Host CPU does not meet target specs")
+	}
+	defer ctxPool.Put(c)
+	n := len(docs)
+	// the pointer array lives in C memory: cgo forbids passing a Go slice of Go pointers; the documents are pinned
+	// for the duration of the call (the library copies them to the device before it returns)
+	var pinner runtime.Pinner
+	defer pinner.Unpin()
+	ptrs := (*[1 << 28]*C.uint8_t)(C.malloc(C.size_t(n+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	lens := (*[1 << 28]C.size_t)(C.malloc(C.size_t(n+1) * C.size_t(unsafe.Sizeof(C.size_t(0)))))
+	defer C.free(unsafe.Pointer(ptrs))
+	defer C.free(unsafe.Pointer(lens))
+	for i, d := range docs {
+		if len(d) > 0 {
+			pinner.Pin(&d[0])
+			ptrs[i] = (*C.uint8_t)(unsafe.Pointer(&d[0]))
+		} else {
+			ptrs[i] = nil
+		}
+		lens[i] = C.size_t(len(d))
+	}
+	var tapeLen, stringsLen C.size_t
+	rc := C.sjhip_parse_batch(c.h, (**C.uint8_t)(unsafe.Pointer(ptrs)), (*C.size_t)(unsafe.Pointer(lens)), C.size_t(n),
+		C.SJHIP_FLAG_COPY_STRINGS, &tapeLen, &stringsLen)
+	runtime.KeepAlive(docs)
+	switch rc {
+	case C.SJHIP_OK:
+	case C.SJHIP_ERR_STAGE1:
+		return nil, errors.New("Failed to find all structural indices for stage 1")
+	case C.SJHIP_ERR_STAGE2:
+		return nil, errors.New("Bad parsing while executing stage 2")
+	default:
+		return nil, fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_last_error(c.h)))
+	}
+	pj.Message = pj.Message[:0]
+	if cap(pj.Tape) < int(tapeLen) {
+		pj.Tape = make([]uint64, int(tapeLen))
+	}
+	pj.Tape = pj.Tape[:int(tapeLen)]
+	if pj.Strings == nil {
+		pj.Strings = &TStrings{}
+	}
+	if cap(pj.Strings.B) < int(stringsLen) {
+		pj.Strings.B = make([]byte, int(stringsLen))
+	}
+	pj.Strings.B = pj.Strings.B[:int(stringsLen)]
+	var tp *C.uint64_t
+	var sp *C.uint8_t
+	if tapeLen > 0 {
+		tp = (*C.uint64_t)(unsafe.Pointer(&pj.Tape[0]))
+	}
+	if stringsLen > 0 {
+		sp = (*C.uint8_t)(unsafe.Pointer(&pj.Strings.B[0]))
+	}
+	if rc := C.sjhip_fetch(c.h, tp, sp); rc != C.SJHIP_OK {
+		return nil, fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_last_error(c.h)))
+	}
+	return &pj.ParsedJson, nil
+}
+
 // Parse an object or array from a block of data and return the parsed JSON (simdjson_amd64.go:66).
 func Parse(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, error) {
 	pj, err := newInternalParsedJson(reuse, opts)

@@ -38,6 +38,8 @@ SYMBOLS = {
     "sjhip_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "sjhip_parse_nd_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
     "sjhip_fetch_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sjhip_parse_batch": (C.c_int, [C.c_void_p, C.c_void_p, szp, C.c_size_t, C.c_uint32, szp, szp]),
+    "sjhip_parse_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, szp, szp, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_trim_space": (None, [C.c_void_p, C.c_size_t, szp, szp]),
     "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
     "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,

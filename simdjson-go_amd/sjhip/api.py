@@ -126,6 +126,31 @@ class Context:
         self._check(rc)
         return tl.value, sl.value
 
+    # ---- many documents, one launch set (include/sjhip.h: sjhip_parse_batch) -----------------------------------
+    def parse_batch(self, docs, fetch=True):
+        """Parses the documents of `docs` (bytes-like, host memory) as ONE packed ND message: document i is root i of
+        the returned ParsedJson (Message = b"": every string is copied).  One invalid document fails the batch."""
+        arrs = [np.frombuffer(d, dtype=np.uint8) if not isinstance(d, np.ndarray) else d for d in docs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+        tl, sl = C.c_size_t(0), C.c_size_t(0)
+        self._check(_lib.lib().sjhip_parse_batch(self._h, ptrs, lens, n, FLAG_COPY_STRINGS, C.byref(tl), C.byref(sl)))
+        if not fetch:
+            return tl.value, sl.value
+        tape, strings = self.fetch(tl.value, sl.value)
+        return ParsedJson(b"", tape, strings)
+
+    def parse_batch_device(self, d_buf_ptr, offs, lens):
+        """The same with the documents resident in one device buffer (offs[i], lens[i]); the result stays on the device."""
+        n = len(offs)
+        o = (C.c_size_t * max(n, 1))(*[int(x) for x in offs])
+        ln = (C.c_size_t * max(n, 1))(*[int(x) for x in lens])
+        tl, sl = C.c_size_t(0), C.c_size_t(0)
+        self._check(_lib.lib().sjhip_parse_batch_device(self._h, C.c_void_p(d_buf_ptr), o, ln, n, FLAG_COPY_STRINGS,
+                                                        C.byref(tl), C.byref(sl)))
+        return tl.value, sl.value
+
     # ---- queries on the device-resident result (include/sjhip.h: sjhip_count_where / sjhip_filter_where) --------
     def count_where(self, key, value):
         """countWhere(key, value, pj) of the reference's tests (ndjson_test.go:421-471) on the device: records whose
