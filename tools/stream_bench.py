@@ -59,11 +59,11 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True, copy_threads=
     blocks_sent = 0
     nslots = L.sjhip_stream_slots(h)
     held = {}
-    tape_words = strings = blocks = 0
+    tape_words = strings = blocks = records = 0
     t0 = time.perf_counter()
 
     def take():
-        nonlocal tape_words, strings, blocks
+        nonlocal tape_words, strings, blocks, records
         rc = L.sjhip_stream_next(h, C.byref(res))
         if rc in (7, 8):
             return False
@@ -73,6 +73,7 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True, copy_threads=
             pmemmove(out_s.ctypes.data, res.strings, res.strings_len, copy_threads)
         tape_words += res.tape_len
         strings += res.strings_len
+        records += res.records
         blocks += 1
         L.sjhip_stream_release(h)
         return True
@@ -101,7 +102,7 @@ def run(data, block=10 << 20, slots=0, n_devices=1, copy_out=True, copy_threads=
     if stream is None:
         L.sjhip_stream_destroy(h)
     return {"bytes": n, "blocks": blocks, "seconds": round(dt, 4), "GBps": round(n / dt / 1e9, 2),
-            "tape_words": tape_words, "strings_bytes": strings, "slots": L.sjhip_stream_slots(h) if stream else slots,
+            "tape_words": tape_words, "strings_bytes": strings, "matching_records": records, "slots": L.sjhip_stream_slots(h) if stream else slots,
             "devices": n_devices,
             "copy_out": copy_out, "copy_threads": copy_threads, "fill": fill,
             "output_bytes_per_input_byte": round((tape_words * 8 + strings) / n, 3)}
