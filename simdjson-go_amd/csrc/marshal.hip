@@ -41,12 +41,13 @@ struct MsView {
     u32 tiles;
     const u8 *strings;
     const u8 *msg;
-    long long *tile_last;        // [tiles] sj_tapewalk.h
+    long long *tile_last;        // [tiles] sj_tapewalk.h, or null: the tiles look for their anchor themselves
     unsigned long long *cnt_b;   // [tiles] text bytes of the tile           -> exclusive prefix
     unsigned long long *cnt_s;   // [tiles] string entries of the tile       -> exclusive prefix
     unsigned long long *totals;  // text bytes, string entries, error flag
     const u8 *keyflag;           // [string entries] 1: the string is an object key
-    u32 *slen;                   // [n] escaped length of the string whose tag word is tape[i] (counting pass -> writing pass)
+    u32 *slen;                   // [tiles][1024] escaped length of the tile's k-th string (counting pass -> writing pass)
+    const u8 *strings_end, *msg_end;  // ends of the buffers the strings live in (8-byte loads stop there)
     u8 *text;
 };
 
@@ -69,23 +70,6 @@ __device__ __forceinline__ u32 escaped_size(u8 c) {
     if (c >= 0x20) return 1;
     return (c == '\b' || c == '\f' || c == '\n' || c == '\r' || c == '\t') ? 2u : 6u;
 }
-__device__ u64 escaped_length(const u8 *s, u64 len) {
-    u64 n = 0, k = 0;
-    for (; k + 8 <= len; k += 8) {  // eight bytes at a time while nothing needs an escape
-        u64 w;
-        memcpy(&w, s + k, 8);
-        const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
-        const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;              // byte < 0x20
-        const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);  // '"' '\\'
-        if ((ctl | q) == 0) {
-            n += 8;
-            continue;
-        }
-        for (int j = 0; j < 8; j++) n += escaped_size(s[k + j]);
-    }
-    for (; k < len; k++) n += escaped_size(s[k]);
-    return n;
-}
 __device__ __forceinline__ u8 *write_escaped_byte(u8 *o, u8 c) {
     const char *hex = "0123456789abcdef";
     const u32 sz = escaped_size(c);
@@ -105,26 +89,6 @@ __device__ __forceinline__ u8 *write_escaped_byte(u8 *o, u8 c) {
     }
     return o;
 }
-__device__ u8 *write_escaped(u8 *o, const u8 *s, u64 len) {
-    u64 k = 0;
-    for (; k + 8 <= len; k += 8) {  // eight bytes at a time while nothing needs an escape (the test of escaped_length)
-        u64 w;
-        memcpy(&w, s + k, 8);
-        const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
-        const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;
-        const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);
-        if ((ctl | q) == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = (u8)(w >> (8 * j));  // (the destination has no alignment: byte stores)
-            o += 8;
-        } else {
-            for (int j = 0; j < 8; j++) o = write_escaped_byte(o, (u8)(w >> (8 * j)));
-        }
-    }
-    for (; k < len; k++) o = write_escaped_byte(o, s[k]);
-    return o;
-}
-
 // ---- keys: string token k is a key iff the next token is ':' ------------------------------------------------------
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_ms_keys(KeyView p) {
@@ -152,53 +116,87 @@ __global__ __launch_bounds__(256) void k_ms_keys(KeyView p) {
 // one block: exclusive prefix sums of up to two per-tile counts; totals[0..1]
 __global__ __launch_bounds__(1024) void k_ms_scan(unsigned long long *a, unsigned long long *b, u32 tiles,
                                                   unsigned long long *totals) {
-    __shared__ unsigned long long s_a[1024], s_b[1024];
-    const u32 tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
-    const u32 lo = tid * per < tiles ? tid * per : tiles, hi = lo + per < tiles ? lo + per : tiles;
-    unsigned long long x = 0, y = 0;
-    for (u32 t = lo; t < hi; t++) {
-        x += a[t];
-        if (b) y += b[t];
-    }
-    s_a[tid] = x;
-    s_b[tid] = y;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long ra = 0, rb = 0;
-        for (int k = 0; k < 1024; k++) {
-            const unsigned long long va = s_a[k], vb = s_b[k];
-            s_a[k] = ra;
-            s_b[k] = rb;
-            ra += va;
-            rb += vb;
-        }
-        if (totals) {
-            totals[0] = ra;
-            totals[1] = rb;
-        }
-    }
-    __syncthreads();
-    unsigned long long ra = s_a[tid], rb = s_b[tid];
-    for (u32 t = lo; t < hi; t++) {
-        const unsigned long long va = a[t];
-        a[t] = ra;
-        ra += va;
-        if (b) {
-            const unsigned long long vb = b[t];
-            b[t] = rb;
-            rb += vb;
-        }
+    __shared__ long long s_w[16];
+    const long long ta = block1024_scan_array<false>((long long *)a, tiles, s_w, (int)threadIdx.x);
+    const long long tb = b ? block1024_scan_array<false>((long long *)b, tiles, s_w, (int)threadIdx.x) : 0;
+    if (threadIdx.x == 0 && totals) {
+        totals[0] = (unsigned long long)ta;
+        totals[1] = (unsigned long long)tb;
     }
 }
 
 // ---- the tape pass: EMIT = false lengths, EMIT = true text ---------------------------------------------------------
-static constexpr u32 MS_WINDOW = 40960;  // bytes of text a tile stages in LDS (3 blocks per CU)
+// A tile is 2048 tape words.  The entries of a tile are SORTED BY KIND into LDS queues and each queue is worked on with
+// the lanes packed densely (the first version let every thread walk its own eight words: under divergence a wave ran the
+// float formatter, the integer formatter and the string walk for every one of the eight steps, and waited for its
+// longest string):
+//   1. classify: tag / raw (sj_tapewalk.h), separator, the fixed part of every entry's length -> s_len[word];
+//      strings, integers and floats enter their queues (strings with their ordinal inside the tile)
+//   2. measure, queue by queue: digits of the integers, shortest digits of the floats, escaped length of the strings
+//      (counting pass; the writing pass reads them back: slen[tile][ordinal]) -- strings of MS_LONG bytes and more are
+//      taken by a whole wave, 8 bytes per lane and step
+//   3. one block scan over the per-thread sums: counting pass -> per-tile totals; writing pass -> the offset of every
+//      entry inside the tile's text (s_len turns into offsets), literals and brackets are written right there
+//   4. write, queue by queue, into the tile's LDS window (or straight to memory when the tile's text is larger), then
+//      the block copies the window out with coalesced stores.
+static constexpr u32 MS_WINDOW = 32768;  // bytes of text a tile stages in LDS (48 KB per block with the queues: 3 blocks per CU)
+static constexpr u32 MS_LONG = 64;       // strings from this length on are measured / written by a whole wave
+static constexpr u32 MS_QCAP = TW_TILE / 2;  // a string or a number takes two words
+
+// eight bytes of a string at offset k (k + 8 may run past its end: bytes behind the end read as 'a'), without reading
+// past `lim` (the end of the buffer the string lives in)
+__device__ __forceinline__ u64 str_load8(const u8 *s, u64 k, u64 len, const u8 *lim) {
+    u64 w;
+    if (s + k + 8 <= lim) {
+        memcpy(&w, s + k, 8);
+    } else {
+        w = 0;
+        for (u32 j = 0; j < 8 && s + k + j < lim; j++) w |= (u64)s[k + j] << (8 * j);
+    }
+    const u64 rem = len - k;
+    if (rem < 8) {
+        const u64 keep = (1ull << (8 * rem)) - 1;
+        w = (w & keep) | (0x6161616161616161ull & ~keep);
+    }
+    return w;
+}
+// escaped size of the (up to) eight valid bytes of such a word
+__device__ __forceinline__ u32 esc_size8(u64 w, u32 valid) {
+    const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
+    const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;              // byte < 0x20
+    const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);  // '"' '\\'
+    if ((ctl | q) == 0) return valid;
+    u32 n = 0;
+    for (u32 j = 0; j < valid; j++) n += escaped_size((u8)(w >> (8 * j)));
+    return n;
+}
+__device__ __forceinline__ u8 *write_esc8(u8 *o, u64 w, u32 valid) {
+    const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
+    const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;
+    const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);
+    if ((ctl | q) == 0) {
+        for (u32 j = 0; j < valid; j++) o[j] = (u8)(w >> (8 * j));  // (the destination has no alignment: byte stores)
+        return o + valid;
+    }
+    for (u32 j = 0; j < valid; j++) o = write_escaped_byte(o, (u8)(w >> (8 * j)));
+    return o;
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     __shared__ long long s_l[TW_THREADS / 64];
     __shared__ unsigned long long s_s[TW_THREADS / 64];
-    const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * TW_TILE + (u64)tid * TW_ITEMS;
+    __shared__ u32 s_len[TW_TILE];   // per word: text bytes of the entry that starts there (0: none); writing pass: then its offset
+    // strings: short ones from the front, long ones from the back; idx | ordinal << 11 | sep << 21 | in Strings.B << 22 |
+    // length << 23 (short ones) | offset << 32: a short string needs no second look at the tape
+    __shared__ u64 s_qs[MS_QCAP];
+    __shared__ u32 s_qn[MS_QCAP];    // numbers: integers from the front, floats from the back; idx | sep << 11
+    __shared__ u32 s_cnt[4];         // short strings, long strings, integers, floats
+    __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? MS_WINDOW : 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 tb = (u64)blockIdx.x * TW_TILE;
+    const u64 base = tb + (u64)tid * TW_ITEMS;
+    if (tid < 4) s_cnt[tid] = 0;
     u64 w[TW_ITEMS + 2];  // the thread's words and the two behind them (an entry's second word, the next entry's tag)
 #pragma unroll
     for (int k = 0; k < TW_ITEMS + 2; k++) w[k] = base + k < p.n ? p.tape[base + k] : 0;
@@ -206,121 +204,256 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++)
         if (base + k < p.n && !two_word_tag(w[k])) last = (long long)(base + k);
-    long long anchor = block_excl_max(last, s_l, tid);
-    const long long carry = p.tile_last[blockIdx.x];
+    // the anchor in front of the tile: from the global scan (tile_last), or -- the common case, no extra pass over the
+    // tape -- the closest of the 64 words in front of the tile that is not a two-word tag; a tile that finds none
+    // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
+    __shared__ long long s_carry;
+    if (!p.tile_last && wave == 0) {
+        const bool have = tb >= 1 + (u64)lane;
+        const bool c0 = have && !two_word_tag(p.tape[tb - 1 - (u64)lane]);
+        const u64 b = __ballot(c0);
+        if (lane == 0) s_carry = b ? (long long)(tb - 1 - (u64)ctz64(b)) : (tb > 64 ? -2ll : -1ll);
+    }
+    long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0 and s_carry)
+    long long carry = p.tile_last ? p.tile_last[blockIdx.x] : s_carry;
+    if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
+        if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
+            atomicOr(&p.totals[2], 4ull);
+            if (!EMIT) p.cnt_b[blockIdx.x] = p.cnt_s[blockIdx.x] = 0;
+        }
+        return;
+    }
     anchor = anchor > carry ? anchor : carry;
 
-    u32 len[TW_ITEMS];
-    u8 isent[TW_ITEMS];
-    u64 bytes = 0;
+    // ---- 1. classify
+    u8 isent[TW_ITEMS], sepf[TW_ITEMS];
     u32 nstr = 0;
-    bool bad = false;
+    bool bad = false, toobig = false;
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++) {
         const u64 i = base + k;
-        len[k] = 0;
         isent[k] = 0;
+        sepf[k] = 0;
         if (i >= p.n) continue;
         const bool raw = anchor >= 0 && ((((long long)i - anchor - 1) & 1) != 0);
         if (!two_word_tag(w[k])) anchor = (long long)i;
         if (raw) continue;
         isent[k] = 1;
-        const u32 t = (u32)(w[k] >> 56);
         const bool two = two_word_tag(w[k]);
         // separator behind a completed value: ',' unless the next entry closes something (for a key: ':', same length)
-        const u64 nw = two ? w[k + 2] : w[k + 1];
-        const u32 nt = (u32)(nw >> 56);
+        const u32 nt = (u32)((two ? w[k + 2] : w[k + 1]) >> 56);
         const bool last_entry = i + (two ? 2 : 1) >= p.n;
-        const u32 sep = (!last_entry && nt != '}' && nt != ']' && nt != 'r') ? 1u : 0u;
-        u32 l = 0;
-        if (t == '"') {
-            u32 el;
-            if (EMIT) {
-                el = p.slen[i];  // measured by the counting pass: no second walk over the string
-            } else {
-                el = (u32)escaped_length(entry_string(p, w[k]), w[k + 1]);
-                p.slen[i] = el;
-            }
-            l = 2 + el + sep;
-            nstr++;
-        } else if (t == 'l' || t == 'u' || t == 'd') {
-            u8 tmp[32];
-            u32 nl = t == 'd' ? format_float(w[k + 1], tmp) : (t == 'l' ? format_int(w[k + 1], tmp) : format_uint(w[k + 1], tmp));
-            if (nl == 0) bad = true;  // Inf / NaN: "INF or NaN number found"
-            l = nl + sep;
-        } else if (t == 't' || t == 'n') {
-            l = 4 + sep;
-        } else if (t == 'f') {
-            l = 5 + sep;
-        } else if (t == '{' || t == '[') {
-            l = 1;
-        } else if (t == '}' || t == ']') {
-            l = 1 + sep;
-        } else if (t == 'r') {
-            const bool is_open = (w[k] & TW_PAYLOAD) > i;  // isOpenRoot (:441)
-            l = (!is_open && i + 1 < p.n) ? 1u : 0u;       // '\n' between records
-        } else {
-            bad = true;
-        }
-        len[k] = l;
-        bytes += l;
+        sepf[k] = (!last_entry && nt != '}' && nt != ']' && nt != 'r') ? 1 : 0;
+        if ((u32)(w[k] >> 56) == '"') nstr++;
     }
-    unsigned long long tot = 0;
-    // text bytes of a tile: < 2^44 even for degenerate strings; string entries: <= 2048
-    const unsigned long long packed = (bytes << 16) | nstr;
-    const unsigned long long ex = block_excl_sum(packed, s_s, tid, &tot);
-    if (!EMIT) {
-        if (tid == 0) {
-            p.cnt_b[blockIdx.x] = tot >> 16;
-            p.cnt_s[blockIdx.x] = tot & 0xffffu;
-        }
-        if (bad) atomicOr(&p.totals[2], 1ull);
-        return;
-    }
-    // The text of a tile is one contiguous range.  When it fits the window the threads write it into LDS (byte stores
-    // that cost a fraction of scattered global ones) and the block copies the window out with coalesced 4-byte
-    // stores; a tile with more text (long strings) writes straight to memory.
-    __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? MS_WINDOW : 16];
-    const u64 tile_bytes = tot >> 16;
-    const bool staged = tile_bytes <= MS_WINDOW;  // block-uniform
-    u8 *const gdst = p.text + p.cnt_b[blockIdx.x];
-    u8 *o = (staged ? s_text : gdst) + (ex >> 16);
-    u64 si = p.cnt_s[blockIdx.x] + (ex & 0xffffu);  // ordinal of the thread's first string entry
+    unsigned long long tot_s = 0;
+    u32 ord = (u32)block_excl_sum(nstr, s_s, tid, &tot_s);  // ordinal of the thread's first string inside the tile
+    const u64 slen_base = (u64)blockIdx.x * MS_QCAP;
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++) {
-        if (!isent[k]) continue;
-        const u32 t = (u32)(w[k] >> 56);
-        u8 *const end = o + len[k];
-        bool sep_is_colon = false;
-        if (t == '"') {
-            *o++ = '"';
-            o = write_escaped(o, entry_string(p, w[k]), w[k + 1]);
-            *o++ = '"';
-            sep_is_colon = p.keyflag[si++] != 0;
-        } else if (t == 'l') {
-            o += format_int(w[k + 1], o);
-        } else if (t == 'u') {
-            o += format_uint(w[k + 1], o);
-        } else if (t == 'd') {
-            u8 tmp[32];  // format_float writes up to 32 bytes: not straight into the neighbours' text
-            const u32 nl = format_float(w[k + 1], tmp);
-            for (u32 j = 0; j < nl; j++) o[j] = tmp[j];
-            o += nl;
-        } else if (t == 't') {
-            o[0] = 't'; o[1] = 'r'; o[2] = 'u'; o[3] = 'e';
-            o += 4;
-        } else if (t == 'n') {
-            o[0] = 'n'; o[1] = 'u'; o[2] = 'l'; o[3] = 'l';
-            o += 4;
-        } else if (t == 'f') {
-            o[0] = 'f'; o[1] = 'a'; o[2] = 'l'; o[3] = 's'; o[4] = 'e';
-            o += 5;
-        } else if (t == 'r') {
-            if (len[k]) *o++ = '\n';
-        } else {
-            *o++ = (u8)t;  // { [ } ]
+        const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
+        u32 l = 0;
+        if (isent[k]) {
+            const u32 t = (u32)(w[k] >> 56), sep = sepf[k];
+            if (t == '"') {
+                const bool lng = w[k + 1] >= MS_LONG;
+                const u32 slot = lng ? MS_QCAP - 1 - atomicAdd(&s_cnt[1], 1u) : atomicAdd(&s_cnt[0], 1u);
+                const u64 v = w[k] & TW_PAYLOAD;
+                const u64 inbuf = (v & STRINGBUFBIT) ? 1u : 0u;
+                s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) |
+                             ((inbuf ? (v & (STRINGBUFBIT - 1)) : v) << 32);
+                l = 2 + sep + (EMIT ? p.slen[slen_base + ord] : 0u);
+                ord++;
+            } else if (t == 'l' || t == 'u') {
+                s_qn[atomicAdd(&s_cnt[2], 1u)] = idx | (sep << 11);
+                l = sep;
+            } else if (t == 'd') {
+                s_qn[MS_QCAP - 1 - atomicAdd(&s_cnt[3], 1u)] = idx | (sep << 11);
+                l = sep;
+            } else if (t == 't' || t == 'n') {
+                l = 4 + sep;
+            } else if (t == 'f') {
+                l = 5 + sep;
+            } else if (t == '{' || t == '[') {
+                l = 1;
+            } else if (t == '}' || t == ']') {
+                l = 1 + sep;
+            } else if (t == 'r') {
+                const bool is_open = (w[k] & TW_PAYLOAD) > base + k;  // isOpenRoot (:441)
+                l = (!is_open && base + k + 1 < p.n) ? 1u : 0u;       // '\n' between records
+            } else {
+                bad = true;
+            }
         }
-        if (o < end) *o++ = sep_is_colon ? ':' : ',';
+        s_len[idx] = l;
+    }
+    __syncthreads();
+    const u32 n_short = s_cnt[0], n_long = s_cnt[1], n_int = s_cnt[2], n_flt = s_cnt[3];
+
+    // ---- 2. measure (numbers in both passes: their digits are not kept; strings in the counting pass only)
+    for (u32 j = (u32)tid; j < n_int; j += TW_THREADS) {
+        const u32 idx = s_qn[j] & 0x7ffu;
+        const u64 tw = p.tape[tb + idx], v = p.tape[tb + idx + 1];
+        s_len[idx] += (u32)(tw >> 56) == 'l' ? int_text_len(v) : digit_count(v);
+    }
+    for (u32 j = (u32)tid; j < n_flt; j += TW_THREADS) {
+        const u32 idx = s_qn[MS_QCAP - 1 - j] & 0x7ffu;
+        u8 tmp[32];
+        const u32 nl = format_float(p.tape[tb + idx + 1], tmp);
+        if (nl == 0) bad = true;  // Inf / NaN: "INF or NaN number found"
+        s_len[idx] += nl;
+    }
+    if (!EMIT) {
+        for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
+            const u64 e64 = s_qs[j];
+            const u32 e = (u32)e64, idx = e & 0x7ffu;
+            const u64 len = (e >> 23) & 0x3fu;
+            const bool inbuf = (e >> 22) & 1u;
+            const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+            const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+            u32 el = 0;
+            for (u64 q = 0; q < len; q += 8) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
+            s_len[idx] += el;
+            p.slen[slen_base + ((e >> 11) & 0x3ffu)] = el;
+        }
+        for (u32 j = (u32)wave; j < n_long; j += TW_THREADS / 64) {  // one wave per long string
+            const u64 e64 = s_qs[MS_QCAP - 1 - j];
+            const u32 e = (u32)e64, idx = e & 0x7ffu;
+            const u64 len = p.tape[tb + idx + 1];
+            const bool inbuf = (e >> 22) & 1u;
+            const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+            const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+            u64 el = 0;
+            for (u64 q = (u64)lane * 8; q < len; q += 512) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) el += (u64)__shfl_xor((long long)el, sft, 64);
+            if (el > 0xfffffff0ull) toobig = true;  // (a single string of more than 4 GiB of text)
+            if (lane == 0) {
+                s_len[idx] += (u32)el;
+                p.slen[slen_base + ((e >> 11) & 0x3ffu)] = (u32)el;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. positions
+    u64 bytes = 0;
+#pragma unroll
+    for (int k = 0; k < TW_ITEMS; k++) bytes += s_len[tid * TW_ITEMS + k];
+    unsigned long long tot = 0;
+    const unsigned long long ex = block_excl_sum(bytes, s_s, tid, &tot);
+    if (tot > 0xfffffff0ull) toobig = true;  // entry offsets inside a tile are 32-bit
+    if (!EMIT) {
+        if (tid == 0) {
+            p.cnt_b[blockIdx.x] = tot;
+            p.cnt_s[blockIdx.x] = tot_s;
+        }
+        if (bad) atomicOr(&p.totals[2], 1ull);
+        if (toobig) atomicOr(&p.totals[2], 2ull);
+        return;
+    }
+    // The text of a tile is one contiguous range.  When it fits the window the block writes it into LDS (byte stores
+    // that cost a fraction of scattered global ones) and copies the window out with coalesced 4-byte stores; a tile
+    // with more text (long strings) writes straight to memory.
+    const u64 tile_bytes = tot;
+    const bool staged = tile_bytes <= MS_WINDOW;  // block-uniform
+    u8 *const gdst = p.text + p.cnt_b[blockIdx.x];
+    u8 *const tbase = staged ? s_text : gdst;
+    {
+        u32 run = (u32)ex;
+#pragma unroll
+        for (int k = 0; k < TW_ITEMS; k++) {
+            const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
+            const u32 l = s_len[idx];
+            s_len[idx] = run;
+            if (isent[k]) {  // literals, brackets and record separators are written here
+                const u32 t = (u32)(w[k] >> 56);
+                u8 *o = tbase + run;
+                if (t == 't') {
+                    o[0] = 't'; o[1] = 'r'; o[2] = 'u'; o[3] = 'e';
+                    if (sepf[k]) o[4] = ',';
+                } else if (t == 'n') {
+                    o[0] = 'n'; o[1] = 'u'; o[2] = 'l'; o[3] = 'l';
+                    if (sepf[k]) o[4] = ',';
+                } else if (t == 'f') {
+                    o[0] = 'f'; o[1] = 'a'; o[2] = 'l'; o[3] = 's'; o[4] = 'e';
+                    if (sepf[k]) o[5] = ',';
+                } else if (t == '{' || t == '[') {
+                    o[0] = (u8)t;
+                } else if (t == '}' || t == ']') {
+                    o[0] = (u8)t;
+                    if (sepf[k]) o[1] = ',';
+                } else if (t == 'r') {
+                    if (l) o[0] = '\n';
+                }
+            }
+            run += l;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. write, queue by queue
+    for (u32 j = (u32)tid; j < n_int; j += TW_THREADS) {
+        const u32 e = s_qn[j], idx = e & 0x7ffu;
+        const u64 tw = p.tape[tb + idx], v = p.tape[tb + idx + 1];
+        u8 *o = tbase + s_len[idx];
+        o += (u32)(tw >> 56) == 'l' ? format_int(v, o) : format_uint(v, o);
+        if ((e >> 11) & 1u) *o = ',';
+    }
+    for (u32 j = (u32)tid; j < n_flt; j += TW_THREADS) {
+        const u32 e = s_qn[MS_QCAP - 1 - j], idx = e & 0x7ffu;
+        u8 tmp[32];  // format_float writes up to 32 bytes: not straight into the neighbours' text
+        const u32 nl = format_float(p.tape[tb + idx + 1], tmp);
+        u8 *o = tbase + s_len[idx];
+        for (u32 q = 0; q < nl; q++) o[q] = tmp[q];
+        if ((e >> 11) & 1u) o[nl] = ',';
+    }
+    const u64 key_base = p.cnt_s[blockIdx.x];
+    for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
+        const u64 e64 = s_qs[j];
+        const u32 e = (u32)e64, idx = e & 0x7ffu;
+        const u64 len = (e >> 23) & 0x3fu;
+        const bool inbuf = (e >> 22) & 1u;
+        const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+        const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+        u8 *o = tbase + s_len[idx];
+        *o++ = '"';
+        for (u64 q = 0; q < len; q += 8) o = write_esc8(o, str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
+        *o++ = '"';
+        if ((e >> 21) & 1u) *o = p.keyflag[key_base + ((e >> 11) & 0x3ffu)] ? ':' : ',';
+    }
+    for (u32 j = (u32)wave; j < n_long; j += TW_THREADS / 64) {  // one wave per long string: 512 bytes per step
+        const u64 e64 = s_qs[MS_QCAP - 1 - j];
+        const u32 e = (u32)e64, idx = e & 0x7ffu;
+        const u64 len = p.tape[tb + idx + 1];
+        const bool inbuf = (e >> 22) & 1u;
+        const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+        const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+        u8 *o = tbase + s_len[idx];
+        if (lane == 0) *o = '"';
+        o++;
+        for (u64 c0 = 0; c0 < len; c0 += 512) {
+            const u64 q = c0 + (u64)lane * 8;
+            u64 x = 0;
+            u32 valid = 0, sz = 0;
+            if (q < len) {
+                valid = (u32)(len - q < 8 ? len - q : 8);
+                x = str_load8(sp, q, len, lim);
+                sz = esc_size8(x, valid);
+            }
+            u32 incl = sz;
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const u32 up = (u32)__shfl_up((int)incl, sft, 64);
+                if (lane >= sft) incl += up;
+            }
+            if (valid) write_esc8(o + (incl - sz), x, valid);
+            o += (u32)__shfl((int)incl, 63, 64);
+        }
+        if (lane == 0) {
+            *o++ = '"';
+            if ((e >> 21) & 1u) *o = p.keyflag[key_base + ((e >> 11) & 0x3ffu)] ? ':' : ',';
+        }
     }
     if (staged) {
         __syncthreads();
@@ -352,13 +485,15 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     p.tiles = (u32)((p.n + TW_TILE - 1) / TW_TILE);
     p.strings = (const u8 *)ctx->d_strings.p;
     p.msg = (const u8 *)ctx->p_msg;
+    p.strings_end = p.strings + ctx->strings_len;
+    p.msg_end = p.msg ? p.msg + ctx->p_len : nullptr;
     KeyView kv;
     kv.kind = ctx->p_kind;
     kv.n = (u32)ctx->p_n;
     kv.tiles = (kv.n + 4095u) / 4096u;
     const size_t per = ((size_t)p.tiles * 8 + 255) / 256 * 256, perk = ((size_t)kv.tiles * 8 + 255) / 256 * 256;
     const size_t flags = ((size_t)kv.n + 255) / 256 * 256;
-    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 3 + perk + flags + (size_t)p.n * 4 + 256);
+    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 3 + perk + flags + (size_t)p.tiles * MS_QCAP * 4 + 256);
     if (rc) return rc;
     char *w = (char *)ctx->d_q.p;
     p.totals = (unsigned long long *)w;
@@ -382,18 +517,32 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, kv.cnt, (unsigned long long *)nullptr, kv.tiles,
                        (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
-    // tag / raw classification, lengths, positions
-    hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
-    hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
-    hipLaunchKernelGGL(k_ms_tile<false>, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.cnt_s, p.tiles, p.totals);
-    HIPCHK(hipGetLastError(), "marshal launch");
+    // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
+    long long *const tile_last = p.tile_last;
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
-    HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
-    if (h[2]) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (attempt == 0) {
+            p.tile_last = nullptr;
+        } else {
+            p.tile_last = tile_last;
+            HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
+            hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
+            hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
+        }
+        hipLaunchKernelGGL(k_ms_tile<false>, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.cnt_s, p.tiles, p.totals);
+        HIPCHK(hipGetLastError(), "marshal launch");
+        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
+        if (!(h[2] & 4ull)) break;
+    }
+    if (h[2] & 1ull) {
         ctx_set_error(ctx, "INF or NaN number found");  // the reference's error (parsed_json.go:1252)
         return SJHIP_ERR_ARG;
+    }
+    if (h[2] & 2ull) {
+        ctx_set_error(ctx, "MarshalJSON: 2048 consecutive tape words produce more than 4 GiB of text");
+        return SJHIP_ERR_TOOBIG;
     }
     rc = arena_reserve(ctx, ctx->d_qtape, (size_t)h[0] + 64);
     if (rc) return rc;

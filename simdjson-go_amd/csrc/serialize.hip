@@ -84,44 +84,14 @@ __device__ __forceinline__ bool ser_equal(const u8 *a, const u8 *b, u64 len) {
 // one block: exclusive prefix sums of the per-tile counts + totals (a: entries, b: value bytes, c: kept string bytes)
 __global__ __launch_bounds__(1024) void k_ser_scan_cnt(unsigned long long *cnt_a, unsigned long long *cnt_b,
                                                        unsigned long long *cnt_c, u32 tiles, unsigned long long *totals) {
-    __shared__ unsigned long long s_a[1024], s_b[1024], s_c[1024];
-    const u32 tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
-    const u32 lo = tid * per < tiles ? tid * per : tiles, hi = lo + per < tiles ? lo + per : tiles;
-    unsigned long long a = 0, b = 0, c = 0;
-    for (u32 t = lo; t < hi; t++) {
-        a += cnt_a[t];
-        b += cnt_b[t];
-        if (cnt_c) c += cnt_c[t];
-    }
-    s_a[tid] = a;
-    s_b[tid] = b;
-    s_c[tid] = c;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long ra = 0, rb = 0, rc = 0;
-        for (int k = 0; k < 1024; k++) {
-            const unsigned long long va = s_a[k], vb = s_b[k], vc = s_c[k];
-            s_a[k] = ra;
-            s_b[k] = rb;
-            s_c[k] = rc;
-            ra += va;
-            rb += vb;
-            rc += vc;
-        }
-        totals[0] = ra;
-        totals[1] = rb;
-        totals[2] = rc;
-    }
-    __syncthreads();
-    unsigned long long ra = s_a[tid], rb = s_b[tid], rc = s_c[tid];
-    for (u32 t = lo; t < hi; t++) {
-        const unsigned long long va = cnt_a[t], vb = cnt_b[t], vc = cnt_c ? cnt_c[t] : 0;
-        cnt_a[t] = ra;
-        cnt_b[t] = rb;
-        if (cnt_c) cnt_c[t] = rc;
-        ra += va;
-        rb += vb;
-        rc += vc;
+    __shared__ long long s_w[16];
+    const long long ta = block1024_scan_array<false>((long long *)cnt_a, tiles, s_w, (int)threadIdx.x);
+    const long long tb = block1024_scan_array<false>((long long *)cnt_b, tiles, s_w, (int)threadIdx.x);
+    const long long tc = cnt_c ? block1024_scan_array<false>((long long *)cnt_c, tiles, s_w, (int)threadIdx.x) : 0;
+    if (threadIdx.x == 0) {
+        totals[0] = (unsigned long long)ta;
+        totals[1] = (unsigned long long)tb;
+        totals[2] = (unsigned long long)tc;
     }
 }
 

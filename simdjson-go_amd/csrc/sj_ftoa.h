@@ -191,21 +191,36 @@ SJ_HD u32 format_float(u64 bits, u8 *out) {
     return n;
 }
 
-// strconv.AppendUint / AppendInt, base 10: `out` needs 20 bytes
+// strconv.AppendUint / AppendInt, base 10: exactly the digits are written (`out` needs up to 20 bytes)
+SJ_HD u32 digit_count(u64 v) {
+    u32 n = 1;
+    for (u64 p = 10; n < 20 && v >= p; p *= 10) n++;  // (10^19 still fits; n = 20 ends the loop before p overflows)
+    return n;
+}
 SJ_HD u32 format_uint(u64 v, u8 *out) {
-    u8 tmp[20];
-    int n = 0;
+    const u32 n = digit_count(v);
+    u8 *e = out + n;
+    while (v >= 1000000000ull) {  // nine digits at a time in 32-bit arithmetic
+        const u64 q = v / 1000000000ull;
+        u32 r = (u32)(v - q * 1000000000ull);
+        for (int k = 0; k < 9; k++) {
+            *--e = (u8)('0' + r % 10u);
+            r /= 10u;
+        }
+        v = q;
+    }
+    u32 r = (u32)v;
     do {
-        tmp[n++] = (u8)('0' + v % 10);
-        v /= 10;
-    } while (v != 0);
-    for (int k = 0; k < n; k++) out[k] = tmp[n - 1 - k];
-    return (u32)n;
+        *--e = (u8)('0' + r % 10u);
+        r /= 10u;
+    } while (r != 0);
+    return n;
 }
 SJ_HD u32 format_int(u64 raw, u8 *out) {  // raw: the two's complement tape word
     if ((raw >> 63) == 0) return format_uint(raw, out);
     out[0] = '-';
     return 1 + format_uint(0 - raw, out + 1);
 }
+SJ_HD u32 int_text_len(u64 raw) { return (raw >> 63) ? 1u + digit_count(0 - raw) : digit_count(raw); }
 
 }  // namespace sj

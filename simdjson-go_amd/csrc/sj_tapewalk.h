@@ -64,6 +64,48 @@ __device__ __forceinline__ unsigned long long block_excl_sum(unsigned long long 
     return before + incl - v;
 }
 
+// In-place exclusive scan of a[0 .. n) by ONE 1024-thread block (the per-tile values of a walk: tens of thousands of
+// elements).  Every wave owns a contiguous range and walks it 64 consecutive elements at a time (coalesced loads, a
+// shuffle scan per step): pass 1 reduces the range, the 16 range totals meet in LDS, pass 2 scans and writes.
+// MAX: running maximum (identity -1), else sum.  (The first version gave every THREAD a contiguous range: 64 different
+// cache lines per load instruction, 180 us for 39 000 tiles.)
+template <bool MAX>
+__device__ __forceinline__ long long block1024_scan_array(long long *a, u32 n, long long *s_w /* [16] */, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const long long id = MAX ? -1ll : 0ll;
+    auto op = [](long long x, long long y) { return MAX ? (x > y ? x : y) : x + y; };
+    const u32 per = ((n + 15u) / 16u + 63u) / 64u * 64u;
+    const u32 lo = (u32)wave * per < n ? (u32)wave * per : n, hi = lo + per < n ? lo + per : n;
+    long long acc = id;
+    for (u32 i = lo + (u32)lane; i < hi; i += 64) acc = op(acc, a[i]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc = op(acc, __shfl_xor(acc, s, 64));
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    long long carry = id, total = id;
+    for (int w = 0; w < 16; w++) {
+        const long long x = s_w[w];
+        if (w < wave) carry = op(carry, x);
+        total = op(total, x);
+    }
+    for (u32 c = lo; c < hi; c += 64) {
+        const u32 i = c + (u32)lane;
+        const long long v = i < hi ? a[i] : id;
+        long long incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const long long o = __shfl_up(incl, s, 64);
+            if (lane >= s) incl = op(o, incl);
+        }
+        long long ex = __shfl_up(incl, 1, 64);
+        if (lane == 0) ex = id;
+        if (i < hi) a[i] = op(carry, ex);
+        carry = op(carry, __shfl(incl, 63, 64));
+    }
+    __syncthreads();  // (s_w may be used again)
+    return total;
+}
+
 __global__ __launch_bounds__(TW_THREADS) void k_tw_last(const u64 *tape, u64 n, long long *tile_last) {
     __shared__ long long s_w[TW_THREADS / 64];
     const int tid = threadIdx.x;
@@ -90,28 +132,8 @@ __global__ __launch_bounds__(TW_THREADS) void k_tw_last(const u64 *tape, u64 n, 
 
 // one block: tile_last[t] := the last anchor in front of tile t (exclusive running maximum)
 __global__ __launch_bounds__(1024) void k_tw_scan_last(long long *tile_last, u32 tiles) {
-    __shared__ long long s_m[1024];
-    const u32 tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
-    const u32 lo = tid * per < tiles ? tid * per : tiles, hi = lo + per < tiles ? lo + per : tiles;
-    long long m = -1;
-    for (u32 t = lo; t < hi; t++) m = tile_last[t] > m ? tile_last[t] : m;
-    s_m[tid] = m;
-    __syncthreads();
-    if (tid == 0) {
-        long long run = -1;
-        for (int k = 0; k < 1024; k++) {
-            const long long v = s_m[k];
-            s_m[k] = run;
-            run = v > run ? v : run;
-        }
-    }
-    __syncthreads();
-    long long run = s_m[tid];
-    for (u32 t = lo; t < hi; t++) {
-        const long long v = tile_last[t];
-        tile_last[t] = run;
-        run = v > run ? v : run;
-    }
+    __shared__ long long s_w[16];
+    block1024_scan_array<true>(tile_last, tiles, s_w, (int)threadIdx.x);
 }
 
 }  // namespace

@@ -68,6 +68,28 @@ def test_numbers_strings_and_shapes(ctx):
     check_marshal(ctx, (nd + "\n\n").encode(), True, "nd-trailing-newlines")
 
 
+def test_raw_words_that_look_like_tags(ctx):
+    """Long runs of numbers whose VALUE word has a top byte equal to a tag (0x6c 'l', 0x75 'u', 0x64 'd', 0x22 '"'): a
+    tile of the walk then finds no anchor among the 64 words in front of it and the library repeats the walk with the
+    global anchor scan (marshal.hip); long strings (whole-wave copies), strings around the 64-byte threshold, escapes at
+    8-byte boundaries."""
+    looks = []
+    for top in (0x6c, 0x75, 0x64, 0x22):
+        x = struct.unpack("<d", struct.pack("<Q", (top << 56) | 0x0123456789abcd))[0]
+        looks.append(repr(x))
+    doc = "[" + ",".join(looks[i % 4] for i in range(9000)) + ',"tail",{"k":[1,2]}]'
+    check_marshal(ctx, doc.encode(), False, "tag-like raw words")
+    nd = "\n".join("[" + ",".join(looks[(i + j) % 4] for j in range(700)) + "]" for i in range(12))
+    check_marshal(ctx, nd.encode(), True, "tag-like raw words, nd")
+    strs = []
+    for n in list(range(56, 76)) + [127, 128, 129, 511, 512, 513, 1023, 4097, 40000, 70001]:
+        body = "".join(("\\n" if (i % 61) == 7 else '\\"' if (i % 97) == 11 else "\\u0001" if (i % 389) == 5 else chr(97 + i % 26))
+                       for i in range(n))
+        strs.append('"' + body + '"')
+    check_marshal(ctx, ("[" + ",".join(strs) + "]").encode(), False, "long strings")
+    check_marshal(ctx, ("{" + ",".join(s + ":" + s for s in strs) + "}").encode(), False, "long keys")
+
+
 def test_random_documents(ctx):
     from test_gpu_parse import _random_records
     rnd, lines = _random_records(321, 2 << 20)
