@@ -208,14 +208,8 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     // tape -- the closest of the 64 words in front of the tile that is not a two-word tag; a tile that finds none
     // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
     __shared__ long long s_carry;
-    if (!p.tile_last && wave == 0) {
-        const bool have = tb >= 1 + (u64)lane;
-        const bool c0 = have && !two_word_tag(p.tape[tb - 1 - (u64)lane]);
-        const u64 b = __ballot(c0);
-        if (lane == 0) s_carry = b ? (long long)(tb - 1 - (u64)ctz64(b)) : (tb > 64 ? -2ll : -1ll);
-    }
-    long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0 and s_carry)
-    long long carry = p.tile_last ? p.tile_last[blockIdx.x] : s_carry;
+    const long long carry = p.tile_last ? p.tile_last[blockIdx.x] : tw_local_anchor(p.tape, tb, tid, &s_carry);
+    long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0)
     if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
         if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
             atomicOr(&p.totals[2], 4ull);

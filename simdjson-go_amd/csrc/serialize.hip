@@ -114,7 +114,18 @@ __global__ __launch_bounds__(ST_THREADS) void k_ser_tile(SerView p) {
     for (int k = 0; k < ST_ITEMS; k++)
         if (base + k < p.n && !two_word_tag(w[k])) last = (long long)(base + k);
     long long anchor = block_excl_max(last, s_l, tid);  // last anchor in front of this thread's words, inside the tile
-    const long long carry = p.tile_last[blockIdx.x];
+    __shared__ long long s_carry;
+    const long long carry = p.tile_last ? p.tile_last[blockIdx.x] : tw_local_anchor(p.tape, (u64)blockIdx.x * ST_TILE, tid, &s_carry);
+    if (carry == -2) {  // (block-uniform, sj_tapewalk.h) nothing of this tile can be classified: report and leave
+        if (tid == 0) {
+            atomicOr(&p.totals[3], 1ull);
+            if (MODE == 1) {
+                p.cnt_t[blockIdx.x] = p.cnt_v[blockIdx.x] = 0;
+                if (p.table) p.cnt_s[blockIdx.x] = 0;
+            }
+        }
+        return;
+    }
     anchor = anchor > carry ? anchor : carry;
     // entries of this thread: tag byte and value bytes
     u8 tg[ST_ITEMS];
@@ -288,17 +299,28 @@ int sjhip_serialize_ex(sjhip_ctx *ctx, uint32_t flags, size_t *tags_len, size_t 
         p.scol = (u8 *)ctx->d_scol.p;
         HIPCHK(hipMemsetAsync(p.table, 0xff, (size_t)SER_SLOTS * 4, ctx->stream), "table reset");
     }
-    hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
-    hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
-    if (dedup) hipLaunchKernelGGL(k_ser_tile<0>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_ser_tile<1>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_ser_scan_cnt, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_t, p.cnt_v, dedup ? p.cnt_s : nullptr, p.tiles, p.totals);
-    if (dedup) hipLaunchKernelGGL(k_ser_tile<2>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_ser_tile<3>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
-    HIPCHK(hipGetLastError(), "serialize launch");
+    // The tiles find the anchor of the tag / raw classification among the 64 words in front of them; a tile that cannot
+    // (sj_tapewalk.h) raises totals[3] and the walk is repeated with the anchors of the global pass.
+    long long *const tile_last = p.tile_last;
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
-    HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "serialize sync");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        p.tile_last = attempt == 0 ? nullptr : tile_last;
+        HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "serialize memset");
+        if (attempt == 1) {
+            hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
+            hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
+            if (dedup) HIPCHK(hipMemsetAsync(p.table, 0xff, (size_t)SER_SLOTS * 4, ctx->stream), "table reset");
+        }
+        if (dedup) hipLaunchKernelGGL(k_ser_tile<0>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_ser_tile<1>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_ser_scan_cnt, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_t, p.cnt_v, dedup ? p.cnt_s : nullptr, p.tiles, p.totals);
+        if (dedup) hipLaunchKernelGGL(k_ser_tile<2>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_ser_tile<3>, dim3(p.tiles), dim3(ST_THREADS), 0, ctx->stream, p);
+        HIPCHK(hipGetLastError(), "serialize launch");
+        HIPCHK(hipMemcpyAsync(h, p.totals, 32, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "serialize sync");
+        if (h[3] == 0) break;
+    }
     ctx->ser_tags = (size_t)h[0];
     ctx->ser_vals = (size_t)h[1];
     ctx->ser_dedup = dedup;

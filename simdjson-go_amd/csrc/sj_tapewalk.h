@@ -64,6 +64,22 @@ __device__ __forceinline__ unsigned long long block_excl_sum(unsigned long long 
     return before + incl - v;
 }
 
+// The anchor in front of the tile that starts at word tb, without the global pass (k_tw_last / k_tw_scan_last): the
+// closest of the 64 words in front of the tile that is not a two-word tag.  -1: the tile is the first one; -2: none
+// among the 64 (they are raw words that all look like string / number tags) -- the tile must then not classify
+// anything (with a wrong anchor raw words would be read as tags and their neighbours as string offsets and lengths):
+// it reports through a flag and the host repeats the walk with the global anchors.  Block-uniform result.
+__device__ __forceinline__ long long tw_local_anchor(const u64 *tape, u64 tb, int tid, long long *s_carry) {
+    if (tid < 64) {
+        const bool have = tb >= 1 + (u64)tid;
+        const bool c0 = have && !two_word_tag(tape[tb - 1 - (u64)tid]);
+        const u64 b = __ballot(c0);
+        if (tid == 0) *s_carry = b ? (long long)(tb - 1 - (u64)ctz64(b)) : (tb > 64 ? -2ll : -1ll);
+    }
+    __syncthreads();
+    return *s_carry;
+}
+
 // In-place exclusive scan of a[0 .. n) by ONE 1024-thread block (the per-tile values of a walk: tens of thousands of
 // elements).  Every wave owns a contiguous range and walks it 64 consecutive elements at a time (coalesced loads, a
 // shuffle scan per step): pass 1 reduces the range, the 16 range totals meet in LDS, pass 2 scans and writes.
