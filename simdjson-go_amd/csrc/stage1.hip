@@ -53,11 +53,14 @@ struct S1Aux {
 __device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len) {
     if (!aux.host) return;
     // every update of *st is an agent-scope atomic (performed at the memory side, like the tile descriptors): once
-    // this wave's are acknowledged and the block has met, one relaxed counter tells which block is the last
+    // this wave's are acknowledged and the block has met, one counter tells which block is the last.  The counter is
+    // an acquire-release operation at agent scope -- one per block, not a hot path -- so that the last block's loads
+    // of *st are ordered behind every other block's updates by the memory model, not only by how gfx950 executes
+    // sc1 atomics.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (d == gridDim.x - 1) {
             // the whole result in ONE 8-byte store (several stores would need a system-scope release, i.e. an L2
             // write-back, to be ordered among themselves): S1_HOST_* in sj_device.h
