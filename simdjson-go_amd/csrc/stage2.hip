@@ -873,10 +873,31 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
         nstr += (MASKS && is_str[k]) ? 1u : 0u;
         natom += is_atom[k] ? 1u : 0u;
     }
+    // queue slots: the counts of a wave are summed with a DPP scan and one lane draws the wave's ranges (an LDS atomic
+    // that all 64 lanes aim at the same counter is executed a lane at a time)
     u32 sslot = 0, dslot = 0;
-    if (nnum) atomicAdd(&s_cnt, nnum);
-    if (nstr) sslot = atomicAdd(&s_scnt, nstr);
-    if (natom + nnum) dslot = atomicAdd(&s_dcnt, natom + nnum);
+    {
+        const u32 pk = nstr | ((natom + nnum) << 10) | (nnum << 20);  // <= 512 each per wave
+        u32 incl = pk;
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+        const u32 wtot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u32 sb = 0, db = 0;
+        if (lane == 63) {
+            if (wtot & 0x3ffu) sb = atomicAdd(&s_scnt, wtot & 0x3ffu);
+            if ((wtot >> 10) & 0x3ffu) db = atomicAdd(&s_dcnt, (wtot >> 10) & 0x3ffu);
+            if (wtot >> 20) atomicAdd(&s_cnt, wtot >> 20);
+        }
+        sb = (u32)__builtin_amdgcn_readlane((int)sb, 63);
+        db = (u32)__builtin_amdgcn_readlane((int)db, 63);
+        const u32 ex = incl - pk;
+        sslot = sb + (ex & 0x3ffu);
+        dslot = db + ((ex >> 10) & 0x3ffu);
+    }
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/${1:-r3c}
 mkdir -p $OUT
 cd $REPO
 timeout 200 python tools/parse_time.py 2>&1 | tee $OUT/parse_time.txt
-timeout 600 python -m pytest tests -m gpu -q --maxfail=8 2>&1 | tail -30 > $OUT/tests.txt
+timeout 300 python -m pytest tests/test_gpu_parse.py tests/test_gpu_quirks.py tests/test_gpu_fuzz.py -m gpu -q --maxfail=8 2>&1 | tail -30 > $OUT/tests.txt
 tail -12 $OUT/tests.txt
 cd /tmp && export TMPDIR=/tmp
 for w in twitter parking; do
