@@ -622,8 +622,9 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
     for (int k = 0; k < RD_ITEMS; k++) {
         const int off = 2 + k;  // byte offset of ppk in the stream
         const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-        const PAgg e = base + k < n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
-        acc = pagg_comb<true>(acc, e);
+        const PAgg te = token_pelement(s_elut, win, copied[k]);  // (no branch around the look-up, see k_s2_emit)
+        const u32 live = base + k < n ? ~0u : 0u;
+        acc = pagg_comb<true>(acc, PAgg{te.x & live, te.y & live, (te.z & live) | (AM_ALL & ~live), te.s & live});
     }
     const PAgg incl = pagg_wave_inclusive<true>(acc);
     if (lane == 63) s_w[wave] = incl;
@@ -852,7 +853,11 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
         for (int k = 0; k < S2_ITEMS; k++) {
             const int off = 2 + k;  // byte offset of ppk in the stream
             const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-            e[k] = base + k < n ? token_pelement(s_elut, win, copied[k]) : pagg_identity();
+            // (no branch around the table look-up: eight dependent LDS round trips otherwise; tokens behind the end
+            // carry sentinel kinds, their element is masked to the identity)
+            const PAgg te = token_pelement(s_elut, win, copied[k]);
+            const u32 live = base + k < n ? ~0u : 0u;
+            e[k] = PAgg{te.x & live, te.y & live, (te.z & live) | (AM_ALL & ~live), te.s & live};
         }
     }
     PAgg mine = e[0];
