@@ -1138,15 +1138,38 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
     const u32 waves = gridDim.x * 4;
     const bool store = p.st->tape_len <= p.tape_cap;  // (cannot fail: the launcher sizes the tape for 2n+2 words)
     bool bad = false;
-    for (u32 g = blockIdx.x * 4 + (threadIdx.x >> 6); (u64)g * 64 < n_br; g += waves) {  // wave-uniform
+    // everything that does not depend on an answer is requested together -- the group's depths, kinds and tape offsets,
+    // and the depths of the group in front (where most questions that leave the group end) -- and one group ahead:
+    // the kernel is bound by the latency of its dependent loads (3 M VALU instructions in 160 k cycles), a wave works
+    // on group g while the loads of group g + waves are in flight
+    struct Group {
+        i32 dep, pd;
+        u32 oc;
+        u8 info;
+    };
+    auto load_group = [&](u32 g) {
+        Group r{0x7fffffff, 0x7fffffff, 0u, (u8)K_BAD};
+        const u32 c = g * 64 + (u32)lane;
+        if ((u64)g * 64 < n_br) {
+            if (c < n_br) {
+                r.dep = p.br_depth[c];
+                r.info = p.br_info[c];
+                r.oc = p.br_off[c];
+            }
+            if (g > 0) r.pd = p.br_depth[(u64)(g - 1) * 64 + lane];
+        }
+        return r;
+    };
+    u32 g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    Group nx = load_group(g);
+    for (; (u64)g * 64 < n_br; g += waves) {  // wave-uniform
         const u32 c = g * 64 + (u32)lane;
         const bool valid = c < n_br;
-        // everything that does not depend on the answer is requested together: the group's depths, kinds and tape
-        // offsets, and the depths of the group in front (where most questions that leave the group end)
-        const i32 dep = valid ? p.br_depth[c] : 0x7fffffff;
-        const u8 info = valid ? p.br_info[c] : (u8)K_BAD;
-        const u32 oc = valid ? p.br_off[c] : 0u;
-        const i32 pd = g > 0 ? p.br_depth[(u64)(g - 1) * 64 + lane] : 0x7fffffff;
+        const Group cur = nx;
+        nx = load_group(g + waves);
+        const i32 dep = cur.dep, pd = cur.pd;
+        const u8 info = cur.info;
+        const u32 oc = cur.oc;
         const u8 kd = info & 15u;
         const bool close = is_close(kd);
         const i32 q = close ? dep : dep - 2;  // depth in front of the bracket - 1
@@ -1411,7 +1434,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     }
     if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
-    hipLaunchKernelGGL(k_br_match, dim3(gb < 4096 ? gb : 4096), dim3(256), 0, a.stream, p);
+    hipLaunchKernelGGL(k_br_match, dim3(gb < 2048 ? gb : 2048), dim3(256), 0, a.stream, p);  // (8 waves per SIMD resident)
     if (beside) {
         const hipError_t e = hipStreamWaitEvent(a.stream, a.ev_join, 0);
         if (e != hipSuccess) return e;
