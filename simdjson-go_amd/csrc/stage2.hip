@@ -990,17 +990,22 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
         const u64 n2 = (mt.size[1] + 63) / 64;  // level-2 entries (also when the tree has no level 2: one pass)
         for (u64 b = blockIdx.x - nblocks; b < n2; b += gridDim.x - nblocks) {
             i32 wmin = 0x7fffffff;
+            i32 dv[16];  // the sixteen groups of the wave: all loads first (one round trip instead of sixteen)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u64 k = (b * 64 + (u64)wave * 16 + i) * 64 + lane;
+                dv[i] = k < mt.size[0] ? p.br_depth[k] : 0x7fffffff;
+            }
+#pragma unroll
             for (int i = 0; i < 16; i++) {
                 const u64 g = b * 64 + (u64)wave * 16 + i;  // (wave-uniform)
-                if (g >= mt.size[1]) break;
-                const u64 k = g * 64 + lane;
-                i32 v = k < mt.size[0] ? p.br_depth[k] : 0x7fffffff;
+                i32 v = dv[i];
 #pragma unroll
                 for (int sft = 32; sft >= 1; sft >>= 1) {
                     const i32 o = __shfl_xor(v, sft, 64);
                     v = o < v ? o : v;
                 }
-                if (lane == 0) p.lev[1][g] = v;
+                if (lane == 0 && g < mt.size[1]) p.lev[1][g] = v;
                 wmin = v < wmin ? v : wmin;
             }
             if (mt.nlev > 2) {  // (block-uniform)
