@@ -145,3 +145,25 @@ def test_batch_of_256_twitter():
     n = len(one.tape)
     tags = (tape >> np.uint64(56)).reshape(256, n)
     assert (tags == (one.tape >> np.uint64(56))[None, :]).all()
+
+
+def test_batch_of_many_tiny_documents():
+    """More documents than one grid dimension holds (65 535): the packing kernels walk (y, z) block indices."""
+    import sjhip
+    ctx = sjhip.Context(0)
+    n = 70001
+    docs = [b'{"i":%d,"s":"v%d"}' % (k, k % 97) for k in range(n)]
+    ref = O.parse(_packed(docs), ndjson=True, copy_strings=True)
+    assert ref.rc == 0
+    pj = ctx.parse_batch(docs)
+    assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
+    # the same from one device buffer
+    import torch
+    blob = b"".join(docs)
+    offs = np.concatenate(([0], np.cumsum([len(d) for d in docs])[:-1]))
+    dev = torch.empty(len(blob) + 64, dtype=torch.uint8, device="cuda:0")
+    dev[: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    tl, sl = ctx.parse_batch_device(dev.data_ptr(), offs.tolist(), [len(d) for d in docs])
+    tape, strings = ctx.fetch(tl, sl)
+    assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings)
