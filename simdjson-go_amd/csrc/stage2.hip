@@ -103,7 +103,37 @@ struct S2Dev {
 __device__ __forceinline__ u32 token_count(const S2Dev &p) { return p.n_dev ? (u32)*p.n_dev : p.n; }
 
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
-__device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nblocks) {
+// The general string routine of a unit, escape by escape instead of chunk by chunk.  sj_strings.h str_chunk_masks is the
+// per-chunk statement (and what the host replay runs): a lane walks the escaped characters of its chunk one after the
+// other, ~250 instructions and a handful of dependent loads each -- twitterescaped.json holds up to thirteen \u escapes
+// per chunk, so a wave spent 57 us on one unit with most of its time in a single lane's serial chain.  Here the escaped
+// characters of the unit's general chunks are listed in LDS and the lanes take them round robin: every escape is
+// evaluated once, by any lane.  What an escape changes in the emit masks is order-independent: the fast formula has
+// the bits of u,X,X,X,X set (they are plain in-string bytes) and a valid escape that emits n bytes CLEARS the bits
+// j >= n -- of its own chunk or the next one -- with an LDS atomic AND; overlapping escapes only exist in documents that
+// are rejected anyway.  Escapes whose 'u' lies in the last four bytes of the chunk in front of the unit reach into
+// chunk 0: lane 0 lists them as foreign items (their owner reports their errors).
+struct GenUnit {       // per wave
+    u64 em[64];        // emit masks of the unit's chunks
+    uint16_t list[2048 + 4];  // escaped characters: byte offset inside the unit; foreign items: 0x8000 | (0..3)
+};
+// le: escaped in-string characters of this lane's chunk that have to be evaluated (0: none); returns the wave's item count
+__device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, int lane) {
+    const u32 n = (u32)popc64(le) + (lane == 0 ? (u32)popc64(foreign) : 0u);
+    u32 incl = n;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const u32 up = (u32)__shfl_up((int)incl, sft, 64);
+        if (lane >= sft) incl += up;
+    }
+    u32 o = incl - n;
+    if (lane == 0)
+        for (u64 f = foreign; f != 0; f &= f - 1) gu->list[o++] = (uint16_t)(0x8000u | (u32)ctz64(f));
+    for (u64 r = le; r != 0; r &= r - 1) gu->list[o++] = (uint16_t)((u32)lane * 64u + (u32)ctz64(r));
+    return (u32)__shfl((int)incl, 63, 64);
+}
+
+__device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nblocks, GenUnit *gu) {
     // Without touching the message (sj_strings.h str_chunk_masks_fast is the per-chunk statement): a chunk takes the
     // general routine only if it, or the chunk in front of it, holds an escaped character that no simple escape names.
     // Persistent waves: unit wave_id, wave_id + waves, ...; the masks of the next unit are requested before the current
@@ -141,12 +171,48 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
         const u64 e = ((in.st << 1) | stp) & sm;  // escaped characters inside strings
         u64 em = sm & ~in.st;
         u32 flags = e != 0 ? CHUNK_SLOW : 0u;
-        if ((((in.slow_w >> lane) & 1u) != 0 && e != 0) || prev_slow) {
-            u64 um;
-            bool escapes, overflow;
-            if (!str_chunk_masks(p.sv, c, &em, &um, &escapes, &overflow)) atomicOr(&p.st->err, 1u);
-            if (overflow) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
-            flags = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+        const bool own_slow = ((in.slow_w >> lane) & 1u) != 0 && e != 0;
+        const bool gen = own_slow || prev_slow;  // == str_chunk_needs_general(c)
+        if (__ballot(gen) != 0) {  // (wave-uniform) the unit takes the general routine
+            // escaped in-string characters in the last four bytes of the chunk in front (they may reach into this one)
+            u64 pe = (u64)__shfl_up((long long)e, 1, 64) >> 60;
+            if (lane == 0) pe = c ? (p.sv.esc(c - 1) & p.sv.sm(c - 1)) >> 60 : 0ull;
+            gu->em[lane] = em;
+            const u32 items = gen_unit_list(gu, own_slow ? e : 0ull, (lane == 0 && gen) ? pe : 0ull, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const u64 u0 = unit * 4096;
+            bool bad = false, over = false;
+            for (u32 j = (u32)lane; j < items; j += 64) {
+                const u32 it = gu->list[j];
+                const bool foreign = (it & 0x8000u) != 0;
+                const u64 a = foreign ? u0 - 4 + (it & 3u) : u0 + it;
+                const u8 b = p.sv.at(a);
+                if (b != 'u') {
+                    if (!foreign && escape_value(b) == 0) bad = true;
+                    continue;
+                }
+                const UEscape ue = unicode_escape(p.sv, a);
+                if (!foreign) {
+                    bad |= !ue.ok;
+                    over |= ue.overflow;
+                }
+                if (!ue.ok || ue.overflow) continue;  // (the parse fails or is repeated: the masks do not matter)
+                for (u32 k = ue.n; k <= 4; k++) {  // u,X,X,X,X emit their first n bytes
+                    const u64 ak = a + k;
+                    if (ak >= u0 && ak < u0 + 4096) atomicAnd(&gu->em[(ak - u0) >> 6], ~(1ull << (ak & 63)));
+                }
+            }
+            if (bad) atomicOr(&p.st->err, 1u);
+            if (over) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (gen) {
+                em = gu->em[lane];
+                flags = (e != 0 || pe != 0) ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the lists are read: the next unit may write them
         }
         const u32 n = (u32)popc64(em);
         u32 incl = n;
@@ -388,6 +454,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
     // unit's unescaped bytes.
     __shared__ __attribute__((aligned(16))) u8 s_io[4][4096 + 16];
+    __shared__ GenUnit s_gu[4];  // (only .list is used here)
     __shared__ u32 s_sel[16];
     __shared__ u8 s_esc[256];
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
@@ -444,12 +511,50 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         // two record loads instead of two records + two unit prefixes
         if (!p.no_abs) p.rec[c].abs = (u32)g + pre;
         if (total != 0) {  // wave-uniform
-            if (em != 0 && patched) {
+            const bool mine = em != 0 && patched;
+            if (mine) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
-                if (general) {
-                    str_chunk_patch(p.sv, c, [&](u32 q, u8 v) { in8[byte_ix(q)] = v; });
-                } else {  // simple escapes only: translated in place, nothing is read from the message
+            }
+            if (__ballot(mine && general) != 0) {  // (wave-uniform)
+                // The general patch of a unit, escape by escape (see GenUnit / k_measure): the emitted escaped characters
+                // of the unit's general chunks -- simple escapes and the 'u' of \u escapes that emit bytes -- are listed
+                // and the lanes take them round robin; the translated bytes go into the parked copy of the chunk they
+                // fall into, this one or the next (sj_strings.h str_chunk_patch is the per-chunk statement).
+                u64 le = 0, foreign = 0;
+                if (mine && general) {
+                    const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+                    le = ((stc << 1) | stp) & em;
+                }
+                if (lane == 0 && general && c > 0)  // escapes of the chunk in front whose bytes reach into chunk 0
+                    foreign = ((p.sv.esc(c - 1) & p.rec[c - 1].em) >> 60) & 0xfull;
+                GenUnit *gu = &s_gu[wave];
+                const u32 items = gen_unit_list(gu, le, foreign, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const u64 u0 = unit * 4096;
+                auto put = [&](u64 a, u8 v) {  // into the dword-major window: chunk (a - u0) >> 6, byte (a & 63)
+                    if (a < u0 || a >= u0 + 4096) return;
+                    const u32 q = (u32)(a & 63), L = (u32)((a - u0) >> 6);
+                    in8[((q >> 2) * 64 + L) * 4 + (q & 3)] = v;
+                };
+                for (u32 j = (u32)lane; j < items; j += 64) {
+                    const u32 it = gu->list[j];
+                    const bool fr = (it & 0x8000u) != 0;
+                    const u64 a = fr ? u0 - 4 + (it & 3u) : u0 + it;
+                    const u8 b = p.sv.at(a);
+                    if (b != 'u') {
+                        if (!fr) put(a, escape_value(b));
+                        continue;
+                    }
+                    const UEscape ue = unicode_escape(p.sv, a);
+                    for (u32 k = 0; k < ue.n; k++) put(a + k, ue.b[k]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (mine) {
+                if (!general) {  // simple escapes only: translated in place, nothing is read from the message
                     const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
                     for (u64 r = ((stc << 1) | stp) & em; r != 0; r &= r - 1) {
                         const u32 ix = byte_ix((u32)ctz64(r));
@@ -640,7 +745,8 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
 __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
-    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks);
+    __shared__ GenUnit s_gu[RD_BLOCK / 64];
+    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
     else s2_reduce_body(p, blockIdx.x - mblocks);
 }
 
