@@ -91,6 +91,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->side_stream) {
@@ -141,6 +142,7 @@ static void invalidate_result(sjhip_ctx *ctx) {
     ctx->pending = 0;
     ctx->q_tape_len = ctx->q_strings_len = 0;
     ctx->f_valid = 0;
+    ctx->pack_valid = 0;  // (sjhip_fetch goes back to the device copies, which a stage-1 call does not touch)
 }
 
 // stage 1 in two halves: enqueue (workspace, launch; the last block of the kernel leaves the packed result -- count,

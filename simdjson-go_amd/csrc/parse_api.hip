@@ -23,6 +23,8 @@ using namespace sj;
 // Phase 1 (parse_begin): stage 1, then stage 2 up to the device-wide scans; a shard reads back the sizes.
 // Phase 2 (parse_finish): the rest of stage 2 with the rebasing offsets, then the verdict.
 // documents up to this size are parsed with one host synchronisation (SJHIP_SMALL_BYTES overrides; 0 turns it off)
+static constexpr size_t PACK_BYTES = (size_t)2 << 20;  // pinned block for the results of small documents (sj_ctx.h h_pack)
+
 static size_t small_document_bytes() {
     static const size_t v = [] {
         const char *e = getenv("SJHIP_SMALL_BYTES");
@@ -78,6 +80,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
                        size_t *tape_len, size_t *strings_len) {
     ctx->tape_len = ctx->strings_len = 0;
     ctx->pending = 0;
+    ctx->pack_valid = 0;
     ctx->q_valid = 0;
     ctx->ser_valid = 0;
     ctx->ms_valid = 0;
@@ -163,12 +166,29 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     ctx->pending = 0;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     S2State *hs = (S2State *)(ctx->h_scratch + 256);
+    // a small document that came from a host buffer: the state, the tape and Strings.B go to pinned memory with the last
+    // launch of the chain (sj_ctx.h h_pack); sjhip_fetch then copies from there
+    const bool pack = ctx->want_pack && ctx->p_deferred && tape_base == 0 && strings_base == 0 && msg_base == 0;
+    ctx->want_pack = 0;
+    ctx->pack_valid = 0;
+    if (pack && !ctx->h_pack && hipHostMalloc((void **)&ctx->h_pack, PACK_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_pack = nullptr;
+    }
     auto run = [&]() -> int {
         const S2Args a = s2_args(ctx, tape_base, strings_base, msg_base);
         HIPCHK(stage2_launch_emit(a), "stage2 launch (emit)");
-        HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
-        HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+        if (pack && ctx->h_pack) {
+            HIPCHK(stage2_launch_pack(a, ctx->h_pack, PACK_BYTES), "stage2 launch (pack)");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+            memcpy(hs, ctx->h_pack, sizeof(S2State));
+            ctx->pack_valid = *(const unsigned long long *)(ctx->h_pack + 64) != 0;
+        } else {
+            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
+        }
         if (hs->bignum_count && !(hs->err & S2_ERR_SERIAL_STRINGS)) {  // rare: >19-digit mantissas that need the exact tie-break
+            ctx->pack_valid = 0;  // (k_pack did not copy: the tape is not final)
             HIPCHK(stage2_launch_bignum(a), "stage2 launch (bignum)");
             HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
             HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
@@ -258,7 +278,10 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
     int rc = arena_reserve(ctx, ctx->d_msg, mlen + 128);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->d_msg.p, msg + off, mlen, hipMemcpyHostToDevice, ctx->stream), "H2D message");
-    return parse_on_device(ctx, ctx->d_msg.p, mlen, flags, msg[off + mlen - 1], 1, tape_len, strings_len);
+    ctx->want_pack = 1;  // the caller holds host buffers: its sjhip_fetch will want the result there
+    rc = parse_on_device(ctx, ctx->d_msg.p, mlen, flags, msg[off + mlen - 1], 1, tape_len, strings_len);
+    ctx->want_pack = 0;
+    return rc;
 }
 
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
@@ -270,6 +293,12 @@ void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_l
 
 int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
     if (!ctx) return SJHIP_ERR_ARG;
+    if (ctx->pack_valid && ctx->h_pack) {  // the result of a small sjhip_parse is already in pinned host memory
+        if (ctx->tape_len && tape_dst) memcpy(tape_dst, ctx->h_pack + STAGE2_PACK_HEAD, ctx->tape_len * sizeof(uint64_t));
+        if (ctx->strings_len && strings_dst)
+            memcpy(strings_dst, ctx->h_pack + STAGE2_PACK_HEAD + ctx->tape_len * sizeof(uint64_t), ctx->strings_len);
+        return SJHIP_OK;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (ctx->tape_len && tape_dst)
         HIPCHK(hipMemcpyAsync(tape_dst, ctx->d_tape.p, ctx->tape_len * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream),

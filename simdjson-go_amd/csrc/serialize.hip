@@ -534,6 +534,7 @@ int sjhip_deserialize(sjhip_ctx *ctx, const uint8_t *stream, size_t len, size_t 
     if (!ctx || !stream) return SJHIP_ERR_ARG;
     ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = 0;
     ctx->pending = 0;
+    ctx->pack_valid = 0;
     ctx->tape_len = ctx->strings_len = 0;
     ctx->des_msg_len = 0;
     auto corrupt = [&](const char *what) {

@@ -21,6 +21,11 @@ struct sjhip_ctx {
     hipStream_t side_stream = nullptr; // the string bytes of a parse run here, beside the tape kernels (parse_api.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
+    // small documents parsed from a host buffer (sjhip_parse): the last kernel of the chain also writes the stage-2 state,
+    // the tape and Strings.B into this pinned block (over PCIe, no copy commands), and sjhip_fetch is two memcpy
+    uint8_t *h_pack = nullptr;
+    int want_pack = 0;                 // set by sjhip_parse for the parse it starts
+    int pack_valid = 0;                // h_pack holds the result of the last parse
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B

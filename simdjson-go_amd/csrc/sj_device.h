@@ -74,6 +74,11 @@ size_t stage2_workspace_bytes(size_t n_tokens);
 hipError_t stage2_launch_measure(const S2Args &a);
 hipError_t stage2_launch_emit(const S2Args &a);
 hipError_t stage2_launch_bignum(const S2Args &a);
+// Behind the emit phase: the 64-byte state to h_dst, and -- if the parse succeeded, needs no bignum pass and
+// 8 * tape_len + strings_len fits `cap` -- the tape to h_dst + STAGE2_PACK_HEAD and Strings.B behind it; h_dst[64] (u64)
+// says whether the payload is there.  h_dst is pinned host memory mapped into the device (one launch, no copy commands).
+constexpr size_t STAGE2_PACK_HEAD = 128;
+hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap);
 
 size_t stage1_workspace_bytes(size_t len);
 // zero2 / zero2_bytes: a second region to zero in the same kernel (the stage-2 state) or null

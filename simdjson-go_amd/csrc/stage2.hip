@@ -1553,6 +1553,32 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     return hipGetLastError();
 }
 
+// ---- small documents: state + tape + Strings.B straight into pinned host memory -------------------------------------
+__global__ __launch_bounds__(256) void k_pack(const S2State *st, const u64 *tape, const u8 *strings, u32 masks, u8 *dst, u64 cap) {
+    const S2State s = *st;
+    const u64 tl = s.tape_len, sl = masks ? s.strings_len_masks : s.strings_len;
+    const bool ok = s.err == 0 && s.bignum_count == 0 && STAGE2_PACK_HEAD + 8 * tl + sl <= cap;
+    const u32 tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    if (tid == 0) {
+        *reinterpret_cast<S2State *>(dst) = s;
+        *reinterpret_cast<u64 *>(dst + 64) = ok ? 1ull : 0ull;
+    }
+    if (!ok) return;
+    uint4 *dt = reinterpret_cast<uint4 *>(dst + STAGE2_PACK_HEAD);
+    const uint4 *st4 = reinterpret_cast<const uint4 *>(tape);  // (the arena is 16-byte aligned)
+    for (u64 i = tid; i < tl / 2; i += nthr) dt[i] = st4[i];
+    if ((tl & 1) && tid == 0) reinterpret_cast<u64 *>(dst + STAGE2_PACK_HEAD)[tl - 1] = tape[tl - 1];
+    u8 *ds = dst + STAGE2_PACK_HEAD + 8 * tl;  // 8-byte aligned
+    const u64 s8 = sl / 8;
+    for (u64 i = tid; i < s8; i += nthr) reinterpret_cast<u64 *>(ds)[i] = reinterpret_cast<const u64 *>(strings)[i];
+    if (tid < (sl & 7)) ds[s8 * 8 + tid] = strings[s8 * 8 + tid];
+}
+hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap) {
+    hipLaunchKernelGGL(k_pack, dim3(128), dim3(256), 0, a.stream, (const S2State *)a.ws_zero, (const u64 *)a.d_tape, (const u8 *)a.d_strings,
+                       a.str_aux ? 1u : 0u, (u8 *)h_dst, (u64)cap);
+    return hipGetLastError();
+}
+
 // exact tie-break of the queued numbers (S2State::bignum_count != 0 after the emit phase: rare)
 hipError_t stage2_launch_bignum(const S2Args &a) {
     const S2Dev p = stage2_view(a);
