@@ -566,3 +566,31 @@ print('ok')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (mode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_fetch_after_small_parse_paths(ctx):
+    """sjhip_parse of a small document leaves its result in pinned host memory (k_pack) and sjhip_fetch copies from there;
+    a stage-1-only call in between, a result larger than the pinned block, a parse that needs the bignum pass and a
+    second fetch must all still deliver the oracle's tape."""
+    import ctypes as C
+    import sjhip
+    from sjhip import _lib
+    L = _lib.lib()
+    big_tape = ("[" + ",".join(["1"] * 300000) + "]").encode()            # 600 KB in, 4.8 MB of tape out
+    bignum = b'[1.00000000000000011102230246251565404236316680908203125, 123456789012345678901234567890e-10, "x"]'
+    for doc, nd in ((fixtures.load("twitter"), False), (fixtures.load("parking-citations"), True), (big_tape, False), (bignum, False)):
+        ref = O.parse(doc, ndjson=nd, copy_strings=True)
+        assert ref.rc == 0
+        a = np.frombuffer(doc, dtype=np.uint8)
+        for stage1_between in (False, True):
+            tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+            rc = L.sjhip_parse(ctx._h, a.ctypes.data, a.size, (1 if nd else 0) | 2, C.byref(tl), C.byref(sl), C.byref(mo), C.byref(ml))
+            assert rc == 0 and tl.value == len(ref.tape) and sl.value == len(ref.strings)
+            if stage1_between:
+                ok, pos = ctx.stage1(fixtures.load("canada").strip())
+                assert ok
+            for _ in range(2):
+                tape = np.zeros(tl.value, dtype=np.uint64)
+                strs = np.zeros(sl.value, dtype=np.uint8)
+                assert L.sjhip_fetch(ctx._h, tape.ctypes.data, strs.ctypes.data) == 0
+                assert np.array_equal(tape, ref.tape) and np.array_equal(strs, ref.strings), (len(doc), stage1_between)
