@@ -223,6 +223,44 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         }
     }
     if (copy) {
+        // The escape-by-escape form of the general routine (what k_measure runs: stage2.hip GenUnit, sj_strings.h
+        // gen_item_masks) must give the verdict, the emit masks and the flags of the per-chunk form above.
+        u32 bad2 = 0;
+        for (size_t u = 0; u < used_units; u++) {
+            u64 em2[64], e_[64], pe_[64];
+            bool gen[64], own[64], any = false;
+            for (u32 l = 0; l < 64; l++) {
+                const u64 c = u * 64 + l, smc = sv.sm(c);
+                e_[l] = sv.esc(c) & smc;
+                pe_[l] = c ? (sv.esc(c - 1) & sv.sm(c - 1)) >> 60 : 0ull;
+                em2[l] = smc & ~v_st[c];
+                own[l] = sv.nonsimple(c) && e_[l] != 0;
+                gen[l] = own[l] || (c > 0 && sv.nonsimple(c - 1));
+                any |= gen[l];
+            }
+            bool b2 = false, o2 = false;
+            if (any) {
+                std::vector<u32> items;
+                if (gen[0])
+                    for (u64 f = pe_[0]; f != 0; f &= f - 1) items.push_back(GEN_FOREIGN | (u32)ctz64(f));
+                for (u32 l = 0; l < 64; l++)
+                    if (own[l])
+                        for (u64 r = e_[l]; r != 0; r &= r - 1) items.push_back(l * 64 + (u32)ctz64(r));
+                for (size_t j = items.size(); j-- > 0;)  // (any order: here the reverse of the listing)
+                    gen_item_masks(sv, (u64)u * 4096, items[j], &b2, &o2, [&](u32 pos) { em2[pos >> 6] &= ~(1ull << (pos & 63)); });
+            }
+            if (o2) return 93;  // (an overflow would have set force_copy above)
+            bad2 |= b2 ? 1u : 0u;
+            if (bad || b2) continue;  // a rejected document: the masks are not compared
+            for (u32 l = 0; l < 64; l++) {
+                const u64 c = u * 64 + l;
+                const u32 f2 = gen[l] ? ((e_[l] != 0 || pe_[l] != 0) ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u) : (e_[l] != 0 ? CHUNK_SLOW : 0u);
+                if (em2[l] != v_em[c] || f2 != v_flags[c]) return 93;
+            }
+        }
+        if ((bad2 != 0) != (bad != 0)) return 93;
+    }
+    if (copy) {
         for (size_t u = 0; u < used_units; u++) {
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
@@ -344,17 +382,42 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     for (u32 c = 0; c < n_br; c++)  // k_br_match: container of every gap, pair words, root words
         if (!bracket_resolve(mt, br_off.data(), br_info.data(), c, tape_base, tape)) bad = 1;
     if (n_br == 0) bad = 1;  // unreachable: token 0 must be an open bracket
-    if (copy && !bad)  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
+    if (copy && !bad) {  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
+        std::vector<u8> ubuf(4096);
         for (size_t c = 0; c < used_units * 64; c++) {
+            if ((c & 63) == 0) {
+                // the escape-by-escape form of the general patch (k_str_emit: gen_item_patch) for the whole unit, to be
+                // compared with the per-chunk form below
+                const size_t u = c >> 6;
+                for (u32 q = 0; q < 4096; q++) ubuf[q] = sv.at(u * 4096 + q);
+                std::vector<u32> items;
+                bool any = false;
+                for (u32 l = 0; l < 64; l++) any |= v_em[c + l] != 0 && (v_flags[c + l] & CHUNK_GENERAL) != 0;
+                if (any) {
+                    if ((v_flags[c] & CHUNK_GENERAL) && c > 0)
+                        for (u64 f = ((sv.esc(c - 1) & v_em[c - 1]) >> 60) & 0xfull; f != 0; f &= f - 1)
+                            items.push_back(GEN_FOREIGN | (u32)ctz64(f));
+                    for (u32 l = 0; l < 64; l++)
+                        if (v_em[c + l] != 0 && (v_flags[c + l] & CHUNK_GENERAL))
+                            for (u64 r = sv.esc(c + l) & v_em[c + l]; r != 0; r &= r - 1) items.push_back(l * 64 + (u32)ctz64(r));
+                    for (size_t j = items.size(); j-- > 0;)
+                        gen_item_patch(sv, (u64)u * 4096, items[j], [&](u32 pos, u8 v) { ubuf[pos] = v; });
+                }
+            }
             if (v_em[c] == 0) continue;
             u8 chunk[64];
             for (u32 q = 0; q < 64; q++) chunk[q] = sv.at(c * 64 + q);
-            if (v_flags[c] & CHUNK_GENERAL) str_chunk_patch(sv, c, [&](u32 q, u8 v) { chunk[q] = v; });
-            else if (v_flags[c] & CHUNK_SLOW)
+            if (v_flags[c] & CHUNK_GENERAL) {
+                str_chunk_patch(sv, c, [&](u32 q, u8 v) { chunk[q] = v; });
+                for (u64 r = v_em[c]; r != 0; r &= r - 1)  // every emitted byte: both forms agree
+                    if (chunk[ctz64(r)] != ubuf[(c & 63) * 64 + ctz64(r)]) return 92;
+            } else if (v_flags[c] & CHUNK_SLOW) {
                 str_chunk_patch_simple(sv, c, v_em[c], [&](u32 q) { return chunk[q]; }, [&](u32 q, u8 v) { chunk[q] = v; });
+            }
             u8 *dst = strs + v_ucnt[c >> 6] + v_pre[c];
             for (u64 r = v_em[c]; r != 0; r &= r - 1) *dst++ = chunk[ctz64(r)];
         }
+    }
     if (bad) {
         free(tape);
         free(strs);

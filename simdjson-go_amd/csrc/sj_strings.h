@@ -295,6 +295,51 @@ SJ_HD void str_chunk_patch(const StrView &m, u64 c, Put put) {
     }
 }
 
+// ---- the general routine escape by escape (k_measure / k_str_emit: stage2.hip GenUnit; host replay: host_selftest.cpp) ---
+// A unit's escaped in-string characters that need the general routine are listed and evaluated one by one, by any lane,
+// in any order.  item = byte offset of the escaped character inside the unit that starts at aligned offset u0, or
+// GEN_FOREIGN | k: escaped character k (0..3) of the last four bytes of the chunk in front of the unit (its bytes may
+// reach into chunk 0; errors of a foreign item are reported by the unit that owns it).
+// Mask pass: the fast formula has the bits of u,X,X,X,X set (plain in-string bytes); a valid escape that emits n bytes
+// clears the bits j >= n -- clear(position inside the unit); overlapping escapes only exist in rejected documents.
+static constexpr u32 GEN_FOREIGN = 0x8000u;
+template <typename Clear>
+SJ_HD void gen_item_masks(const StrView &m, u64 u0, u32 item, bool *bad, bool *over, Clear clear) {
+    const bool foreign = (item & GEN_FOREIGN) != 0;
+    const u64 a = foreign ? u0 - 4 + (item & 3u) : u0 + item;
+    const u8 b = m.at(a);
+    if (b != 'u') {
+        if (!foreign && escape_value(b) == 0) *bad = true;
+        return;
+    }
+    const UEscape ue = unicode_escape(m, a);
+    if (!foreign) {
+        if (!ue.ok) *bad = true;
+        if (ue.overflow) *over = true;
+    }
+    if (!ue.ok || ue.overflow) return;  // (the parse fails or is repeated: the masks do not matter)
+    for (u32 k = ue.n; k <= 4; k++) {
+        const u64 ak = a + k;
+        if (ak >= u0 && ak < u0 + 4096) clear((u32)(ak - u0));
+    }
+}
+// Writing pass: the translated byte of a simple escape, the n bytes of a \u escape -- put(position inside the unit, byte)
+template <typename Put>
+SJ_HD void gen_item_patch(const StrView &m, u64 u0, u32 item, Put put) {
+    const bool foreign = (item & GEN_FOREIGN) != 0;
+    const u64 a = foreign ? u0 - 4 + (item & 3u) : u0 + item;
+    const u8 b = m.at(a);
+    if (b != 'u') {
+        if (!foreign) put((u32)(a - u0), escape_value(b));
+        return;
+    }
+    const UEscape ue = unicode_escape(m, a);
+    for (u32 k = 0; k < ue.n; k++) {
+        const u64 ak = a + k;
+        if (ak >= u0 && ak < u0 + 4096) put((u32)(ak - u0), ue.b[k]);
+    }
+}
+
 // E(a): emitted bytes in front of aligned offset a
 SJ_HD u64 emitted_before(const u32 *unit_base, const ChunkRec *rec, u64 a) {
     const ChunkRec r = rec[a >> 6];

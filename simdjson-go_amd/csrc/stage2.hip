@@ -128,7 +128,7 @@ __device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, i
     }
     u32 o = incl - n;
     if (lane == 0)
-        for (u64 f = foreign; f != 0; f &= f - 1) gu->list[o++] = (uint16_t)(0x8000u | (u32)ctz64(f));
+        for (u64 f = foreign; f != 0; f &= f - 1) gu->list[o++] = (uint16_t)(GEN_FOREIGN | (u32)ctz64(f));
     for (u64 r = le; r != 0; r &= r - 1) gu->list[o++] = (uint16_t)((u32)lane * 64u + (u32)ctz64(r));
     return (u32)__shfl((int)incl, 63, 64);
 }
@@ -183,26 +183,9 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
             __builtin_amdgcn_wave_barrier();
             const u64 u0 = unit * 4096;
             bool bad = false, over = false;
-            for (u32 j = (u32)lane; j < items; j += 64) {
-                const u32 it = gu->list[j];
-                const bool foreign = (it & 0x8000u) != 0;
-                const u64 a = foreign ? u0 - 4 + (it & 3u) : u0 + it;
-                const u8 b = p.sv.at(a);
-                if (b != 'u') {
-                    if (!foreign && escape_value(b) == 0) bad = true;
-                    continue;
-                }
-                const UEscape ue = unicode_escape(p.sv, a);
-                if (!foreign) {
-                    bad |= !ue.ok;
-                    over |= ue.overflow;
-                }
-                if (!ue.ok || ue.overflow) continue;  // (the parse fails or is repeated: the masks do not matter)
-                for (u32 k = ue.n; k <= 4; k++) {  // u,X,X,X,X emit their first n bytes
-                    const u64 ak = a + k;
-                    if (ak >= u0 && ak < u0 + 4096) atomicAnd(&gu->em[(ak - u0) >> 6], ~(1ull << (ak & 63)));
-                }
-            }
+            for (u32 j = (u32)lane; j < items; j += 64)
+                gen_item_masks(p.sv, u0, gu->list[j], &bad, &over,
+                               [&](u32 pos) { atomicAnd(&gu->em[pos >> 6], ~(1ull << (pos & 63))); });
             if (bad) atomicOr(&p.st->err, 1u);
             if (over) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -533,23 +516,11 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 const u64 u0 = unit * 4096;
-                auto put = [&](u64 a, u8 v) {  // into the dword-major window: chunk (a - u0) >> 6, byte (a & 63)
-                    if (a < u0 || a >= u0 + 4096) return;
-                    const u32 q = (u32)(a & 63), L = (u32)((a - u0) >> 6);
-                    in8[((q >> 2) * 64 + L) * 4 + (q & 3)] = v;
-                };
-                for (u32 j = (u32)lane; j < items; j += 64) {
-                    const u32 it = gu->list[j];
-                    const bool fr = (it & 0x8000u) != 0;
-                    const u64 a = fr ? u0 - 4 + (it & 3u) : u0 + it;
-                    const u8 b = p.sv.at(a);
-                    if (b != 'u') {
-                        if (!fr) put(a, escape_value(b));
-                        continue;
-                    }
-                    const UEscape ue = unicode_escape(p.sv, a);
-                    for (u32 k = 0; k < ue.n; k++) put(a + k, ue.b[k]);
-                }
+                for (u32 j = (u32)lane; j < items; j += 64)
+                    gen_item_patch(p.sv, u0, gu->list[j], [&](u32 pos, u8 v) {  // into the dword-major window
+                        const u32 q = pos & 63u, L = pos >> 6;
+                        in8[((q >> 2) * 64 + L) * 4 + (q & 3)] = v;
+                    });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
