@@ -5,17 +5,22 @@
 // sj_number.h / sj_bignum.h (host+device, replayed on the CPU by the test-suite); this file holds the
 // kernels, the device-wide scan and the launcher.  No host synchronisation happens between the kernels.
 //
-// Passes over the tokens (one token = one structural index):
-//   k_s2_reduce      scan element per token from the token kinds (written by stage 1), one aggregate per 4096-token tile
-//   k_s2_scan_tiles  exclusive scan of the tile aggregates (one block) + totals: tape length, records, brackets
-//   k_s2_emit        (512 threads x 8 tokens) rebuilds the elements, scans inside the tile, and writes every tape word that does not depend
-//                    on a bracket partner: strings, numbers, atoms; brackets go to a compact view
-//                    (depth, tape offset, kind, allowed-context set of the gap in front), newlines that
-//                    separate records leave their tape offset
-//   k_numbers (second role), k_min_upper, k_br_match   64-ary min tree over the compact bracket view and
-//                    previous-smaller-value queries over it: partners' tape words, the grammar check of every gap
-//                    against the type of its container, root words
-// plus the byte-parallel string kernels (every string copied) or k_emit_strings (selective copy), and k_bignum.
+// Launches of one parse, behind stage 1 (one token = one structural index):
+//   k_measure   two independent measuring passes in one launch: the string masks of stage 1 -> emit masks, one 16-byte
+//               record per 64-byte chunk and one count per 4 KiB unit (general \u routine escape by escape: GenUnit);
+//               the token kinds (written by stage 1) -> scan element per token, one aggregate per 4096-token tile
+//   k_scans     both exclusive scans (unit counts; tile aggregates) + totals: tape length, records, brackets
+//   k_str_emit  Strings.B: the emitted bytes of every chunk, compacted through LDS
+//   k_s2_emit   (512 threads x 8 tokens) rebuilds the elements, scans inside the tile, sorts the tokens by kind into LDS
+//               queues and writes every tape word that does not depend on a bracket partner: strings, atoms; numbers
+//               go to a global queue, brackets to a compact view (depth, tape offset, kind, allowed-context set of the
+//               gap in front), newlines that separate records leave their tape offset
+//   k_numbers   the queued numbers; in the same launch levels 1 and 2 of the 64-ary min tree over the bracket depths
+//   k_min_upper the upper levels of the tree
+//   k_br_match  previous-smaller-value queries over the compact bracket view: partners' tape words, the grammar check
+//               of every gap against the type of its container, root words
+// plus k_emit_strings (selective copy), k_bignum (on demand) and k_pack (small documents: the result straight into
+// pinned host memory).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
