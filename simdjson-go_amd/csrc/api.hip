@@ -92,6 +92,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->side_stream) {

@@ -134,12 +134,46 @@ int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *
     }
     rc = sj::arena_reserve(ctx, ctx->d_msg, total + 128);
     if (rc) return rc;
-    for (size_t k = 0; k < n; k++)
-        if (hipMemcpyAsync((uint8_t *)ctx->d_msg.p + docs[k].dst, msgs[k] + host_off[k], docs[k].len, hipMemcpyHostToDevice,
-                           ctx->stream) != hipSuccess) {
-            sj::ctx_set_error(ctx, "sjhip_parse_batch: H2D of a document failed");
-            return SJHIP_ERR_HIP;
+    // H2D.  A copy command costs microseconds whatever it moves, so consecutive small documents are gathered in a pinned
+    // block at their packed offsets (the separator bytes between them are written by k_batch_fix) and travel as one
+    // copy; a document of STAGE_DOC bytes or more goes straight from the caller's buffer.
+    constexpr size_t STAGE_DOC = 64 << 10, STAGE_CAP = 32 << 20;
+    if (!ctx->h_stage && hipHostMalloc((void **)&ctx->h_stage, STAGE_CAP, hipHostMallocDefault) == hipSuccess) ctx->h_stage_cap = STAGE_CAP;
+    if (!ctx->h_stage) (void)hipGetLastError();  // (no pinned memory: every document is copied on its own)
+    auto h2d = [&](uint64_t dst, const void *src, size_t bytes) {
+        return hipMemcpyAsync((uint8_t *)ctx->d_msg.p + dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    };
+    bool ok = true;
+    uint64_t run_dst = 0;   // packed offset of the staged run
+    size_t run_len = 0, stage_used = 0;  // bytes of the open run; bytes of the block that copies in flight may still read
+    auto flush = [&]() {
+        if (run_len) ok = ok && h2d(run_dst, ctx->h_stage + stage_used, run_len);
+        stage_used += run_len;
+        run_len = 0;
+    };
+    for (size_t k = 0; k < n && ok; k++) {
+        const uint8_t *src = msgs[k] + host_off[k];
+        if (!ctx->h_stage || docs[k].len >= STAGE_DOC) {
+            flush();
+            ok = ok && h2d(docs[k].dst, src, docs[k].len);
+            continue;
         }
+        const size_t gap = run_len ? (size_t)(docs[k].dst - (run_dst + run_len)) : 0;  // the separator in front (1 byte)
+        if (stage_used + run_len + gap + docs[k].len > ctx->h_stage_cap) {  // the block is full: wait for its copies
+            flush();
+            ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+            stage_used = 0;
+        }
+        if (run_len == 0) run_dst = docs[k].dst;
+        else run_len += (size_t)(docs[k].dst - (run_dst + run_len));
+        memcpy(ctx->h_stage + stage_used + run_len, src, docs[k].len);
+        run_len += docs[k].len;
+    }
+    flush();
+    if (!ok) {
+        sj::ctx_set_error(ctx, "sjhip_parse_batch: H2D of the documents failed");
+        return SJHIP_ERR_HIP;
+    }
     const DocDesc *d_docs = nullptr;
     rc = upload_docs(ctx, docs, &d_docs);
     if (rc) return rc;
