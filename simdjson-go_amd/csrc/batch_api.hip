@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/sjhip.h"
+#include "sj_chunk.h"
 #include "sj_ctx.h"
 #include "sj_host.h"
 
@@ -47,12 +48,7 @@ __global__ __launch_bounds__(256) void k_batch_pack(const uint8_t *__restrict__ 
     const uint64_t i = first + (uint64_t)threadIdx.x * 16;
     if (aligned && i + 16 <= end) {
         uint4 v = *reinterpret_cast<const uint4 *>(s + i);
-        auto fix = [](uint32_t w) {  // every byte 0x0a -> 0x0d
-            const uint32_t x = w ^ 0x0a0a0a0au;
-            const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);  // 0x80 in every byte that is '\n'
-            return w ^ ((z >> 7) * 0x07u);                                               // 0x0a ^ 0x07 = 0x0d
-        };
-        v.x = fix(v.x); v.y = fix(v.y); v.z = fix(v.z); v.w = fix(v.w);
+        v.x = sj::newlines_to_cr(v.x); v.y = sj::newlines_to_cr(v.y); v.z = sj::newlines_to_cr(v.z); v.w = sj::newlines_to_cr(v.w);
         *reinterpret_cast<uint4 *>(o + i) = v;
     } else {
         for (uint64_t k = i; k < i + 16 && k < end; k++) {

@@ -436,3 +436,22 @@ extern "C" unsigned sj_selftest_format_float(uint64_t bits, uint8_t *out32) { re
 extern "C" unsigned sj_selftest_format_int(uint64_t raw, int is_unsigned, uint8_t *out24) {
     return is_unsigned ? format_uint(raw, out24) : format_int(raw, out24);
 }
+
+// batch_api.hip: the SWAR newline -> carriage return of the packing kernel against the byte loop, every byte value in
+// every lane over a background of newlines and of other bytes
+extern "C" int sj_selftest_newlines_to_cr(void) {
+    for (u32 bg = 0; bg < 4; bg++) {
+        const u32 back = bg == 0 ? 0x0a0a0a0au : bg == 1 ? 0x00000000u : bg == 2 ? 0xffffffffu : 0x0b090d8au;
+        for (u32 lane = 0; lane < 4; lane++)
+            for (u32 b = 0; b < 256; b++) {
+                const u32 w = (back & ~(0xffu << (8 * lane))) | (b << (8 * lane));
+                u32 want = 0;
+                for (u32 k = 0; k < 4; k++) {
+                    const u32 x = (w >> (8 * k)) & 0xffu;
+                    want |= (x == 0x0au ? 0x0du : x) << (8 * k);
+                }
+                if (newlines_to_cr(w) != want) return 1;
+            }
+    }
+    return 0;
+}

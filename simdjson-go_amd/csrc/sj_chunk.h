@@ -281,4 +281,11 @@ SJ_HD u64 finalize(u64 structs, u64 ws, u64 quote_mask, u64 quote_bits, u32 pseu
     return bitop3<(TA & (~TB | TC))>(s0 | t, quote_bits, quote_mask);
 }
 
+// every byte 0x0a ('\n') of a word becomes 0x0d ('\r'), the other bytes stay (batch_api.hip packs documents with it)
+SJ_HD u32 newlines_to_cr(u32 w) {
+    const u32 x = w ^ 0x0a0a0a0au;
+    const u32 z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);  // 0x80 in every byte that is '\n'
+    return w ^ ((z >> 7) * 0x07u);                                          // 0x0a ^ 0x07 = 0x0d
+}
+
 }  // namespace sj

@@ -137,3 +137,10 @@ def test_classify_every_byte_value():
             for j in range(64):
                 kind = sum(((out[7 + b] >> j) & 1) << b for b in range(4))
                 assert kind == kinds.get(chunk[j], 0), (chunk[j], kind)
+
+
+def test_batch_newline_translation():
+    """sj_chunk.h newlines_to_cr (the packing kernel of sjhip_parse_batch): four bytes at a time against the byte loop."""
+    L = C.CDLL(G.build_selftest())
+    L.sj_selftest_newlines_to_cr.restype = C.c_int
+    assert L.sj_selftest_newlines_to_cr() == 0
