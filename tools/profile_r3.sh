@@ -8,19 +8,19 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${1:-prof_r3}
 mkdir -p $OUT
 cd $REPO
-timeout 400 python bench.py > $OUT/bench_plain.log 2>&1
+timeout 120 python bench.py > $OUT/bench_plain.log 2>&1
 grep -h "^{" $OUT/bench_plain.log | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 for w in twitter parking; do
-  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/trace_$w -o p -- python $REPO/tools/parse_loop.py $w 6 > $OUT/trace_$w.log 2>&1
-  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/fetch_$w.log 2>&1
-  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/write_$w.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --stats -d $OUT/trace_$w -o p -- python $REPO/tools/parse_loop.py $w 6 > $OUT/trace_$w.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/fetch_$w.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/write_$w.log 2>&1
 done
 for c in 426 1700; do
   export COPIES=$c
-  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/s1trace_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1trace_$c.log 2>&1
-  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/s1fetch_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1fetch_$c.log 2>&1
-  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/s1write_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1write_$c.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --stats -d $OUT/s1trace_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1trace_$c.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/s1fetch_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1fetch_$c.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/s1write_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1write_$c.log 2>&1
 done
 cd $REPO && python tools/summarize_prof.py $OUT $OUT/summary.txt > /dev/null
 grep -E "^==|pmc|kernel " $OUT/summary.txt | sed "s/(sj::S2Dev[^)]*)//" | grep -v fillBuffer | cut -c1-200 | head -150
