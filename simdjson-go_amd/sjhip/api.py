@@ -116,7 +116,7 @@ class Context:
             np.empty(sl.value, dtype=np.uint8)
         rc = L.sjhip_fetch(self._h, tape_buf.ctypes.data, str_buf.ctypes.data)
         self._check(rc)
-        msg = a[mo.value: mo.value + ml.value].tobytes()
+        msg = a[mo.value: mo.value + ml.value]  # (a view: no copy of the message on the parse path)
         return ParsedJson(msg, tape_buf[:tl.value], str_buf[:sl.value], tape_buf, str_buf)
 
     def parse_device(self, d_msg_ptr, length, ndjson=False, copy_strings=True):
@@ -270,15 +270,23 @@ class MultiContext:
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 
-    __slots__ = ("Message", "Tape", "Strings", "_tape_buf", "_str_buf", "records")
+    __slots__ = ("_msg", "Tape", "Strings", "_tape_buf", "_str_buf", "records")
 
     def __init__(self, message, tape, strings, tape_buf=None, str_buf=None):
-        self.Message = message
+        # `message`: bytes, or a uint8 view of the caller's buffer -- the reference's pj.Message ALIASES the input
+        # (bytes.TrimSpace, parse_json_amd64.go:55); the bytes object is only made when somebody asks for it
+        self._msg = message
         self.Tape = tape
         self.Strings = strings
         self._tape_buf = tape if tape_buf is None else tape_buf  # capacity behind Tape / Strings (reuse)
         self._str_buf = strings if str_buf is None else str_buf
         self.records = 0  # filtered streams: matching records of the block
+
+    @property
+    def Message(self):
+        if not isinstance(self._msg, bytes):
+            self._msg = self._msg.tobytes()
+        return self._msg
 
 
 _DEFAULT = {}
