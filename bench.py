@@ -246,6 +246,29 @@ def main():
             del d_big, p_big
             torch.cuda.empty_cache()
 
+        # ---- the same kernel on a 64 MiB document: the smallest size the north_star's >= 40 % read-bandwidth target names
+        if rank == 0 and args.copies == 426:
+            sm = workloads.c2_twitter_array(107)
+            ns = len(sm)
+            ss = workloads.c2_expected_structurals(107)
+            d_sm = device_doc(sm)
+            del sm
+            p_sm = torch.empty(ss + 1024, dtype=torch.int32, device=dev)
+            oks, cnts = ctx.stage1_device(d_sm.data_ptr(), ns, p_sm.data_ptr(), p_sm.numel())
+            assert oks and cnts == ss
+            ms_s = ctx.stage1_time(d_sm.data_ptr(), ns, p_sm.data_ptr(), p_sm.numel(), 20)
+            roof["at_64MiB"] = {"workload": f"twitter.json x107 array, {ns} B (64.4 MiB)", "kernel_ms": round(ms_s, 4),
+                                "input_GBps": round(ns / ms_s / 1e6, 1), "achieved": round((ns + 4 * ss) / ms_s / 1e6, 1),
+                                "frac": round((ns + 4 * ss) / ms_s / 1e6 / HBM_PEAK_GBS, 4),
+                                "input_frac": round(ns / ms_s / 1e6 / HBM_PEAK_GBS, 4)}
+            pmc_sm = _profile("stage1_pmc_64MiB.json")
+            if pmc_sm:
+                roof["at_64MiB"]["read_frac"] = round(2 * pmc_sm["FETCH_SIZE_KB"] * 1024 / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["at_64MiB"]["traffic"] = int(pmc_sm["hbm_bytes_per_launch"])
+                roof["at_64MiB"]["traffic_source_box"] = "committed profile (profiles/stage1_pmc_64MiB.json), not this run"
+            del d_sm, p_sm
+            torch.cuda.empty_cache()
+
         # ---- stage1+stage2 of the bench document
         tl = sl = 0
 
@@ -264,6 +287,20 @@ def main():
                          "kernels_us_committed_profile": (kprof or {}).get("twitter_x426"),
                          "note": "algorithmic bytes = (N + 4S) + (4S + N + 8T + B_str), SURVEY.md 8d; time = wall time of "
                                  "sjhip_parse_device (two host syncs included); per-kernel averages: profiles/r03_parse_kernels.json"}}
+        if rank == 0:  # WithCopyStrings(false): the reference publishes copy / nocopy pairs (README.md:517-557)
+            tln = sln = 0
+
+            def full_nc():
+                nonlocal tln, sln
+                tln, sln = ctx.parse_device(d_msg.data_ptr(), n_bytes, ndjson=False, copy_strings=False)
+            t_nc = timed(full_nc, reps)
+            algo_nc = (n_bytes + 4 * s_expect) + (4 * s_expect + n_bytes + 8 * tln + sln)
+            extra["full_parse_nocopy"] = {
+                "workload": f"configs[1] document, stage1+stage2 with WithCopyStrings(false) (only strings that unescaping changes go "
+                            f"to Strings.B), {n_bytes} B", "GBps": round(n_bytes / t_nc / 1e9, 2), "ms": round(t_nc * 1e3, 3),
+                "tape_words": tln, "strings_bytes": sln,
+                "roofline": {"bound": "hbm", "algorithmic_bytes": algo_nc, "achieved": round(algo_nc / t_nc / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_nc / t_nc / 1e9 / HBM_PEAK_GBS, 4)}}
         del d_pos
 
         # ---- Parse() of the single documents BASELINE.json names: configs[0] twitter.json, configs[2] canada.json
@@ -287,12 +324,19 @@ def main():
                     nonlocal tl1, sl1
                     tl1, sl1 = ctx.parse_device(d_one.data_ptr(), len(raw), ndjson=False, copy_strings=True)
                 t_dev = timed(one, 50)
+                t_h2h_nc = timed(lambda: ctx.parse(arr, reuse=reuse, copy_strings=False), 50)
+
+                def one_nc():
+                    ctx.parse_device(d_one.data_ptr(), len(raw), ndjson=False, copy_strings=False)
+                t_dev_nc = timed(one_nc, 50)
                 s_one = int(ctx.stage1(arr)[1].size)
                 algo = (len(raw) + 4 * s_one) + (4 * s_one + len(raw) + 8 * tl1 + sl1)
                 singles[key] = {"workload": f"Parse({name}.json), {len(raw)} B, every string copied", "structurals": s_one,
                                 "tape_words": tl1, "strings_bytes": sl1,
                                 "host_to_host_us": round(t_h2h * 1e6, 1), "host_to_host_GBps": round(len(raw) / t_h2h / 1e9, 2),
                                 "device_us": round(t_dev * 1e6, 1), "device_GBps": round(len(raw) / t_dev / 1e9, 2),
+                                "nocopy_host_to_host_us": round(t_h2h_nc * 1e6, 1), "nocopy_host_to_host_GBps": round(len(raw) / t_h2h_nc / 1e9, 2),
+                                "nocopy_device_us": round(t_dev_nc * 1e6, 1), "nocopy_device_GBps": round(len(raw) / t_dev_nc / 1e9, 2),
                                 "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / t_dev / 1e9, 1),
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / t_dev / 1e9 / HBM_PEAK_GBS, 5),
                                              "note": "a document of this size is bound by launch and synchronisation latency, not by "

@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-3 profile (GPU box, repo root): tools/profile_r3.sh <name>  -> gpurun_out/<name>/
+# Round-4 profile (GPU box, repo root): tools/profile_r4.sh <name>  -> gpurun_out/<name>/
 #  (1) bench.py plain (the bench line), (2) kernel trace + stats of the whole parse on the two BASELINE workloads,
 #  (3) HBM counters of every parse kernel (FETCH_SIZE / WRITE_SIZE in separate PMC passes, MI355X_MICROARCH.md),
-#  (4) stage 1 alone: kernel trace + FETCH/WRITE passes on configs[1] and on the 1 GiB document (twitter x1700).
+#  (4) stage 1 alone: kernel trace + FETCH/WRITE passes on the 64 MiB document (x107), configs[1] and the 1 GiB document (x1700).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/${1:-prof_r3}
+OUT=$REPO/gpurun_out/${1:-prof_r4}
 mkdir -p $OUT
 cd $REPO
-timeout 120 python bench.py > $OUT/bench_plain.log 2>&1
+timeout 400 python bench.py > $OUT/bench_plain.log 2>&1
 grep -h "^{" $OUT/bench_plain.log | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 for w in twitter parking; do
@@ -16,7 +16,7 @@ for w in twitter parking; do
   timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/fetch_$w.log 2>&1
   timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$w -o p -- python $REPO/tools/parse_loop.py $w 3 > $OUT/write_$w.log 2>&1
 done
-for c in 426 1700; do
+for c in 107 426 1700; do
   export COPIES=$c
   timeout 60 rocprofv3 --kernel-trace --stats -d $OUT/s1trace_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1trace_$c.log 2>&1
   timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/s1fetch_$c -o s1 -- python $REPO/tools/s1_time.py > $OUT/s1fetch_$c.log 2>&1
