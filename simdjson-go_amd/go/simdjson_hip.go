@@ -1,21 +1,27 @@
 //go:build hip && cgo
 // +build hip,cgo
 
-// simdjson_hip.go -- third backend of package simdjson: the MI355X engine (libsjhip).
+// simdjson_hip.go -- third backend of the reference's Go package: the MI355X engine (libsjhip).
 //
 // Drop this file into the root of github.com/minio/simdjson-go and build with
 //     CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/simdjson-go_amd -lsjhip" go build -tags hip
-// The two existing backend files must exclude the tag (see INTEGRATION.md):
+// The two existing backend files must exclude the tag (INTEGRATION.md section 2 lists the complete edits):
 //     simdjson_amd64.go   //go:build !appengine && !noasm && gc && !hip
 //     simdjson_other.go   //go:build (!amd64 || appengine || !gc || noasm) && !hip
+// No other reference file changes: this file declares no identifier that an untagged reference file (or a
+// *_amd64.go file, which stays in the build on amd64) declares -- tools/check_go_collisions.py checks that against
+// the identifier inventory of the reference (tests/golden/go_reference_symbols.json, tests/test_go_binding.py).
 //
-// It provides exactly the backend symbol set of simdjson_other.go:29-76 (SupportedCPU, Parse,
-// ParseND, Stream, ParseNDStream).  Everything above the tape -- Iter, Object, Array, the
-// Serializer -- is unchanged Go code that only reads ParsedJson{Message, Tape, Strings}.
+// It provides exactly the backend symbol set of simdjson_other.go:29-76 (SupportedCPU, Parse, ParseND, Stream,
+// ParseNDStream) plus newInternalParsedJson (simdjson_amd64.go:41, which the excluded file no longer provides).
+// It uses the reference's own types: ParsedJson / TStrings (parsed_json.go:60-71), internalParsedJson
+// (parsed_json.go:83-93: the embedded ParsedJson and copyStrings, which WithCopyStrings sets, options.go:13-18) and
+// ParserOption (options.go:4).  Everything above the tape -- Iter, Object, Array, the Serializer -- is unchanged Go
+// code that only reads ParsedJson{Message, Tape, Strings}.
 //
 // NOTE: there is no Go toolchain in the build container of this repository, so this file has
 // not been compiled there; the Python mirror (simdjson-go_amd/sjhip) binds the same C symbols
-// through ctypes and is what the test-suite executes.
+// through ctypes and tests/test_cabi_caller.py drives this file's exact call sequences from a C program.
 
 package simdjson
 
@@ -67,19 +73,23 @@ var ctxPool = sync.Pool{New: func() interface{} {
 	return c
 }}
 
-type internalParsedJson struct {
-	ParsedJson
-	copyStrings bool
-}
-
+// newInternalParsedJson is simdjson_amd64.go:41-62 for this backend: the reference's own internalParsedJson
+// (parsed_json.go:83-93) carries the options and is recycled through reuse.internal exactly as there.
 func newInternalParsedJson(reuse *ParsedJson, opts []ParserOption) (*internalParsedJson, error) {
 	if !SupportedCPU() {
 		return nil, errors.New("Host CPU does not meet target specs")
 	}
-	pj := &internalParsedJson{}
-	if reuse != nil {
+	var pj *internalParsedJson
+	if reuse != nil && reuse.internal != nil {
+		pj = reuse.internal
 		pj.ParsedJson = *reuse // recycle Tape / Strings capacity (simdjson_amd64.go:46-51)
 		pj.ParsedJson.internal = nil
+	} else {
+		pj = &internalParsedJson{}
+		if reuse != nil {
+			pj.ParsedJson = *reuse
+			pj.ParsedJson.internal = nil
+		}
 	}
 	pj.copyStrings = true
 	for _, opt := range opts {
@@ -90,8 +100,9 @@ func newInternalParsedJson(reuse *ParsedJson, opts []ParserOption) (*internalPar
 	return pj, nil
 }
 
-// parseMessage mirrors (*internalParsedJson).parseMessage (parse_json_amd64.go:52).
-func (pj *internalParsedJson) parseMessage(msg []byte, ndjson bool) error {
+// parseMessageHip is (*internalParsedJson).parseMessage (parse_json_amd64.go:52) on the GPU.  (Its own name: the
+// reference's method stays in the build on amd64.)
+func (pj *internalParsedJson) parseMessageHip(msg []byte, ndjson bool) error {
 	c, _ := ctxPool.Get().(*hipCtx)
 	if c == nil {
 		return errors.New("Host CPU does not meet target specs")
@@ -228,7 +239,7 @@ func Parse(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, erro
 	if err != nil {
 		return nil, err
 	}
-	if err = pj.parseMessage(b, false); err != nil {
+	if err = pj.parseMessageHip(b, false); err != nil {
 		return nil, err
 	}
 	parsed := &pj.ParsedJson
@@ -253,7 +264,7 @@ type hipMulti struct{ h *C.sjhip_multi }
 // messages below this size stay on one device (a shard should keep a GPU busy for longer than its fixed costs)
 const multiMinBytes = 32 << 20
 
-// parseMessageMulti is parseMessage(msg, true) over every GPU of the node.
+// parseMessageMulti is parseMessageHip(msg, true) over every GPU of the node.
 func (pj *internalParsedJson) parseMessageMulti(msg []byte) error {
 	m, _ := multiPool.Get().(*hipMulti)
 	if m == nil {
@@ -313,7 +324,7 @@ func ParseND(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, er
 	if len(b) >= multiMinBytes && int(C.sjhip_device_count()) > 1 {
 		err = pj.parseMessageMulti(b)
 	} else {
-		err = pj.parseMessage(b, true)
+		err = pj.parseMessageHip(b, true)
 	}
 	if err != nil {
 		return nil, err
@@ -383,8 +394,12 @@ func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 					return
 				}
 			}
-			if rc != C.SJHIP_OK { // SJHIP_ERR_STREAM_CLOSED after a failed block, or an internal error
-				readDone <- nil
+			if rc != C.SJHIP_OK {
+				if rc == C.SJHIP_ERR_STREAM_CLOSED { // a block has failed: the deliverer reports that block's error
+					readDone <- nil
+				} else { // an internal error: it must reach the consumer, or res would be closed without a final value
+					readDone <- fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_stream_last_error(st)))
+				}
 				notify(submitted)
 				return
 			}
