@@ -154,3 +154,24 @@ def test_deserialize_rejects_corrupt_streams(ctx):
         with pytest.raises(sjhip.ParseError):
             ctx.deserialize(np.ascontiguousarray(bad))
     ctx.deserialize(stream)  # the context is still usable
+
+
+def test_hand_derived_format_vectors(ctx):
+    """tests/golden/serialize_v3_vectors.py (streams derived by hand from parsed_serialize.go:201-236, 283-341, 376-431):
+    the device's de-duplicating serializer must produce exactly these bytes, the plain one where no string repeats,
+    and the device's Deserialize must read them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("serialize_v3_vectors", os.path.join(os.path.dirname(__file__), "golden", "serialize_v3_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for v in mod.VECTORS:
+        ref = O.parse(v["doc"], ndjson=v["ndjson"], copy_strings=True)
+        ctx.parse(v["doc"], ndjson=v["ndjson"], copy_strings=True)
+        got = ctx.serialize(dedup=True)
+        assert bytes(got) == v["stream"], (v["name"], bytes(got).hex(), v["stream"].hex())
+        if not v["repeats"]:
+            assert bytes(ctx.serialize(dedup=False)) == v["stream"], v["name"]
+        pj = ctx.deserialize(v["stream"])
+        assert len(pj.Tape) == len(ref.tape), v["name"]
+        assert tape_reader.to_python(pj.Tape, pj.Strings, pj.Message) == tape_reader.to_python(ref.tape, ref.strings, v["doc"]), v["name"]
