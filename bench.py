@@ -412,6 +412,17 @@ def main():
             tot = torch.tensor([len(shard)], dtype=torch.int64, device=dev)
             dist.all_reduce(tot)
             total_bytes = int(tot.item())
+        # the sizes of the pieces must add up to the sizes of the whole parse whichever path produced them: parking-citations
+        # holds 80 tape words and 256 664 / 1000 Strings.B bytes per record in every copy (tests/test_gpu_big_nd.py closed
+        # form); on one GPU the two-phase shard path (the one N > 1 runs) is run once beside the plain parse
+        sizes = torch.tensor([tl, sl], dtype=torch.int64, device=dev)
+        if distributed:
+            dist.all_reduce(sizes)
+        else:
+            one = (tl, sl)
+            ndshard.run_shard(0, 1, len(shard) == 0, nd_begin, nd_finish, nd_gather, 0)
+            assert (tl, sl) == one, ("shard path and plain ParseND disagree", (tl, sl), one)
+        assert tuple(int(x) for x in sizes) == (80000 * 1000, 256664 * 1000), tuple(int(x) for x in sizes)
         # structurals of the shard: 77 per record + one newline between records
         s_shard = 77 * s_nd + (s_nd - 1)
         algo_nd = (len(shard) + 4 * s_shard) + (4 * s_shard + len(shard) + 8 * tl + sl)

@@ -95,6 +95,10 @@ typedef struct sjhip_multi sjhip_multi;
 sjhip_multi *sjhip_multi_create(const int *devices, int n);
 void sjhip_multi_destroy(sjhip_multi *m);
 int sjhip_multi_shards(const sjhip_multi *m);
+/* the device that holds the tape of shard `shard` after a parse, as the HIP runtime reports it for that allocation
+ * (hipPointerGetAttributes), -1 if the shard has parsed nothing yet: lets a caller (and the tests) see that the shards
+ * really sit on the devices they were asked for */
+int sjhip_multi_shard_device(const sjhip_multi *m, int shard);
 const char *sjhip_multi_last_error(const sjhip_multi *m);
 int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len,
                          size_t *strings_len, size_t *msg_off, size_t *msg_len);
@@ -105,8 +109,12 @@ int sjhip_fetch_multi(sjhip_multi *m, uint64_t *tape_dst, uint8_t *strings_dst);
  * stage-1 error inside one; "1\n2" stays the error it is in Parse()) -- and parsed as one ND document.  The result is
  * what ParseND of that message returns: document i is root i of the tape (Iter.Advance walks them), all string words
  * point into one Strings.B; sjhip_fetch and every query / serializer call work on it.  An empty document or any invalid
- * one fails the whole batch with that document's code (stage 1 before stage 2).  Needs SJHIP_FLAG_COPY_STRINGS.
- * sjhip_parse_batch_device: the documents lie in ONE device buffer at offs[i] (lens[i] bytes, taken untrimmed). */
+ * one fails the whole batch with the code Parse() of that document returns (stage 1 before stage 2) -- including the
+ * end-of-message rule of stage 1 (the last structural must close a container, stage1_find_marks_amd64.go:115-129), to
+ * which every document is held while the batch is packed: a scalar, a truncated or an all-whitespace document is
+ * SJHIP_ERR_STAGE1 wherever it stands.  Needs SJHIP_FLAG_COPY_STRINGS.
+ * sjhip_parse_batch_device: the documents lie in ONE device buffer at offs[i] (lens[i] bytes, taken untrimmed: JSON
+ * whitespace around a document is whitespace of its record). */
 int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *lens, size_t n, uint32_t flags,
                       size_t *tape_len, size_t *strings_len);
 int sjhip_parse_batch_device(sjhip_ctx *ctx, const void *d_buf, const size_t *offs, const size_t *lens, size_t n,

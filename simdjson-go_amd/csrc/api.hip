@@ -64,7 +64,7 @@ sjhip_ctx *sjhip_ctx_create(int device) {
         return nullptr;
     }
     ctx->stream = ctx->own_stream;
-    if (hipHostMalloc((void **)&ctx->h_scratch, 4096, hipHostMallocDefault) != hipSuccess) {
+    if (sj::pinned_alloc((void **)&ctx->h_scratch, 4096) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return nullptr;
@@ -90,6 +90,8 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
                       &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    sj::release_nd_big(ctx);
+    (void)hipSetDevice(ctx->device);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -215,6 +217,10 @@ int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uin
                  size_t *n, int *ok) {
     if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
     invalidate_result(ctx);
+    if (len >= 0xffffffc0ull) {  // before anything is allocated or copied
+        ctx_set_error(ctx, "message too long for uint32 positions (4 GiB - 64)");
+        return SJHIP_ERR_TOOBIG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_msg, len + 128);
     if (rc) return rc;

@@ -7,8 +7,10 @@
 //     batch with the stage-1 code, as Parse() of it would;
 //   * the documents are laid out one behind the other, separated by '\n';
 //   * a raw '\n' INSIDE a document becomes '\r': outside strings both are whitespace, inside a string both are the
-//     same stage-1 error (a control character, find_quote_mask_and_bits_amd64.s:67-80) -- and "1\n2", two roots in a
-//     single document, stays the stage-2 error it is in Parse() instead of turning into two records.
+//     same stage-1 error (a control character, find_quote_mask_and_bits_amd64.s:67-80) -- and "[1]\n[2]", two roots in
+//     a single document, stays the stage-2 error it is in Parse() instead of turning into two records;
+//   * every document must end like Parse() demands of a message (last structural '}' or ']',
+//     stage1_find_marks_amd64.go:115-129): in the packed message only the last document would meet that rule.
 // The result is what ParseND of that message returns: document i is root i of the tape (Iter.Advance walks them), string
 // words point into one Strings.B.  One invalid document fails the whole batch (ParseND semantics).  Needs
 // SJHIP_FLAG_COPY_STRINGS: without it string words would point into the packed message, which the caller never sees.
@@ -31,47 +33,63 @@ struct DocDesc {
     uint64_t len;
 };
 
-// one block row per document (blockIdx.y), 4 KiB per block: copy with '\n' -> '\r'; the block that holds the end of
-// a document writes the separator behind it
-__global__ __launch_bounds__(256) void k_batch_pack(const uint8_t *__restrict__ src, const DocDesc *__restrict__ docs,
-                                                    uint8_t *__restrict__ dst, uint32_t n_docs) {
-    const uint32_t doc = blockIdx.z * 65535u + blockIdx.y;
-    if (doc >= n_docs) return;
-    const DocDesc d = docs[doc];
-    const uint64_t first = (uint64_t)blockIdx.x * 4096;
-    if (first >= d.len) return;
-    const uint8_t *s = src + d.src;
-    uint8_t *o = dst + d.dst;
-    const uint64_t end = first + 4096 < d.len ? first + 4096 : d.len;
-    // 16 bytes per thread where source and destination allow it, bytes otherwise
-    const bool aligned = (((uintptr_t)(s + first) | (uintptr_t)(o + first)) & 15u) == 0;
-    const uint64_t i = first + (uint64_t)threadIdx.x * 16;
-    if (aligned && i + 16 <= end) {
-        uint4 v = *reinterpret_cast<const uint4 *>(s + i);
-        v.x = sj::newlines_to_cr(v.x); v.y = sj::newlines_to_cr(v.y); v.z = sj::newlines_to_cr(v.z); v.w = sj::newlines_to_cr(v.w);
-        *reinterpret_cast<uint4 *>(o + i) = v;
-    } else {
-        for (uint64_t k = i; k < i + 16 && k < end; k++) {
-            const uint8_t b = s[k];
-            o[k] = b == '\n' ? (uint8_t)'\r' : b;
-        }
+// The document that holds byte `p` of the packed message (or whose separator it is): the last one with dst <= p
+__device__ __forceinline__ uint32_t doc_of(const DocDesc *__restrict__ docs, uint32_t n_docs, uint64_t p) {
+    uint32_t lo = 0, hi = n_docs;  // docs[lo].dst <= p < docs[hi].dst
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (docs[mid].dst <= p) lo = mid;
+        else hi = mid;
     }
-    if (end == d.len && threadIdx.x == 0 && doc + 1 < n_docs) o[d.len] = '\n';
+    return lo;
+}
+// Parse() of a document fails in stage 1 unless its last structural is '}' or ']' (stage1_find_marks_amd64.go:115-129)
+// -- a scalar, a truncated document, an empty or all-whitespace one.  Inside a batch only the last document meets that
+// check, so every document is held to it here: the last byte that is not JSON whitespace must close a container.
+__device__ __forceinline__ bool doc_end_ok(const uint8_t *__restrict__ s, uint64_t len) {
+    while (len != 0) {
+        const uint8_t b = s[len - 1];
+        if (b == ' ' || b == '\t' || b == '\n' || b == '\r') len--;
+        else return b == '}' || b == ']';
+    }
+    return false;
 }
 
-// in place: the documents are already where they belong (host packing): only the translation and the separators
-__global__ __launch_bounds__(256) void k_batch_fix(uint8_t *__restrict__ msg, const DocDesc *__restrict__ docs, uint32_t n_docs) {
-    const uint32_t doc = blockIdx.z * 65535u + blockIdx.y;
-    if (doc >= n_docs) return;
-    const DocDesc d = docs[doc];
-    const uint64_t first = (uint64_t)blockIdx.x * 4096;
-    if (first >= d.len) return;
-    uint8_t *o = msg + d.dst;
-    const uint64_t end = first + 4096 < d.len ? first + 4096 : d.len;
-    const uint64_t i = first + (uint64_t)threadIdx.x * 16;
-    for (uint64_t k = i; k < i + 16 && k < end; k++)
-        if (o[k] == '\n') o[k] = '\r';
-    if (end == d.len && threadIdx.x == 0 && doc + 1 < n_docs) o[d.len] = '\n';
+// One block per 4 KiB of the PACKED message (a grid over the longest document times the number of documents launches
+// billions of empty blocks for one 100 MB document among a million small ones): a thread owns 16 packed bytes, finds
+// its document with a binary search over the descriptors and walks on from there -- copy with '\n' -> '\r', the
+// separator behind every document but the last, and the end check of the documents whose last byte it owns.
+// IN_PLACE: the documents already lie at their packed offsets (host packing), only translation and separators.
+template <bool IN_PLACE>
+__global__ __launch_bounds__(256) void k_batch_pack(const uint8_t *__restrict__ src, const DocDesc *__restrict__ docs,
+                                                    uint8_t *__restrict__ dst, uint32_t n_docs, uint64_t total,
+                                                    unsigned int *bad_host) {
+    const uint64_t p0 = (uint64_t)blockIdx.x * 4096 + (uint64_t)threadIdx.x * 16;
+    if (p0 >= total) return;
+    const uint64_t p1 = p0 + 16 < total ? p0 + 16 : total;
+    uint32_t k = doc_of(docs, n_docs, p0);
+    DocDesc d = docs[k];
+    bool bad = false;
+    if (p1 <= d.dst + d.len && p0 + 16 == p1 && (IN_PLACE || (((uintptr_t)(src + d.src + (p0 - d.dst)) | (uintptr_t)(dst + p0)) & 15u) == 0)) {
+        // sixteen bytes of one document
+        uint4 v = *reinterpret_cast<const uint4 *>(IN_PLACE ? dst + p0 : src + d.src + (p0 - d.dst));
+        v.x = sj::newlines_to_cr(v.x); v.y = sj::newlines_to_cr(v.y); v.z = sj::newlines_to_cr(v.z); v.w = sj::newlines_to_cr(v.w);
+        *reinterpret_cast<uint4 *>(dst + p0) = v;
+        if (!IN_PLACE && p1 == d.dst + d.len) bad = !doc_end_ok(src + d.src, d.len);
+    } else {
+        for (uint64_t p = p0; p < p1; p++) {
+            while (k + 1 < n_docs && docs[k + 1].dst <= p) d = docs[++k];
+            const uint64_t off = p - d.dst;
+            if (off < d.len) {
+                const uint8_t b = IN_PLACE ? dst[p] : src[d.src + off];
+                dst[p] = b == '\n' ? (uint8_t)'\r' : b;
+                if (!IN_PLACE && off + 1 == d.len) bad |= !doc_end_ok(src + d.src, d.len);
+            } else {
+                dst[p] = '\n';  // the separator behind document k
+            }
+        }
+    }
+    if (bad) __hip_atomic_store(bad_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -86,7 +104,7 @@ static int batch_common(sjhip_ctx *ctx, size_t n, uint32_t flags, size_t *tape_l
         return SJHIP_ERR_ARG;
     }
     if (n == 0) return SJHIP_ERR_STAGE1;  // like Parse of an empty message
-    if (n > 65535ull * 65535ull) {
+    if (n > 0xfffffff0ull) {
         sj::ctx_set_error(ctx, "sjhip_parse_batch: too many documents in one call");
         return SJHIP_ERR_TOOBIG;
     }
@@ -114,15 +132,17 @@ int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *
     if (hipSetDevice(ctx->device) != hipSuccess) return SJHIP_ERR_HIP;
     std::vector<DocDesc> docs(n);
     std::vector<size_t> host_off(n);
-    uint64_t total = 0, longest = 0;
+    uint64_t total = 0;
     for (size_t k = 0; k < n; k++) {
         size_t off = 0, ln = 0;
         if (lens[k] && msgs[k]) sj::trim_space(msgs[k], lens[k], &off, &ln);
         if (ln == 0) return SJHIP_ERR_STAGE1;
+        // Parse() of this document alone fails in stage 1 unless its last structural closes a container
+        // (stage1_find_marks_amd64.go:115-129); inside the packed message only the last document meets that check
+        if (msgs[k][off + ln - 1] != '}' && msgs[k][off + ln - 1] != ']') return SJHIP_ERR_STAGE1;
         host_off[k] = off;
         docs[k] = DocDesc{0, total, ln};
         total += ln + (k + 1 < n ? 1 : 0);
-        if (ln > longest) longest = ln;
     }
     if (total > 0xffffffc0ull) {
         sj::ctx_set_error(ctx, "sjhip_parse_batch: the packed message exceeds 4 GiB");
@@ -131,10 +151,10 @@ int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *
     rc = sj::arena_reserve(ctx, ctx->d_msg, total + 128);
     if (rc) return rc;
     // H2D.  A copy command costs microseconds whatever it moves, so consecutive small documents are gathered in a pinned
-    // block at their packed offsets (the separator bytes between them are written by k_batch_fix) and travel as one
+    // block at their packed offsets (the separator bytes between them are written by k_batch_pack<true>) and travel as one
     // copy; a document of STAGE_DOC bytes or more goes straight from the caller's buffer.
     constexpr size_t STAGE_DOC = 64 << 10, STAGE_CAP = 32 << 20;
-    if (!ctx->h_stage && hipHostMalloc((void **)&ctx->h_stage, STAGE_CAP, hipHostMallocDefault) == hipSuccess) ctx->h_stage_cap = STAGE_CAP;
+    if (!ctx->h_stage && sj::pinned_alloc((void **)&ctx->h_stage, STAGE_CAP) == hipSuccess) ctx->h_stage_cap = STAGE_CAP;
     if (!ctx->h_stage) (void)hipGetLastError();  // (no pinned memory: every document is copied on its own)
     auto h2d = [&](uint64_t dst, const void *src, size_t bytes) {
         return hipMemcpyAsync((uint8_t *)ctx->d_msg.p + dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
@@ -173,8 +193,8 @@ int sjhip_parse_batch(sjhip_ctx *ctx, const uint8_t *const *msgs, const size_t *
     const DocDesc *d_docs = nullptr;
     rc = upload_docs(ctx, docs, &d_docs);
     if (rc) return rc;
-    const dim3 grid((unsigned)((longest + 4095) / 4096), (unsigned)(n < 65535 ? n : 65535), (unsigned)((n + 65534) / 65535));
-    hipLaunchKernelGGL(k_batch_fix, grid, dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_msg.p, d_docs, (uint32_t)n);
+    hipLaunchKernelGGL(k_batch_pack<true>, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, ctx->stream, (const uint8_t *)nullptr, d_docs,
+                       (uint8_t *)ctx->d_msg.p, (uint32_t)n, (uint64_t)total, (unsigned int *)nullptr);
     if (hipGetLastError() != hipSuccess) return SJHIP_ERR_HIP;
     const size_t last = n - 1;
     uint8_t last_byte = msgs[last][host_off[last] + docs[last].len - 1];
@@ -188,15 +208,16 @@ int sjhip_parse_batch_device(sjhip_ctx *ctx, const void *d_buf, const size_t *of
     if (rc) return rc;
     if (!d_buf || !offs || !lens) return SJHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SJHIP_ERR_HIP;
-    // the documents are on the device: they are taken as they are (no trimming -- leading / trailing whitespace of a
-    // document is whitespace of its record) except that an empty document is refused
+    // the documents are on the device: they are taken as they are (no trimming -- leading / trailing JSON whitespace of a
+    // document is whitespace of its record); a document whose last non-whitespace byte does not close a container --
+    // an empty or all-whitespace one, a scalar, a truncated one -- fails the batch with the stage-1 code like Parse()
+    // of it would (checked on the device while the documents are packed)
     std::vector<DocDesc> docs(n);
-    uint64_t total = 0, longest = 0;
+    uint64_t total = 0;
     for (size_t k = 0; k < n; k++) {
         if (lens[k] == 0) return SJHIP_ERR_STAGE1;
         docs[k] = DocDesc{offs[k], total, lens[k]};
         total += lens[k] + (k + 1 < n ? 1 : 0);
-        if (lens[k] > longest) longest = lens[k];
     }
     if (total > 0xffffffc0ull) {
         sj::ctx_set_error(ctx, "sjhip_parse_batch_device: the packed message exceeds 4 GiB");
@@ -207,8 +228,22 @@ int sjhip_parse_batch_device(sjhip_ctx *ctx, const void *d_buf, const size_t *of
     const DocDesc *d_docs = nullptr;
     rc = upload_docs(ctx, docs, &d_docs);
     if (rc) return rc;
-    const dim3 grid((unsigned)((longest + 4095) / 4096), (unsigned)(n < 65535 ? n : 65535), (unsigned)((n + 65534) / 65535));
-    hipLaunchKernelGGL(k_batch_pack, grid, dim3(256), 0, ctx->stream, (const uint8_t *)d_buf, d_docs, (uint8_t *)ctx->d_msg.p, (uint32_t)n);
+    // the end check of every document (doc_end_ok) reports through a word of the context's pinned scratch block; the
+    // parse below synchronises the stream, after which the word is final
+    volatile unsigned int *bad = (volatile unsigned int *)(ctx->h_scratch + 1024);
+    *bad = 0;
+    hipLaunchKernelGGL(k_batch_pack<false>, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, ctx->stream, (const uint8_t *)d_buf, d_docs,
+                       (uint8_t *)ctx->d_msg.p, (uint32_t)n, (uint64_t)total, (unsigned int *)bad);
     if (hipGetLastError() != hipSuccess) return SJHIP_ERR_HIP;
-    return sj::parse_packed(ctx, (size_t)total, flags | SJHIP_FLAG_NDJSON, 0, 0, tape_len, strings_len);
+    rc = sj::parse_packed(ctx, (size_t)total, flags | SJHIP_FLAG_NDJSON, 0, 0, tape_len, strings_len);
+    if (rc != SJHIP_OK && rc != SJHIP_ERR_STAGE1 && rc != SJHIP_ERR_STAGE2) return rc;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return SJHIP_ERR_HIP;  // (a parse that failed early may not have waited)
+    if (*bad) {  // a document that Parse() rejects in stage 1: that code wins (parse_json_amd64.go:97-105,123-126)
+        ctx->tape_len = ctx->strings_len = 0;
+        ctx->q_valid = ctx->pack_valid = 0;
+        if (tape_len) *tape_len = 0;
+        if (strings_len) *strings_len = 0;
+        return SJHIP_ERR_STAGE1;
+    }
+    return rc;
 }

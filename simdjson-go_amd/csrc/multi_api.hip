@@ -74,6 +74,17 @@ void sjhip_multi_destroy(sjhip_multi *m) {
 
 int sjhip_multi_shards(const sjhip_multi *m) { return m ? (int)m->shards.size() : 0; }
 const char *sjhip_multi_last_error(const sjhip_multi *m) { return m ? m->err : "no handle"; }
+int sjhip_multi_shard_device(const sjhip_multi *m, int shard) {
+    if (!m || shard < 0 || (size_t)shard >= m->shards.size()) return -1;
+    const sjhip_ctx *c = m->shards[(size_t)shard].ctx;
+    if (!c || !c->d_tape.p) return -1;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, c->d_tape.p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return at.device;
+}
 
 // runs f(shard) for every shard on its own host thread (one shard: on the caller's)
 template <typename F>
@@ -103,13 +114,66 @@ static int agree(sjhip_multi *m, const char *phase) {
     return code;
 }
 
-int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len, size_t *strings_len,
-                         size_t *msg_off, size_t *msg_len) {
+// A message that lies in device memory is only looked at through small windows copied to the host: the record cuts and
+// the whitespace at the ends of every shard (the reference trims what it parses, simdjson_amd64.go:87,
+// parse_json_amd64.go:55).  JSON whitespace and the other ASCII blanks bytes.TrimSpace removes; a shard of a
+// device-resident message that ends in a multi-byte Unicode blank keeps it (and fails like any other stray byte).
+namespace {
+constexpr size_t WINDOW = 64 << 10;
+struct DevPeek {
+    const uint8_t *d_msg;
+    std::vector<uint8_t> buf = std::vector<uint8_t>(WINDOW);
+    bool ok = true;
+    const uint8_t *get(size_t at, size_t n) {  // n <= WINDOW
+        if (hipMemcpy(buf.data(), d_msg + at, n, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        return buf.data();
+    }
+    // first '\n' at or behind `from` (len if there is none)
+    size_t find_newline(size_t from, size_t len) {
+        for (size_t at = from; at < len && ok; at += WINDOW) {
+            const size_t n = len - at < WINDOW ? len - at : WINDOW;
+            const void *nl = memchr(get(at, n), '\n', n);
+            if (nl) return at + (size_t)((const uint8_t *)nl - buf.data());
+        }
+        return len;
+    }
+    static bool blank(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+    void trim(size_t a, size_t b, size_t *off, size_t *ln) {  // [a, b) without the ASCII blanks at its ends
+        while (a < b && ok) {
+            const size_t n = b - a < WINDOW ? b - a : WINDOW;
+            const uint8_t *w = get(a, n);
+            size_t k = 0;
+            while (k < n && blank(w[k])) k++;
+            a += k;
+            if (k < n) break;
+        }
+        while (b > a && ok) {
+            const size_t n = b - a < WINDOW ? b - a : WINDOW;
+            const uint8_t *w = get(b - n, n);
+            size_t k = n;
+            while (k > 0 && blank(w[k - 1])) k--;
+            b -= n - k;
+            if (k > 0) break;
+        }
+        *off = a;
+        *ln = b - a;
+    }
+};
+}  // namespace
+
+// msg: host memory, or (d_resident) device memory of the device every shard of m runs on -- then nothing is copied, a
+// shard parses its window of the message in place
+static int multi_parse(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, bool d_resident, size_t *tape_len,
+                       size_t *strings_len, size_t *msg_off, size_t *msg_len) {
     if (!m || m->shards.empty()) return SJHIP_ERR_ARG;
     m->valid = 0;
     m->tape_len = m->strings_len = 0;
+    DevPeek peek{msg};
     size_t g_off = 0, g_len = 0;
-    if (len) sj::trim_space(msg, len, &g_off, &g_len);  // pj.Message = bytes.TrimSpace(msg), parse_json_amd64.go:55
+    if (len) {
+        if (d_resident) peek.trim(0, len, &g_off, &g_len);
+        else sj::trim_space(msg, len, &g_off, &g_len);  // pj.Message = bytes.TrimSpace(msg), parse_json_amd64.go:55
+    }
     if (msg_off) *msg_off = g_off;
     if (msg_len) *msg_len = g_len;
     if (tape_len) *tape_len = 0;
@@ -126,16 +190,32 @@ int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_
         if (k + 1 < n) {
             size_t target = len * (k + 1) / n;
             if (target < cut) target = cut;
-            const void *nl = target < len ? memchr(msg + target, '\n', len - target) : nullptr;
-            end = nl ? (size_t)((const uint8_t *)nl - msg) + 1 : len;
+            if (d_resident) {
+                const size_t nl = peek.find_newline(target, len);
+                end = nl < len ? nl + 1 : len;
+            } else {
+                const void *nl = target < len ? memchr(msg + target, '\n', len - target) : nullptr;
+                end = nl ? (size_t)((const uint8_t *)nl - msg) + 1 : len;
+            }
         }
         size_t off = 0, ln = 0;
-        if (end > cut) sj::trim_space(msg + cut, end - cut, &off, &ln);
+        if (end > cut) {
+            if (d_resident) {
+                peek.trim(cut, end, &off, &ln);
+                off -= cut;
+            } else {
+                sj::trim_space(msg + cut, end - cut, &off, &ln);
+            }
+        }
         s.start = cut + off;
         s.len = ln;
         s.tape_len = s.strings_len = 0;
         s.rc = 0;
         cut = end;
+    }
+    if (!peek.ok) {
+        snprintf(m->err, sizeof m->err, "reading the device-resident message failed");
+        return SJHIP_ERR_HIP;
     }
     const uint32_t fl = flags | SJHIP_FLAG_NDJSON;
     for_shards(m, [&](Shard &s) {  // phase 1
@@ -143,6 +223,10 @@ int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_
         sjhip_ctx *ctx = s.ctx;
         if (hipSetDevice(s.device) != hipSuccess) {
             s.rc = SJHIP_ERR_HIP;
+            return;
+        }
+        if (d_resident) {
+            s.rc = sjhip_parse_shard_begin(ctx, msg + s.start, s.len, fl, &s.tape_len, &s.strings_len);
             return;
         }
         s.rc = sj::arena_reserve(ctx, ctx->d_msg, s.len + 128);
@@ -178,6 +262,58 @@ int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_
     if (tape_len) *tape_len = t;
     if (strings_len) *strings_len = b;
     return SJHIP_OK;
+}
+
+int sjhip_parse_nd_multi(sjhip_multi *m, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len, size_t *strings_len,
+                         size_t *msg_off, size_t *msg_len) {
+    return multi_parse(m, msg, len, flags, false, tape_len, strings_len, msg_off, msg_len);
+}
+
+// ---- ND messages beyond one context's reach (uint32 positions: 4 GiB - 64) ----------------------------------------------
+// The reference parses "arbitrarily large" ND inputs (README.md:567-569: its index stream is deltas,
+// flatten_bits_amd64.s:38-41).  Here sjhip_parse / sjhip_parse_device hand such a message to a multi handle the context
+// owns: shards of at most `shard_bytes` cut at record boundaries, every shard on its own context with absolute uint32
+// positions inside the shard and 64-bit bases added on the device -- the sharded ParseND path, on one device or, for a
+// host message, round robin over every visible one.  All shards are resident at once (their tapes wait for sjhip_fetch).
+int sj::parse_nd_big(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, bool d_resident, size_t shard_bytes,
+                     size_t *tape_len, size_t *strings_len, size_t *msg_off, size_t *msg_len) {
+    const size_t want = (len + shard_bytes - 1) / shard_bytes;
+    if (want > 4096) {
+        sj::ctx_set_error(ctx, "ND message of %zu bytes: more than 4096 shards", len);
+        return SJHIP_ERR_TOOBIG;
+    }
+    if (ctx->big && (size_t)sjhip_multi_shards(ctx->big) != want) {
+        sjhip_multi_destroy(ctx->big);
+        ctx->big = nullptr;
+    }
+    if (!ctx->big) {
+        const int have = sjhip_device_count();
+        std::vector<int> devs(want);
+        // a device-resident message is parsed where it lies; a host message uses every visible device, this one first
+        for (size_t k = 0; k < want; k++) devs[k] = d_resident || have < 1 ? ctx->device : (int)((ctx->device + k) % (size_t)have);
+        ctx->big = sjhip_multi_create(devs.data(), (int)want);
+        if (!ctx->big) {
+            sj::ctx_set_error(ctx, "ND message of %zu bytes: no contexts for %zu shards", len, want);
+            return SJHIP_ERR_HIP;
+        }
+    }
+    ctx->big_valid = 0;
+    const int rc = multi_parse(ctx->big, msg, len, flags, d_resident, tape_len, strings_len, msg_off, msg_len);
+    if (rc == SJHIP_OK) ctx->big_valid = 1;
+    else if (rc != SJHIP_ERR_STAGE1 && rc != SJHIP_ERR_STAGE2) sj::ctx_set_error(ctx, "%s", sjhip_multi_last_error(ctx->big));
+    (void)hipSetDevice(ctx->device);
+    return rc;
+}
+int sj::fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
+    const int rc = sjhip_fetch_multi(ctx->big, tape_dst, strings_dst);
+    if (rc) sj::ctx_set_error(ctx, "%s", sjhip_multi_last_error(ctx->big));
+    (void)hipSetDevice(ctx->device);
+    return rc;
+}
+void sj::release_nd_big(sjhip_ctx *ctx) {
+    if (ctx->big) sjhip_multi_destroy(ctx->big);
+    ctx->big = nullptr;
+    ctx->big_valid = 0;
 }
 
 int sjhip_fetch_multi(sjhip_multi *m, uint64_t *tape_dst, uint8_t *strings_dst) {

@@ -25,6 +25,8 @@ using namespace sj;
 // documents up to this size are parsed with one host synchronisation (SJHIP_SMALL_BYTES overrides; 0 turns it off)
 static constexpr size_t PACK_BYTES = (size_t)2 << 20;  // pinned block for the results of small documents (sj_ctx.h h_pack)
 
+static constexpr int PARSE_AGAIN_SYNCHRONOUS = -1000;  // internal: parse_finish -> parse_on_device
+
 static size_t small_document_bytes() {
     static const size_t v = [] {
         const char *e = getenv("SJHIP_SMALL_BYTES");
@@ -76,9 +78,29 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     return a;
 }
 
+// One context parses messages of up to 4 GiB - 64 bytes (uint32 positions).  A longer ND message is cut into shards of
+// SJHIP_ND_SHARD_BYTES (default 1 GiB) at record boundaries -- SJHIP_ND_LIMIT_BYTES moves the threshold (tests: the
+// sharded path on documents of a few megabytes).  A single document beyond the limit is SJHIP_ERR_TOOBIG: it does not
+// shard, and the reference's own tape could hold it only because its index stream is deltas.
+static constexpr size_t ND_LIMIT = 0xffffffc0ull - 64;
+static size_t env_bytes(const char *name, size_t dflt) {
+    const char *e = getenv(name);
+    const size_t v = e ? (size_t)strtoull(e, nullptr, 0) : 0;
+    return v ? v : dflt;
+}
+static bool nd_too_big(size_t len, uint32_t flags) {
+    if (!(flags & SJHIP_FLAG_NDJSON)) return false;
+    return len > (len > (1u << 20) ? env_bytes("SJHIP_ND_LIMIT_BYTES", ND_LIMIT) : ND_LIMIT);
+}
+static size_t nd_shard_bytes() {
+    const size_t v = env_bytes("SJHIP_ND_SHARD_BYTES", (size_t)1 << 30);
+    return v < ND_LIMIT ? v : ND_LIMIT;
+}
+
 static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte, int have_last,
                        size_t *tape_len, size_t *strings_len) {
     ctx->tape_len = ctx->strings_len = 0;
+    ctx->big_valid = 0;
     ctx->pending = 0;
     ctx->pack_valid = 0;
     ctx->q_valid = 0;
@@ -86,6 +108,10 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->ms_valid = 0;
     ctx->f_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
+    if (len > ND_LIMIT) {  // (an ND message of this size went to parse_nd_big; a single document does not shard)
+        ctx_set_error(ctx, "document of %zu bytes: one context parses up to 4 GiB - 128 (uint32 positions); only ND messages are sharded", len);
+        return SJHIP_ERR_TOOBIG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // One position (4 B) and one kind (1 B) per message byte is the worst case (every byte a structural): 5 bytes per
     // input byte of a grow-only, recycled arena -- 1.3 GB for configs[1] on a 288 GB device -- instead of guessing a
@@ -111,11 +137,15 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         // A small document is not worth a host round trip in the middle: stage 2 is queued behind stage 1 with arenas
         // and grids sized for the upper bound (a token is at least one byte), the kernels read the token count on the
         // device, and stage 1's verdict is taken after the one synchronisation at the end.  (A shard needs its sizes first.)
-        ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes();
+        ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes() && !ctx->p_no_defer;
         if (ctx->p_deferred) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
-            n = len;
+            // The stage-2 arrays are laid out for one token per four bytes (the densest fixture, marine_ik, has 0.22):
+            // ~14 B of arena per message byte instead of 57.  The kernels clamp the device-side count to this layout
+            // (stage2.hip token_count), so a denser document stays in bounds and is parsed again the synchronous way
+            // (parse_on_device) once stage 1's real count is known.
+            n = len / 4 + 4096 < len ? len / 4 + 4096 : len;
             ok = 1;
             ctx->p_last = last_byte;
             ctx->p_have_last = have_last;
@@ -171,7 +201,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     const bool pack = ctx->want_pack && ctx->p_deferred && tape_base == 0 && strings_base == 0 && msg_base == 0;
     ctx->want_pack = 0;
     ctx->pack_valid = 0;
-    if (pack && !ctx->h_pack && hipHostMalloc((void **)&ctx->h_pack, PACK_BYTES, hipHostMallocDefault) != hipSuccess) {
+    if (pack && !ctx->h_pack && sj::pinned_alloc((void **)&ctx->h_pack, PACK_BYTES) != hipSuccess) {
         (void)hipGetLastError();
         ctx->h_pack = nullptr;
     }
@@ -203,6 +233,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         rc = stage1_collect(ctx, ctx->p_len, ctx->p_last, ctx->p_have_last, &n, &ok);
         if (rc) return rc;
         if (!ok) return SJHIP_ERR_STAGE1;
+        if (n > ctx->p_nlay) return PARSE_AGAIN_SYNCHRONOUS;  // denser than the layout assumed: nothing of this run counts
         ctx->p_n = n;  // (the arrays stay laid out for p_nlay)
     }
     if ((hs->err & S2_ERR_SERIAL_STRINGS) && ctx->p_aux) {
@@ -234,9 +265,19 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
 
 static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, uint8_t last_byte,
                            int have_last, size_t *tape_len, size_t *strings_len) {
+    const int want_pack = ctx->want_pack;
     int rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
     if (rc) return rc;
-    return parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
+    rc = parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
+    if (rc == PARSE_AGAIN_SYNCHRONOUS) {  // a small document with more than one token per four bytes
+        ctx->p_no_defer = 1;
+        ctx->want_pack = want_pack;
+        rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
+        ctx->p_no_defer = 0;
+        if (rc) return rc;
+        rc = parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
+    }
+    return rc;
 }
 
 // batch_api.hip: the whole parse of the message it packed into the context's message arena
@@ -260,6 +301,13 @@ int sjhip_parse_shard_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t string
 int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,
                        size_t *strings_len) {
     if (!ctx) return SJHIP_ERR_ARG;
+    if (nd_too_big(len, flags)) {  // shards on this device, each parsing its window of the message in place
+        ctx->tape_len = ctx->strings_len = 0;
+        ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
+        HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync");  // (the shards run on streams of their own)
+        return parse_nd_big(ctx, (const uint8_t *)d_msg, len, flags, true, nd_shard_bytes(), tape_len, strings_len, nullptr, nullptr);
+    }
     return parse_on_device(ctx, d_msg, len, flags, 0, 0, tape_len, strings_len);
 }
 
@@ -273,7 +321,16 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
     if (tape_len) *tape_len = 0;
     if (strings_len) *strings_len = 0;
     ctx->tape_len = ctx->strings_len = 0;
+    ctx->big_valid = 0;
     if (mlen == 0) return SJHIP_ERR_STAGE1;
+    if (nd_too_big(mlen, flags)) {  // shards of the host message, H2D straight from the caller's buffer
+        ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
+        return parse_nd_big(ctx, msg, len, flags, false, nd_shard_bytes(), tape_len, strings_len, nullptr, nullptr);
+    }
+    if (mlen > ND_LIMIT) {  // before 4 GiB are copied to the device
+        ctx_set_error(ctx, "document of %zu bytes: one context parses up to 4 GiB - 128 (uint32 positions); only ND messages are sharded", mlen);
+        return SJHIP_ERR_TOOBIG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_msg, mlen + 128);
     if (rc) return rc;
@@ -293,6 +350,7 @@ void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_l
 
 int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
     if (!ctx) return SJHIP_ERR_ARG;
+    if (ctx->big_valid) return fetch_nd_big(ctx, tape_dst, strings_dst);  // every shard straight into its slice
     if (ctx->pack_valid && ctx->h_pack) {  // the result of a small sjhip_parse is already in pinned host memory
         if (ctx->tape_len && tape_dst) memcpy(tape_dst, ctx->h_pack + STAGE2_PACK_HEAD, ctx->tape_len * sizeof(uint64_t));
         if (ctx->strings_len && strings_dst)

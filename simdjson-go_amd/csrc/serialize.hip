@@ -416,7 +416,8 @@ __device__ __forceinline__ void des_shape(u8 t, u32 &words, u32 &bytes, bool &ok
     default: words = 0; bytes = 0; ok = false; break;  // incl. TagNop
     }
 }
-template <bool EMIT>
+// MODE 0: per-tile counts; 1: the scatter pass; 2: verification of what the scatter pass left (closing brackets)
+template <int MODE>
 __global__ __launch_bounds__(DS_THREADS) void k_des_tile(DesView p) {
     __shared__ unsigned long long s_s[DS_THREADS / 64];
     const int tid = threadIdx.x;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_des_tile(DesView p) {
     }
     unsigned long long tot = 0;
     const unsigned long long ex = block_excl_sum(((unsigned long long)nv << 24) | nw, s_s, tid, &tot);
-    if (!EMIT) {
+    if (MODE == 0) {
         if (tid == 0) {
             p.cnt_w[blockIdx.x] = tot & 0xffffffu;
             p.cnt_v[blockIdx.x] = tot >> 24;
@@ -460,6 +461,27 @@ __global__ __launch_bounds__(DS_THREADS) void k_des_tile(DesView p) {
         }
         const u64 tag = (u64)tg[k] << 56;
         const u64 *v = reinterpret_cast<const u64 *>(p.vals + vo);
+        if (MODE == 2) {
+            // The reference walks the tags in order and checks, when it reaches a closing bracket, that the word its
+            // opener left there carries the same tag (parsed_serialize.go:666-671).  Here the scatter pass ran in
+            // parallel, so both ends are checked: a closing tag must sit on a word of its kind whose payload is an
+            // opener in front of it that points right behind it -- a slot no opener of THIS stream wrote would still hold
+            // a word of the previous parse -- and an opener must still own its closing slot (two openers claiming one
+            // slot, or a distance that does not reach past the opener itself, are corrupt streams).
+            if (tg[k] == '}' || tg[k] == ']') {
+                const u64 w = p.tape[off], j = w & PAYLOAD;
+                const u8 open = tg[k] == '}' ? (u8)'{' : (u8)'[';
+                if ((w >> 56) != tg[k] || j >= off || p.tape[j] != (((u64)open << 56) | (off + 1))) bad = true;
+            } else if (tg[k] == '{' || tg[k] == '[') {
+                const u64 val = v[0] + off;
+                if (val < off + 2 || val > p.tape_len ||
+                    p.tape[val - 1] != (((u64)(tg[k] == '{' ? '}' : ']') << 56) | off))
+                    bad = true;
+            }
+            off += words;
+            vo += bytes;
+            continue;
+        }
         switch (tg[k]) {
         case '"':
             p.tape[off] = tag | v[0];
@@ -474,8 +496,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_des_tile(DesView p) {
             p.tape[off + 1] = v[0];
             break;
         case '{': case '[': {
-            const u64 val = v[0] + off;  // always forward
-            if (val > p.tape_len || val == 0) {
+            const u64 val = v[0] + off;  // always forward, and past the opener itself
+            if (val > p.tape_len || val < off + 2) {
                 bad = true;
                 break;
             }
@@ -585,15 +607,16 @@ int sjhip_deserialize(sjhip_ctx *ctx, const uint8_t *stream, size_t len, size_t 
     if (ss) HIPCHK(hipMemcpyAsync(ctx->d_strings.p, stream + off_s, ss, hipMemcpyHostToDevice, ctx->stream), "H2D strings");
     if (ms) HIPCHK(hipMemcpyAsync(ctx->d_msg.p, stream + off_m, ms, hipMemcpyHostToDevice, ctx->stream), "H2D message");
     if (p.tiles) {
-        hipLaunchKernelGGL(k_des_tile<false>, dim3(p.tiles), dim3(DS_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_des_tile<0>, dim3(p.tiles), dim3(DS_THREADS), 0, ctx->stream, p);
         hipLaunchKernelGGL(k_ser_scan_cnt, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_w, p.cnt_v, (unsigned long long *)nullptr, p.tiles, p.totals);
-        hipLaunchKernelGGL(k_des_tile<true>, dim3(p.tiles), dim3(DS_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_des_tile<1>, dim3(p.tiles), dim3(DS_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_des_tile<2>, dim3(p.tiles), dim3(DS_THREADS), 0, ctx->stream, p);
         HIPCHK(hipGetLastError(), "deserialize launch");
     }
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
     HIPCHK(hipMemcpyAsync(h, p.totals, 32, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
     HIPCHK(hipStreamSynchronize(ctx->stream), "deserialize sync");
-    if (h[3] != 0) return corrupt("unknown tag, or a value beyond the tape (TagNop entries are not read on the device)");
+    if (h[3] != 0) return corrupt("unknown tag, a value beyond the tape, or a closing bracket without its opener (TagNop entries are not read on the device)");
     if (h[0] != tl) return corrupt("tags did not fill tape");
     if (h[1] != nv) return corrupt("values did not fill tape");
     ctx->tape_len = (size_t)tl;

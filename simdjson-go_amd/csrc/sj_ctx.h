@@ -47,6 +47,7 @@ struct sjhip_ctx {
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
     int p_deferred = 0;   // stage 1's result has not been collected yet (small documents: one synchronisation per parse)
+    int p_no_defer = 0;   // the deferred run met more tokens than its layout holds: this parse takes the synchronous path
     uint8_t p_last = 0;   // ... its caller-supplied last byte
     int p_have_last = 0;
     size_t p_nlay = 0;    // the token count the stage-2 arrays were laid out for (>= p_n)
@@ -55,15 +56,27 @@ struct sjhip_ctx {
     uint32_t p_flags = 0;
     void *p_aux = nullptr;
     uint8_t *p_kind = nullptr;  // token kinds of the pending parse (behind the positions in d_pos)
+    // an ND message beyond 4 GiB - 64 is parsed shard by shard by a multi handle the context owns (multi_api.hip
+    // parse_nd_big); the merged result waits there for sjhip_fetch
+    struct sjhip_multi *big = nullptr;
+    int big_valid = 0;
     char err[256];
 };
 
 namespace sj {
+// Pinned host memory of the library: portable (every device context may use it, not only the one that was current when
+// it was allocated -- streams and multi handles own contexts on several devices) and mapped (kernels of any of them
+// write results straight into it: the stage-1 verdict word, k_pack, the batch end check).
+inline hipError_t pinned_alloc(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocPortable | hipHostMallocMapped); }
 void ctx_set_error(sjhip_ctx *ctx, const char *fmt, ...);
 int ctx_hip_fail(sjhip_ctx *ctx, hipError_t e, const char *what);
 int arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes);
 int parse_packed(sjhip_ctx *ctx, size_t len, uint32_t flags, uint8_t last_byte, int have_last, size_t *tape_len,
                  size_t *strings_len);  // parse_api.hip
+int parse_nd_big(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, bool d_resident, size_t shard_bytes,
+                 size_t *tape_len, size_t *strings_len, size_t *msg_off, size_t *msg_len);  // multi_api.hip
+int fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
+void release_nd_big(sjhip_ctx *ctx);
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                    uint8_t *d_kind, void *zero2, size_t zero2_bytes);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);

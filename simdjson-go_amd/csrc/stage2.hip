@@ -105,7 +105,12 @@ struct S2Dev {
 #else
 #define SJ_EXPBIT(p, b) false
 #endif
-__device__ __forceinline__ u32 token_count(const S2Dev &p) { return p.n_dev ? (u32)*p.n_dev : p.n; }
+// (clamped to the layout: a small document denser than the host assumed stays in bounds and is parsed again, parse_api.hip)
+__device__ __forceinline__ u32 token_count(const S2Dev &p) {
+    if (!p.n_dev) return p.n;
+    const unsigned long long n = *p.n_dev;
+    return n < p.n ? (u32)n : p.n;
+}
 
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
 // The general string routine of a unit, escape by escape instead of chunk by chunk.  sj_strings.h str_chunk_masks is the

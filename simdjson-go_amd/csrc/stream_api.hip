@@ -72,7 +72,7 @@ static int grow_pinned(void **p, size_t *cap, size_t want) {
     *p = nullptr;
     *cap = 0;
     const size_t n = want + want / 4 + 4096;
-    if (hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) return SJHIP_ERR_HIP;
+    if (sj::pinned_alloc(p, n) != hipSuccess) return SJHIP_ERR_HIP;
     *cap = n;
     return 0;
 }
@@ -136,7 +136,7 @@ sjhip_stream *sjhip_stream_create(int first_device, int n_devices, size_t block_
         sl.device = first_device + k % n_devices;
         sl.ctx = sjhip_ctx_create(sl.device);
         ok = sl.ctx != nullptr && hipSetDevice(sl.device) == hipSuccess &&
-             hipHostMalloc((void **)&sl.in, block_bytes + 64, hipHostMallocDefault) == hipSuccess;
+             sj::pinned_alloc((void **)&sl.in, block_bytes + 64) == hipSuccess;
         sl.in_cap = block_bytes;
     }
     if (!ok) {
@@ -216,7 +216,7 @@ int sjhip_stream_grow(sjhip_stream *s, size_t keep, size_t new_capacity, uint8_t
     }
     uint8_t *bigger = nullptr;
     (void)hipSetDevice(sl.device);
-    if (hipHostMalloc((void **)&bigger, new_capacity + 64, hipHostMallocDefault) != hipSuccess) {
+    if (sj::pinned_alloc((void **)&bigger, new_capacity + 64) != hipSuccess) {
         snprintf(s->err, sizeof s->err, "pinned block of %zu bytes: allocation failed", new_capacity);
         return SJHIP_ERR_HIP;
     }

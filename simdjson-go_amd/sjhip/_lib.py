@@ -35,6 +35,7 @@ SYMBOLS = {
     "sjhip_multi_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int]),
     "sjhip_multi_destroy": (None, [C.c_void_p]),
     "sjhip_multi_shards": (C.c_int, [C.c_void_p]),
+    "sjhip_multi_shard_device": (C.c_int, [C.c_void_p, C.c_int]),
     "sjhip_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "sjhip_parse_nd_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
     "sjhip_fetch_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

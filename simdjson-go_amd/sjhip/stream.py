@@ -139,6 +139,7 @@ class Stream:
             L.sjhip_stream_release(self._h)
         pj = ParsedJson(msg, tape_buf[:tl], str_buf[:sl], tape_buf, str_buf)
         pj.records = int(r.records)
+        pj.device = int(r.device)  # the GPU that parsed the block
         return pj
 
 

@@ -2,10 +2,11 @@
 The batch is defined as ParseND of the packed message (documents trimmed, '\\n' inside a document -> '\\r', '\\n'
 between documents): the result must be bit for bit the oracle's ParseND of that message, document i must be root i, and
 every document's piece of the tape must be the tape Parse() of the document alone produces, up to the rebased indices.
-One invalid document fails the batch with the code ParseND of the packed message returns (stage 1 first); an empty one
-with the stage-1 code, as Parse() of it.  (Where ParseND is more lenient than Parse -- a scalar root such as `1` is a
-stage-1 error for Parse, whose end-of-message rule wants a closing bracket, but passes as a record that is not the last
--- the batch inherits ParseND's behaviour: it IS ParseND of the packed message.)"""
+One invalid document fails the batch with the code Parse() of that document returns (stage 1 first): ParseND of the
+packed message reports it, except for the end-of-message rule of stage 1 (the last structural must close a container,
+stage1_find_marks_amd64.go:115-129), which inside a packed message only the last document would meet -- so every
+document is held to it while the batch is packed (a scalar such as `1`, a truncated or an all-whitespace document fail
+with the stage-1 code wherever they stand)."""
 import numpy as np
 import pytest
 
@@ -167,3 +168,51 @@ def test_batch_of_many_tiny_documents():
     tl, sl = ctx.parse_batch_device(dev.data_ptr(), offs.tolist(), [len(d) for d in docs])
     tape, strings = ctx.fetch(tl, sl)
     assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings)
+
+
+@pytest.mark.parametrize("bad", [b"1", b'"str"', b'{"a":1', b'{"a":1} x', b" ", b"\n", b" \t\r\n ", b"[1,2", b"true"])
+def test_batch_documents_meet_parse_end_rule(bad):
+    """A document that Parse() rejects in stage 1 because its last structural does not close a container fails the batch
+    with the stage-1 code at every position, from host buffers and from one device buffer (where documents are taken
+    untrimmed: an all-whitespace document would otherwise vanish as an empty ND line and shift every later root)."""
+    import sjhip
+    import torch
+    ctx = sjhip.Context(0)
+    assert O.parse(bad, ndjson=False, copy_strings=True).rc == 1
+    good = [b'{"x":1}', b' [1,2,3]\n', fixtures.load("payload-small")]
+    for pos in (0, 1, 3):
+        docs = good[:pos] + [bad] + good[pos:]
+        with pytest.raises(sjhip.ParseError) as e:
+            ctx.parse_batch(docs)
+        assert e.value.code == 1, (pos, e.value.code)
+        blob = b"".join(docs)
+        offs = np.concatenate(([0], np.cumsum([len(d) for d in docs])[:-1]))
+        dev = torch.empty(len(blob) + 64, dtype=torch.uint8, device="cuda:0")
+        dev[: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        with pytest.raises(sjhip.ParseError) as e:
+            ctx.parse_batch_device(dev.data_ptr(), offs.tolist(), [len(d) for d in docs])
+        assert e.value.code == 1, (pos, e.value.code)
+    # the context is fine afterwards, and good documents with whitespace around them keep root i = document i
+    blob = b"".join(good)
+    offs = np.concatenate(([0], np.cumsum([len(d) for d in good])[:-1]))
+    dev = torch.empty(len(blob) + 64, dtype=torch.uint8, device="cuda:0")
+    dev[: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    tl, sl = ctx.parse_batch_device(dev.data_ptr(), offs.tolist(), [len(d) for d in good])
+    tape, strings = ctx.fetch(tl, sl)
+    ref = O.parse(b"\n".join(d.replace(b"\n", b"\r") for d in good), ndjson=True, copy_strings=True)
+    assert ref.rc == 0 and np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings)
+    assert len(_roots(tape)) == 3
+
+
+def test_batch_one_huge_document_among_many_small():
+    """Sizes as skewed as they get: the packing grid is sized by the packed bytes, not by longest x count."""
+    import sjhip
+    ctx = sjhip.Context(0)
+    big = b"[" + b",".join([fixtures.load("twitter")] * 12) + b"]"
+    docs = [b'{"i":%d}' % k for k in range(20000)]
+    docs.insert(7777, big)
+    ref = O.parse(_packed(docs), ndjson=True, copy_strings=True)
+    pj = ctx.parse_batch(docs)
+    assert ref.rc == 0 and np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)

@@ -63,3 +63,43 @@ def test_multi_all_devices_and_reuse():
             assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), copies
     finally:
         m.close()
+
+
+def test_shards_and_stream_blocks_sit_on_the_devices_asked_for():
+    """Placement, as the HIP runtime reports it.  On the one-GPU development boxes everything is device 0; on a node
+    with several GPUs this is the test that sees the multi-device code on real devices: one shard per GPU with its tape
+    resident there, the merged result still bit for bit the oracle's, and the blocks of a stream spread round robin."""
+    import io
+    import sjhip
+    from sjhip.api import MultiContext
+    L = sjhip.lib()
+    count = L.sjhip_device_count()
+    assert count >= 1
+    doc = fixtures.load("parking-citations") * (12 * count)
+    ref = O.parse(doc, ndjson=True, copy_strings=True)
+    for devices in (None, list(range(count)), list(range(count)) * 2, [count - 1]):
+        m = MultiContext(devices)
+        try:
+            want = list(range(count)) if devices is None else devices
+            assert m.shards == len(want)
+            assert all(L.sjhip_multi_shard_device(m._h, k) == -1 for k in range(m.shards))  # nothing parsed yet
+            pj = m.parse_nd(doc)
+            assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), devices
+            assert [L.sjhip_multi_shard_device(m._h, k) for k in range(m.shards)] == want
+        finally:
+            m.close()
+    # ParseNDStream over every visible GPU: blocks go round robin over the devices, results arrive in input order
+    bs = 1 << 20
+    blocks = list(sjhip.cut_blocks(io.BytesIO(doc), bs))
+    got = list(sjhip.parse_nd_stream(io.BytesIO(doc), block_size=bs, inflight=2 * count, n_devices=0))
+    assert len(got) == len(blocks)
+    for pj, blk in zip(got, blocks):
+        r = O.parse(blk, ndjson=True, copy_strings=True)
+        assert np.array_equal(pj.Tape, r.tape) and np.array_equal(pj.Strings, r.strings)
+    assert {pj.device for pj in got} == set(range(min(count, len(blocks))))
+    # one context per device through the plain API (what the Go binding's context pool does)
+    for d in range(count):
+        c = sjhip.Context(d)
+        pj = c.parse(doc, ndjson=True)
+        assert np.array_equal(pj.Tape, ref.tape)
+        c.close()

@@ -594,3 +594,22 @@ def test_fetch_after_small_parse_paths(ctx):
                 strs = np.zeros(sl.value, dtype=np.uint8)
                 assert L.sjhip_fetch(ctx._h, tape.ctypes.data, strs.ctypes.data) == 0
                 assert np.array_equal(tape, ref.tape) and np.array_equal(strs, ref.strings), (len(doc), stage1_between)
+
+
+def test_small_documents_denser_than_the_deferred_layout(ctx):
+    """Documents up to SJHIP_SMALL_BYTES run with one host synchronisation on stage-2 arrays laid out for one token per
+    four bytes (csrc/parse_api.hip); a denser document must come back through the synchronous path with the same
+    result -- and an invalid dense one with its own error class, not with whatever the clamped run saw."""
+    rnd = random.Random(11)
+    docs = [
+        b"[" + b",".join([b"1"] * 40000) + b"]",                       # one token per byte
+        b"[" * 3000 + b"]" * 3000,
+        b"[" + b",".join(b'{"a":[%d,"%s"]}' % (rnd.randrange(10), b"x" * rnd.randrange(3)) for _ in range(30000)) + b"]",
+        b"\n".join(b"[[],{},[1]]" for _ in range(20000)),
+        b"[" + b",".join([b"1"] * 16384) + b"]",                       # right at the layout's edge (len/4 + 4096)
+    ]
+    for i, d in enumerate(docs):
+        check(ctx, d, nd=(i == 3), what=f"dense {i}")
+        check(ctx, fixtures.load("payload-small"), what="sparse after dense")
+    check(ctx, b"[" + b",".join([b"1"] * 40000) + b",]", what="dense, stage-2 error")
+    check(ctx, b"[" + b",".join([b"1"] * 40000), what="dense, stage-1 error")

@@ -156,6 +156,43 @@ def test_deserialize_rejects_corrupt_streams(ctx):
     ctx.deserialize(stream)  # the context is still usable
 
 
+def _frame(tags, values, strings=b"", tape_len=None):
+    """a version-3 stream of uncompressed blocks around the given columns (parsed_serialize.go:376-431)"""
+    def uv(v):
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7f) | 0x80)
+            v >>= 7
+        out.append(v)
+        return bytes(out)
+    vals = b"".join((v & 0xFFFFFFFFFFFFFFFF).to_bytes(8, "little") for v in values)
+    body = uv(tape_len) + b"\x00\x00" + uv(len(strings)) + uv(len(strings) + 1) + b"\x00" + strings + \
+        uv(len(tags)) + uv(len(tags) + 1) + b"\x00" + tags + uv(len(vals)) + uv(len(vals) + 1) + b"\x00" + vals
+    return np.frombuffer(b"\x03" + uv(len(body)) + body, dtype=np.uint8)
+
+
+def test_deserialize_checks_closing_brackets(ctx):
+    """parsed_serialize.go:666-671: a closing tag must meet the word its opener left.  The device scatters in parallel, so
+    a slot no opener wrote would keep a word of the previous parse: streams with a closing tag without an opener, with
+    the wrong kind of closing tag, with an opener whose distance does not reach past itself, and with two openers that
+    claim one slot are all rejected; the well-formed stream next to each is read."""
+    import sjhip
+    good = _frame(b"r[[]]r", [6, 4, 2, -5], tape_len=6)
+    for _ in range(2):
+        pj = ctx.deserialize(good)
+        assert [int(x) >> 56 for x in pj.Tape] == [ord(c) for c in "r[[]]r"]
+        assert [int(x) & 0xFFFFFFFF for x in pj.Tape] == [6, 5, 4, 2, 1, 0]
+        for tags, values, tl in (
+                (b"r[]]]r", [6, 4, -5], 6),          # two closing tags no opener wrote (stale words of the run before)
+                (b"rt]tr", [5, -4], 5),
+                (b"r[[}]r", [6, 4, 2, -5], 6),       # wrong kind
+                (b"r[tr", [4, 1, -3], 4),            # an opener whose closing slot is itself
+                (b"r[[]tr", [6, 3, 2, -5], 6),       # two openers, one closing slot
+                (b"r[[]]r", [6, 4, 3, -5], 6)):      # the inner opener points at the outer's slot: the outer lost it
+            with pytest.raises(sjhip.ParseError):
+                ctx.deserialize(_frame(tags, values, tape_len=tl))
+
+
 def test_hand_derived_format_vectors(ctx):
     """tests/golden/serialize_v3_vectors.py (streams derived by hand from parsed_serialize.go:201-236, 283-341, 376-431):
     the device's de-duplicating serializer must produce exactly these bytes, the plain one where no string repeats,
