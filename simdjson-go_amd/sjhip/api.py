@@ -270,7 +270,7 @@ class MultiContext:
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 
-    __slots__ = ("_msg", "Tape", "Strings", "_tape_buf", "_str_buf", "records")
+    __slots__ = ("_msg", "Tape", "Strings", "_tape_buf", "_str_buf", "records", "device")
 
     def __init__(self, message, tape, strings, tape_buf=None, str_buf=None):
         # `message`: bytes, or a uint8 view of the caller's buffer -- the reference's pj.Message ALIASES the input
@@ -281,6 +281,7 @@ class ParsedJson:
         self._tape_buf = tape if tape_buf is None else tape_buf  # capacity behind Tape / Strings (reuse)
         self._str_buf = strings if str_buf is None else str_buf
         self.records = 0  # filtered streams: matching records of the block
+        self.device = -1  # streams: the GPU that parsed the block
 
     @property
     def Message(self):
