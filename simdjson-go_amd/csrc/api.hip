@@ -87,7 +87,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings};
+                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings, &ctx->d_strtmp};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     sj::release_nd_big(ctx);

@@ -165,8 +165,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                           uint64_t msg_base, uint64_t **tape_out, size_t *tape_len, uint8_t **strings_out,
                           size_t *strings_len, size_t *msg_off, size_t *msg_len) {
     const bool ndjson = flags & 1;
-    bool copy = flags & 2;      // every string copied through the emit masks (byte-parallel path)
-    bool force_copy = false;    // ... or, after a surrogate-walk overflow, through the per-string walks (parse_api.hip)
+    const bool copy_all = flags & 2;
+    bool copy = copy_all;       // every string copied through the emit masks (byte-parallel path)
+    bool masks = true;          // the emit masks are computed (both modes); false after a surrogate-walk overflow
+    bool force_copy = false;    // every string copied, but through the per-string walks (after an overflow, parse_api.hip)
     size_t off, len;
     trim_space(msg0, len0, &off, &len);
     *msg_off = off;
@@ -186,7 +188,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     std::vector<u32> v_flags(chunks, 0);
     std::vector<uint16_t> v_pre(chunks, 0);
     std::vector<ChunkRec> v_rec(chunks);
-    std::vector<u32> v_ucnt(units, 0);
+    std::vector<u32> v_ucnt(units, 0), v_ucount(units, 0);
     g_qm = v_qm.data();
     g_q = v_q.data();
     g_st = v_st.data();
@@ -203,7 +205,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data(), v_slow.data()};
     const size_t used_units = (len + 4095) / 4096;
     u64 masks_total = 0;
-    if (copy) {
+    if (masks) {
         for (size_t c = 0; c < used_units * 64; c++)
         {
             bool overflow;
@@ -219,10 +221,12 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         }
         if (force_copy) {  // S2_ERR_SERIAL_STRINGS: nothing of the mask pass is a verdict
             copy = false;
+            masks = false;
+            force_copy = copy_all;  // (selective copy stays selective: the walks decide per string)
             bad = 0;
         }
     }
-    if (copy) {
+    if (masks) {
         // The escape-by-escape form of the general routine (what k_measure runs: stage2.hip GenUnit, sj_strings.h
         // gen_item_masks) must give the verdict, the emit masks and the flags of the per-chunk form above.
         u32 bad2 = 0;
@@ -260,7 +264,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         }
         if ((bad2 != 0) != (bad != 0)) return 93;
     }
-    if (copy) {
+    if (masks) {
         for (size_t u = 0; u < used_units; u++) {
             u32 run = 0;
             for (size_t c = u * 64; c < u * 64 + 64; c++) {
@@ -269,6 +273,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                 run += (u32)popc64(v_em[c]);
             }
             v_ucnt[u] = (u32)masks_total;
+            v_ucount[u] = run;  // (what the measuring phase sees: the unit scan has not run yet)
             for (size_t c = u * 64; c < u * 64 + 64; c++) v_rec[c].abs = (u32)masks_total + v_pre[c];  // k_str_emit
             masks_total += run;
         }
@@ -291,6 +296,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                 dlen[i] = dl;
                 needcopy[i] = force_copy || sl != dl;
                 copied[i] = needcopy[i] ? dl : 0u;
+                if (masks && !bad) {  // WithCopyStrings(false) on the device measures from the emit masks: same answers
+                    const StrMeasure sm = string_measure_masks(sv, v_rec.data(), v_ucount.data(), (u64)pos[i] + 1, i + 1 < n ? pos[i + 1] : len);
+                    if (!sm.ok || sm.dl != dl || sm.copied != (sl != dl)) return 94;
+                }
             }
         }
     }
@@ -382,7 +391,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     for (u32 c = 0; c < n_br; c++)  // k_br_match: container of every gap, pair words, root words
         if (!bracket_resolve(mt, br_off.data(), br_info.data(), c, tape_base, tape)) bad = 1;
     if (n_br == 0) bad = 1;  // unreachable: token 0 must be an open bracket
-    if (copy && !bad) {  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
+    std::vector<u8> full;  // selective copy: k_str_emit's compaction of ALL strings (the device's scratch buffer)
+    if (masks && !copy) full.resize(masks_total + 64);
+    if (masks && !bad) {  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
+        u8 *const sink = copy ? strs : full.data();
         std::vector<u8> ubuf(4096);
         for (size_t c = 0; c < used_units * 64; c++) {
             if ((c & 63) == 0) {
@@ -414,9 +426,14 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             } else if (v_flags[c] & CHUNK_SLOW) {
                 str_chunk_patch_simple(sv, c, v_em[c], [&](u32 q) { return chunk[q]; }, [&](u32 q, u8 v) { chunk[q] = v; });
             }
-            u8 *dst = strs + v_ucnt[c >> 6] + v_pre[c];
+            u8 *dst = sink + v_ucnt[c >> 6] + v_pre[c];
             for (u64 r = v_em[c]; r != 0; r &= r - 1) *dst++ = chunk[ctz64(r)];
         }
+        if (!copy)  // k_emit_strings: the strings that changed are taken from the compaction -- the walk's bytes
+            for (size_t i = 0; i < n; i++)
+                if (kind[i] == K_STRING && needcopy[i] && !strbad[i] &&
+                    memcmp(full.data() + emitted_before(v_ucnt.data(), v_rec.data(), (u64)pos[i] + 1), strs + soff[i], dlen[i]) != 0)
+                    return 94;
     }
     if (bad) {
         free(tape);

@@ -69,6 +69,7 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.d_tape = (uint64_t *)ctx->d_tape.p;
     a.tape_cap = 2 * ctx->p_nlay + 2;
     a.d_strings = (uint8_t *)ctx->d_strings.p;
+    a.d_strings_tmp = (ctx->p_flags & SJHIP_FLAG_COPY_STRINGS) ? nullptr : (uint8_t *)ctx->d_strtmp.p;
     a.strings_cap = ctx->p_len + 64;
     a.tape_base = tape_base;
     a.strings_base = strings_base;
@@ -119,12 +120,18 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     const size_t pos_cap = (len + 63) / 64 * 64 + 64;
     size_t n = 0;
     int ok = 0;
-    // every string copied (the reference's default): stage 1 leaves its string masks for the byte-parallel unescape
+    // stage 1 leaves its string masks for the byte-parallel unescape.  Every string copied (the reference's default):
+    // Strings.B is the compaction itself; WithCopyStrings(false): the compaction goes to a scratch buffer and the strings
+    // that unescaping changed are copied out of it (stage2.hip k_emit_strings)
     void *aux = nullptr;
-    if (flags & SJHIP_FLAG_COPY_STRINGS) {
+    {
         int rc = arena_reserve(ctx, ctx->d_aux, str_aux_bytes(len + 64));
         if (rc) return rc;
         aux = ctx->d_aux.p;
+        if (!(flags & SJHIP_FLAG_COPY_STRINGS)) {
+            rc = arena_reserve(ctx, ctx->d_strtmp, len + 64);
+            if (rc) return rc;
+        }
     }
     {
         // the state and the scan slots of stage 2: zeroed by stage 1's preparation kernel (no memset launch of their own)
@@ -182,7 +189,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
         }
         if (tape_len) *tape_len = (size_t)hs->tape_len;
-        if (strings_len) *strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
+        if (strings_len) *strings_len = (ctx->p_aux && (flags & SJHIP_FLAG_COPY_STRINGS)) ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     }
     return SJHIP_OK;
 }
@@ -255,7 +262,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
     ctx->tape_len = (size_t)hs->tape_len;
-    ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
+    ctx->strings_len = (ctx->p_aux && (ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
     ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
     if (tape_len) *tape_len = ctx->tape_len;

@@ -52,6 +52,14 @@ SJ_HD int ctz64(u64 x) {  // x != 0
 #endif
 }
 
+SJ_HD int clz64(u64 x) {  // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+
 // ---- three-input boolean functions (v_bitop3_b32 on gfx950) --------------------------------
 // TT is the truth table of f(a, b, c): bit (a*4 + b*2 + c) of TT is f's value.  Write TT as the same
 // expression over the constants TA, TB, TC, e.g. "a & ~b | c" -> (TA & ~TB | TC) & 0xff.

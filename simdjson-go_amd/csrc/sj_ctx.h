@@ -29,6 +29,7 @@ struct sjhip_ctx {
     uint8_t *h_stage = nullptr;        // pinned staging of sjhip_parse_batch: runs of small documents travel as one copy
     size_t h_stage_cap = 0;
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
+    sj::DevBuf d_strtmp;               // WithCopyStrings(false): the unescaped bytes of all strings (parse_api.hip)
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     sj::Stage1State s1;                // last stage-1 state (host copy)

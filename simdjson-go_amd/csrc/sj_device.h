@@ -57,6 +57,8 @@ struct S2Args {
     uint64_t *d_tape;
     size_t tape_cap;
     uint8_t *d_strings;
+    uint8_t *d_strings_tmp;  // WithCopyStrings(false) with string masks: scratch of strings_cap bytes for the unescaped bytes of
+                             // ALL strings (k_str_emit), from which the strings that changed are copied to d_strings
     size_t strings_cap;
     uint64_t tape_base, strings_base, msg_base;
     void *str_aux;          // string masks of stage 1 (str_aux_layout) or null: per-string walks

@@ -77,13 +77,6 @@ SJ_HD U128 mul64(u64 a, u64 b) {
     return U128{(u64)p, (u64)(p >> 64)};
 #endif
 }
-SJ_HD int clz64(u64 x) {  // x != 0
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __clzll((long long)x);
-#else
-    return __builtin_clzll(x);
-#endif
-}
 
 // ---- Eisel-Lemire: w * 10^q -> binary64 bits (sign excluded) ---------------------------------------
 // Returns the IEEE bits of the correctly rounded value for w != 0 (Mushtak & Lemire 2023: the

@@ -348,6 +348,44 @@ SJ_HD u64 emitted_before(const u32 *unit_base, const ChunkRec *rec, u64 a) {
     return (u64)unit_base[a >> 12] + (r.pre & CHUNK_PRE_MASK) + (u64)popc64(below);
 }
 
+// ---- WithCopyStrings(false) from the same masks (parseString, stage2_build_tape_amd64.go:90-109: a string goes to
+// Strings.B only if unescaping changed its length) ---------------------------------------------------------------------
+// a0 = aligned offset of the first content byte (behind the opening quote), a1 = aligned offset of the next token (the
+// end of the message behind the last token).  The unescaped length is the number of emit-mask bits in [a0, a1) -- the
+// emit mask is empty outside strings -- and the raw length the distance to the closing quote, the last unescaped quote
+// in front of a1 (whitespace may lie between it and the next token).  Every escape shortens a string, so the two
+// differ exactly for the strings that hold one.  unit_counts: emitted bytes per unit (BEFORE the unit scan turns them
+// into prefixes: this runs in the measuring phase).  ok = false: no closing quote in reach (stage 1 has failed).
+struct StrMeasure {
+    u32 dl;
+    bool copied, ok;
+};
+SJ_HD StrMeasure string_measure_masks(const StrView &m, const ChunkRec *rec, const u32 *unit_counts, u64 a0, u64 a1) {
+    StrMeasure r{0u, false, false};
+    if (a1 <= a0) return r;  // (the quote is the last byte: nothing closes it)
+    const u64 c0 = a0 >> 6, c1 = a1 >> 6;
+    const u32 b0 = (u32)(a0 & 63), b1 = (u32)(a1 & 63);
+    const u64 below0 = b0 ? ~0ull >> (64 - b0) : 0ull, below1 = b1 ? ~0ull >> (64 - b1) : 0ull;
+    const ChunkRec r0 = rec[c0], r1 = rec[c1];
+    u64 n = (u64)(r1.pre & CHUNK_PRE_MASK) + (u64)popc64(r1.em & below1) - ((u64)(r0.pre & CHUNK_PRE_MASK) + (u64)popc64(r0.em & below0));
+    for (u64 u = a0 >> 12; u < (a1 >> 12); u++) n += unit_counts[u];  // (a string that leaves its 4 KiB unit: rare)
+    r.dl = (u32)n;
+    u64 c = c1, mask = below1;
+    for (;;) {
+        u64 qb = m.q[c] & mask;
+        if (c == c0) qb &= ~below0;
+        if (qb != 0) {
+            const u64 cq = c * 64 + (u64)(63 - clz64(qb));
+            r.copied = cq - a0 != n;
+            r.ok = true;
+            return r;
+        }
+        if (c == c0) return r;
+        c--;
+        mask = ~0ull;
+    }
+}
+
 // the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)
 SJ_HD u64 emitted_before_abs(const ChunkRec *rec, u64 a) {
     const ChunkRec r = rec[a >> 6];

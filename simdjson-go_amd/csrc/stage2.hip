@@ -91,6 +91,8 @@ struct S2Dev {
     SegSlot *seg_units, *seg_tiles;  // [SCAN_SEGS] segment aggregates of the two multi-block scans (zeroed with st)
     u64 *tape;
     u8 *strings;
+    u8 *str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
+                   // scratch buffer with WithCopyStrings(false), from which k_emit_strings takes the strings that changed
     u64 tape_cap, strings_cap;
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
     // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (g + total <= p.strings_cap && !SJ_EXPBIT(p, 6)) {
-                u8 *dst = p.strings + g;
+                u8 *dst = p.str_out + g;
                 const u32 q16 = total >> 4;
                 for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
                     *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
@@ -683,7 +685,23 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
 #pragma unroll
     for (int k = 0; k < RD_ITEMS; k++) copied[k] = 0;
     const u32 kd4[4] = {kv.x, kv.y, kv.z, kv.w};
-    if (!p.sv.qm) {
+    if (p.sv.qm && !p.copy_strings) {
+        // the emit masks are there (the string half ran as a launch of its own in front of this one): unescaped length
+        // and "did unescaping change it" of every string without a walk (sj_strings.h string_measure_masks)
+#pragma unroll
+        for (int k = 0; k < RD_ITEMS; k++) {
+            if (base + k >= n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
+            const u64 a0 = (u64)p.pos[base + k] + p.sv.lead + 1;
+            const u64 a1 = (base + k + 1 < n ? (u64)p.pos[base + k + 1] : p.len) + p.sv.lead;
+            const StrMeasure sm = string_measure_masks(p.sv, p.rec, p.unit_cnt, a0, a1);
+            u32 out = DLEN_INVALID;
+            if (sm.ok) {
+                out = sm.dl | (sm.copied ? DLEN_COPY : 0u);
+                copied[k] = sm.copied ? sm.dl : 0u;
+            }
+            p.dlen[base + k] = out;
+        }
+    } else if (!p.sv.qm) {
         const MsgView mv{p.msg, p.len};
 #pragma unroll
         for (int k = 0; k < RD_ITEMS; k++) {
@@ -725,6 +743,8 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
 // Both measuring passes in one launch (they are independent and neither fills the device on its own): blocks below
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
+// (WithCopyStrings(false) launches the halves one behind the other: the token half then measures the strings from the
+// records the string half leaves.)
 __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
     if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
@@ -1329,7 +1349,16 @@ __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
     const u32 dl = p.dlen[i];
     if (dl == DLEN_INVALID || !(dl & DLEN_COPY)) return;
     const u32 so = p.str_off[i];
-    if ((u64)so + (dl & ~DLEN_COPY) > p.strings_cap) return;
+    const u32 n = dl & ~DLEN_COPY;
+    if ((u64)so + n > p.strings_cap) return;
+    if (p.sv.qm) {  // the unescaped bytes of every string wait in k_str_emit's compaction: E(first content byte) on
+        const u8 *src = p.str_out + emitted_before(p.unit_cnt, p.rec, (u64)p.pos[i] + p.sv.lead + 1);
+        u8 *dst = p.strings + so;
+        u32 j = 0;
+        for (; j + 8 <= n; j += 8) store_u64(dst + j, load_u64(src + j));  // (neither side is aligned: fine on gfx950)
+        for (; j < n; j++) dst[j] = src[j];
+        return;
+    }
     const MsgView mv{p.msg, p.len};
     u32 sl, dl2;
     string_walk(mv, p.pos[i], p.strings + so, &sl, &dl2);
@@ -1450,7 +1479,9 @@ static S2Dev stage2_view(const S2Args &a) {
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
 #endif
-    if (a.str_aux && p.copy_strings) {
+    p.str_out = a.d_strings;
+    if (a.str_aux && !p.copy_strings) p.str_out = a.d_strings_tmp;
+    if (a.str_aux && (p.copy_strings || a.d_strings_tmp)) {
         const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
         p.sv.qm = x.qm;
         p.sv.q = x.q;
@@ -1478,7 +1509,12 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
 hipError_t stage2_launch_measure(const S2Args &a) {
     const S2Dev p = stage2_view(a);
     if (a.n == 0) return hipSuccess;
-    {
+    if (p.sv.qm && !p.copy_strings) {
+        // selective copy: the token half measures every string from the records of the string half
+        const u32 mblocks = persistent_blocks(k_measure, (p.units + 3) / 4);
+        hipLaunchKernelGGL(k_measure, dim3(mblocks), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
+        hipLaunchKernelGGL(k_measure, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p, 0u);
+    } else {
         const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
         hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
     }
@@ -1497,7 +1533,8 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     // The string bytes: in front of the tape kernels (k_str_emit then leaves every chunk's absolute Strings.B offset
     // for k_s2_emit), or, with S2_FLAG_NO_ABS and a side stream, beside them: k_str_emit streams at HBM speed while
     // k_br_match / k_min_upper / k_numbers wait on dependent loads, so the two chains fill each other's gaps.
-    const bool beside = p.sv.qm && a.side && (a.flags & S2_FLAG_NO_ABS);
+    const bool masks_copy = p.sv.qm && p.copy_strings;  // every string copied: offsets and lengths straight from the emit masks
+    const bool beside = masks_copy && a.side && (a.flags & S2_FLAG_NO_ABS);
     const bool late = beside && (a.flags & S2_FLAG_FORK_LATE);  // the side stream starts behind k_s2_emit
     auto fork_strings = [&]() -> hipError_t {
         hipError_t e = hipEventRecord(a.ev_fork, a.stream);
@@ -1512,7 +1549,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     } else if (p.sv.qm && !beside) {
         hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     }
-    if (p.sv.qm) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    if (masks_copy) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
     else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
     if (late) {
         const hipError_t e = fork_strings();
@@ -1524,7 +1561,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
         const u32 lblocks = (u32)(want < 2048 ? want : 2048);
         hipLaunchKernelGGL(k_numbers, dim3(nblocks + lblocks), dim3(256), 0, a.stream, p, nblocks);
     }
-    if (!p.sv.qm) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
+    if (!masks_copy) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 2048 ? gb : 2048), dim3(256), 0, a.stream, p);  // (8 waves per SIMD resident)
     if (beside) {
@@ -1556,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_pack(const S2State *st, const u64 *tape
 }
 hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap) {
     hipLaunchKernelGGL(k_pack, dim3(128), dim3(256), 0, a.stream, (const S2State *)a.ws_zero, (const u64 *)a.d_tape, (const u8 *)a.d_strings,
-                       a.str_aux ? 1u : 0u, (u8 *)h_dst, (u64)cap);
+                       (a.str_aux && (a.flags & 2u)) ? 1u : 0u, (u8 *)h_dst, (u64)cap);
     return hipGetLastError();
 }
 
