@@ -244,6 +244,12 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
  *   1 phase A done, 2 serial section done (only the wave that ran it), 3 state of the tile known, 4 flatten done,
  *   5 HW_ID | XCC_ID << 32.  Plain (non-ND) stage 1 of a device-resident message. */
 int sjhip_stage1_set_variant(int variant);
+/* The library can be built with -DSJ_DEBUG_BOUNDS (csrc/sj_bounds.h; __graft_entry__.build_lib(debug_bounds=True) ->
+ * libsjhip_dbg.so): every array of the parse path is then reached through a bounds-checked view, and a parse during
+ * which a kernel touched an element outside its array fails with SJHIP_ERR_HIP ("bounds check: ...").
+ * sjhip_debug_bounds_selftest: -1 in the product build; in the debug build it runs a kernel with two deliberate
+ * violations and returns how many were recorded (2). */
+int sjhip_debug_bounds_selftest(void);
 int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_pos, size_t pos_cap, uint64_t *trace_out,
                        size_t trace_cap_words, unsigned *tiles, int *waves, int *words);
 

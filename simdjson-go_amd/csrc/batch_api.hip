@@ -70,15 +70,19 @@ __global__ __launch_bounds__(256) void k_batch_pack(const uint8_t *__restrict__ 
     uint32_t k = doc_of(docs, n_docs, p0);
     DocDesc d = docs[k];
     bool bad = false;
-    if (p1 <= d.dst + d.len && p0 + 16 == p1 && (IN_PLACE || (((uintptr_t)(src + d.src + (p0 - d.dst)) | (uintptr_t)(dst + p0)) & 15u) == 0)) {
-        // sixteen bytes of one document
+    if (p1 <= d.dst + d.len && p0 + 16 == p1) {
+        // sixteen bytes of one document (the source is byte-aligned at best: unaligned 16-byte loads are fine on gfx950)
         uint4 v = *reinterpret_cast<const uint4 *>(IN_PLACE ? dst + p0 : src + d.src + (p0 - d.dst));
         v.x = sj::newlines_to_cr(v.x); v.y = sj::newlines_to_cr(v.y); v.z = sj::newlines_to_cr(v.z); v.w = sj::newlines_to_cr(v.w);
         *reinterpret_cast<uint4 *>(dst + p0) = v;
         if (!IN_PLACE && p1 == d.dst + d.len) bad = !doc_end_ok(src + d.src, d.len);
     } else {
+        uint64_t next_dst = k + 1 < n_docs ? docs[k + 1].dst : ~0ull;
         for (uint64_t p = p0; p < p1; p++) {
-            while (k + 1 < n_docs && docs[k + 1].dst <= p) d = docs[++k];
+            while (next_dst <= p) {
+                d = docs[++k];
+                next_dst = k + 1 < n_docs ? docs[k + 1].dst : ~0ull;
+            }
             const uint64_t off = p - d.dst;
             if (off < d.len) {
                 const uint8_t b = IN_PLACE ? dst[p] : src[d.src + off];

@@ -252,6 +252,15 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         rc = run();
         if (rc) return rc;
     }
+    {  // debug build: an out-of-bounds access anywhere in the stage-2 kernels fails the parse, whatever its verdict
+        unsigned hits = 0, id = 0;
+        unsigned long long index = 0, size = 0;
+        if (stage2_debug_bounds(&hits, &id, &index, &size) && hits) {
+            ctx_set_error(ctx, "bounds check: %u out-of-bounds accesses, the first to array %u (sj_bounds.h ArrId) at element %llu of %llu",
+                          hits, id, index, size);
+            return SJHIP_ERR_HIP;
+        }
+    }
     if (hs->err & 8u) {  // a bounded spin loop of a scan kernel ran out: internal error, never a verdict
         ctx_set_error(ctx, "stage-2 scan aborted (internal synchronisation timeout)");
         return SJHIP_ERR_HIP;
@@ -347,6 +356,8 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
     ctx->want_pack = 0;
     return rc;
 }
+
+int sjhip_debug_bounds_selftest(void) { return stage2_debug_bounds_selftest(); }
 
 void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
     size_t o = 0, l = 0;

@@ -36,7 +36,8 @@ struct S2State {
     uint32_t tail_mask;      // allowed contexts of the gap behind the last bracket (sj_stage2.h)
     unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
     uint32_t num_count;      // number tokens queued for k_numbers
-    uint32_t pad[3];
+    uint32_t str_count;      // selective copy: strings queued for k_emit_strings (the ones unescaping changes)
+    uint32_t pad[2];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 // a run of more than SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string
@@ -81,6 +82,11 @@ hipError_t stage2_launch_bignum(const S2Args &a);
 // says whether the payload is there.  h_dst is pinned host memory mapped into the device (one launch, no copy commands).
 constexpr size_t STAGE2_PACK_HEAD = 128;
 hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap);
+
+// debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses since the last call (cleared);
+// 0 in the product build.  _selftest: -1 in the product build, else the violations recorded for two deliberate ones
+int stage2_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size);
+int stage2_debug_bounds_selftest();
 
 size_t stage1_workspace_bytes(size_t len);
 // zero2 / zero2_bytes: a second region to zero in the same kernel (the stage-2 state) or null

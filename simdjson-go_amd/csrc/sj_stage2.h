@@ -20,6 +20,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "sj_bounds.h"
 #include "sj_chunk.h"
 
 namespace sj {
@@ -125,7 +126,7 @@ static constexpr EscapeLut ESCAPE_LUT = make_escape_lut();
 SJ_HD u8 escape_value(u8 b) { return ESCAPE_LUT.v[b]; }  // one load instead of a compare chain
 
 struct MsgView {
-    const u8 *p;
+    Arr<const u8> p;  // (sj_bounds.h: a plain pointer in the product build)
     u64 len;
     SJ_HD u8 at(u64 i) const { return i < len ? p[i] : (u8)0; }  // the Go caller zero-pads (stage2…:75-86)
 };
@@ -185,7 +186,7 @@ SJ_HD bool string_walk(const MsgView &m, u64 q, u8 *dst, u32 *src_len, u32 *dst_
     for (;;) {
         // plain bytes, eight at a time (unaligned 8-byte loads and stores are fine on gfx950 global memory)
         while (pos + 8 <= m.len) {
-            const u64 x = load_u64(m.p + pos);
+            const u64 x = load_u64(arr_at(m.p, pos, 8));
             const u64 z = zero_bytes(x ^ 0x2222222222222222ull) | zero_bytes(x ^ 0x5c5c5c5c5c5c5c5cull);
             if (z == 0) {
                 if (dst) store_u64(dst + out, x);
@@ -288,7 +289,7 @@ SJ_HD bool atom_valid_word(u64 w8, u64 rem, u8 kind) {
     return kind == K_FALSE ? ok6 : ok5;
 }
 SJ_HD u64 load8_guarded(const MsgView &m, u64 p) {
-    if (p + 8 <= m.len) return load_u64(m.p + p);
+    if (p + 8 <= m.len) return load_u64(arr_at(m.p, p, 8));
     u64 v = 0;
     for (u32 k = 0; k < 8 && p + k < m.len; k++) v |= (u64)m.p[p + k] << (8 * k);
     return v;
@@ -298,7 +299,7 @@ SJ_HD bool atom_valid(const MsgView &m, u64 p, u8 kind) { return atom_valid_word
 // ---- previous-smaller-value over depth[] with a 64-ary min tree ------------------------------------
 struct MinTree {
     static constexpr int MAXLEV = 7;
-    const i32 *lev[MAXLEV];  // lev[0] = depth[], lev[k][g] = min of lev[k-1][64g .. 64g+63]
+    Arr<const i32> lev[MAXLEV];  // lev[0] = depth[], lev[k][g] = min of lev[k-1][64g .. 64g+63]
     u64 size[MAXLEV];
     int nlev;
 };

@@ -28,17 +28,18 @@
 namespace sj {
 
 struct StrView {
-    const u8 *base;  // 64-byte aligned base of the message
+    Arr<const u8> base;  // 64-byte aligned base of the message (Arr: sj_bounds.h, a plain pointer in the product build)
     u64 lead, end;   // the message occupies [lead, end) of it
-    const u64 *qm, *q, *st;
-    const u8 *unit_h;
-    const u64 *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
+    Arr<const u64> qm, q, st;
+    Arr<const u8> unit_h;
+    Arr<const u64> unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
     // the 16 bytes at a .. a+15 as two little-endian words (two unaligned 8-byte loads away from the message ends)
     SJ_HD void window16(u64 a, u64 &w0, u64 &w1) const {
         if (a >= lead && a + 16 <= end) {
-            w0 = load_u64(base + a);
-            w1 = load_u64(base + a + 8);
+            const u8 *w = arr_at(base, a, 16);
+            w0 = load_u64(w);
+            w1 = load_u64(w + 8);
         } else {
             w0 = w1 = 0;
             for (u32 k = 0; k < 8; k++) {
@@ -341,7 +342,7 @@ SJ_HD void gen_item_patch(const StrView &m, u64 u0, u32 item, Put put) {
 }
 
 // E(a): emitted bytes in front of aligned offset a
-SJ_HD u64 emitted_before(const u32 *unit_base, const ChunkRec *rec, u64 a) {
+SJ_HD u64 emitted_before(Arr<const u32> unit_base, Arr<const ChunkRec> rec, u64 a) {
     const ChunkRec r = rec[a >> 6];
     const u32 bit = (u32)(a & 63);
     const u64 below = bit ? (r.em & (~0ull >> (64 - bit))) : 0ull;
@@ -360,7 +361,7 @@ struct StrMeasure {
     u32 dl;
     bool copied, ok;
 };
-SJ_HD StrMeasure string_measure_masks(const StrView &m, const ChunkRec *rec, const u32 *unit_counts, u64 a0, u64 a1) {
+SJ_HD StrMeasure string_measure_masks(const StrView &m, Arr<const ChunkRec> rec, Arr<const u32> unit_counts, u64 a0, u64 a1) {
     StrMeasure r{0u, false, false};
     if (a1 <= a0) return r;  // (the quote is the last byte: nothing closes it)
     const u64 c0 = a0 >> 6, c1 = a1 >> 6;
@@ -387,7 +388,7 @@ SJ_HD StrMeasure string_measure_masks(const StrView &m, const ChunkRec *rec, con
 }
 
 // the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)
-SJ_HD u64 emitted_before_abs(const ChunkRec *rec, u64 a) {
+SJ_HD u64 emitted_before_abs(Arr<const ChunkRec> rec, u64 a) {
     const ChunkRec r = rec[a >> 6];
     const u32 bit = (u32)(a & 63);
     const u64 below = bit ? (r.em & (~0ull >> (64 - bit))) : 0ull;

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "sj_bignum.h"
+#include "sj_bounds.h"
 #include "sj_chunk.h"
 #include "sj_device.h"
 #include "sj_number.h"
@@ -65,40 +66,44 @@ struct alignas(32) TileAgg {
 
 // device view of all stage-2 arrays (carved out of one workspace by the launcher)
 struct S2Dev {
-    const u8 *msg;
+    Arr<const u8> msg;   // (Arr: sj_bounds.h -- a plain pointer in the product build, bounds-checked under -DSJ_DEBUG_BOUNDS)
     u64 len;
-    const u32 *pos;
+    Arr<const u32> pos;
     u32 n;         // tokens -- or, with n_dev, an upper bound the arrays are sized for
     const unsigned long long *n_dev;  // null, or the token count on the device (Stage1State::total): the host has not
                                       // waited for stage 1 (small documents: one synchronisation per parse)
     u32 ndjson, copy_strings, no_abs;
-    const u8 *kind;  // [n] token kinds (stage 1 writes them next to the positions)
-    u32 *dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
-    u32 *str_off;  // [n] selective copy only: Strings.B offset of a copied string
-    u32 *nl_off;   // [n] tape offset of the r-th record-separating newline
-    uint2 *numq;   // [n] (message offset, tape offset) of every number token, in no particular order
-    u32 *bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
-    i32 *br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
-    u32 *br_off;   // [n]                       its tape offset
-    u8 *br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
-    TileAgg *agg;  // [tiles] aggregates, then (k_s2_scan_tiles) exclusive prefixes
+    Arr<const u8> kind;  // [n] token kinds (stage 1 writes them next to the positions)
+    Arr<u32> dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
+    Arr<u32> str_off;  // [n] selective copy only: Strings.B offset of a copied string
+    Arr<u32> nl_off;   // [n] tape offset of the r-th record-separating newline
+    Arr<uint2> numq;   // [n] (message offset, tape offset) of every number token, in no particular order
+    Arr<u32> bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
+    Arr<uint4> strq;   // [n/2 + 8] selective copy: (message offset, Strings.B offset, length) of the strings to copy (a string
+    u32 strq_cap;  //           token is followed by a token that is none, so a valid document has at most n/2 of them)
+    Arr<i32> br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
+    Arr<u32> br_off;   // [n]                       its tape offset
+    Arr<u8> br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
+    Arr<TileAgg> agg;  // [tiles] aggregates, then (k_s2_scan_tiles) exclusive prefixes
     u32 tiles;
     // min tree levels 1.. (level 0 is br_depth[])
-    i32 *lev[MinTree::MAXLEV];
+    Arr<i32> lev[MinTree::MAXLEV];
     u64 lev_size[MinTree::MAXLEV];
     int nlev;
     S2State *st;
     SegSlot *seg_units, *seg_tiles;  // [SCAN_SEGS] segment aggregates of the two multi-block scans (zeroed with st)
-    u64 *tape;
-    u8 *strings;
-    u8 *str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
+    int scan_segs;                   // blocks per scan: SCAN_SEGS, or 1 for documents one block scans in a single round
+                                     // (no aggregates to publish or wait for: k_scans costs a small document 4 us, not 9-17)
+    Arr<u64> tape;
+    Arr<u8> strings;
+    Arr<u8> str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
                    // scratch buffer with WithCopyStrings(false), from which k_emit_strings takes the strings that changed
     u64 tape_cap, strings_cap;
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
     // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
-    ChunkRec *rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
-    u32 *unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
+    Arr<ChunkRec> rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
+    Arr<u32> unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
     u64 units;
     u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
 };
@@ -311,8 +316,8 @@ __device__ __forceinline__ SegSum seg_lookback(SegSlot *slots, int seg, int lane
     return r;
 }
 // contiguous share of `n` items for segment `seg`, in whole multiples of `quantum`
-__device__ __forceinline__ void seg_range(u64 n, u64 quantum, int seg, u64 &lo, u64 &hi) {
-    const u64 per = ((n + SCAN_SEGS - 1) / SCAN_SEGS + quantum - 1) / quantum * quantum;
+__device__ __forceinline__ void seg_range(u64 n, u64 quantum, int seg, int segs, u64 &lo, u64 &hi) {
+    const u64 per = ((n + (u64)segs - 1) / (u64)segs + quantum - 1) / quantum * quantum;
     lo = (u64)seg * per;
     hi = lo + per;
     if (lo > n) lo = n;
@@ -321,11 +326,11 @@ __device__ __forceinline__ void seg_range(u64 n, u64 quantum, int seg, u64 &lo, 
 
 // ---- exclusive scan of the unit byte counts (in place) + Strings.B length: SCAN_SEGS blocks of 1024 threads ------
 // 16 units per thread and round with 16-byte accesses.
-__device__ __forceinline__ void unit_round_load(const u32 *data, u64 i, u64 hi, u32 (&v)[16]) {
+__device__ __forceinline__ void unit_round_load(Arr<const u32> data, u64 i, u64 hi, u32 (&v)[16]) {
     if (i + 15 < hi) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint4 x = *reinterpret_cast<const uint4 *>(data + i + 4 * q);
+            const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(data, i + 4 * q, 4));
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
         }
     } else {
@@ -337,9 +342,9 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
     __shared__ u32 s_wave[2][16];
     __shared__ unsigned long long s_sum[16], s_prefix;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32 *data = p.unit_cnt;
+    const Arr<u32> data = p.unit_cnt;
     u64 lo, hi;
-    seg_range(p.units, 1024, seg, lo, hi);
+    seg_range(p.units, 1024, seg, p.scan_segs, lo, hi);
     // pass 1: the segment's byte count
     unsigned long long mine = 0;
     for (u64 start = lo; start < hi; start += 16384) {
@@ -363,7 +368,7 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
         const SegSum before = seg_lookback(p.seg_units, seg, lane, p.st);
         if (lane == 0) {
             s_prefix = before.s;
-            if (seg == SCAN_SEGS - 1) p.st->strings_len_masks = before.s + tot;
+            if (seg == p.scan_segs - 1) p.st->strings_len_masks = before.s + tot;
         }
     }
     __syncthreads();
@@ -401,7 +406,7 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
                 o.y = run; run += v[4 * q + 1];
                 o.z = run; run += v[4 * q + 2];
                 o.w = run; run += v[4 * q + 3];
-                *reinterpret_cast<uint4 *>(data + i + 4 * q) = o;
+                *reinterpret_cast<uint4 *>(arr_at(data, i + 4 * q, 4)) = o;
             }
         } else {
 #pragma unroll
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     };
     auto load_chunk = [&](u64 u, u64 em, u32 (&w)[16]) {
         if (u < p.units && em != 0 && !SJ_EXPBIT(p, 5)) {  // the chunk holds message bytes: its 64-byte line is readable
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.sv.base + (u * 64 + lane) * 64);
+            const uint4 *src = reinterpret_cast<const uint4 *>(arr_at(p.sv.base, (u * 64 + lane) * 64, 64));
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint4 v = src[q];
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (g + total <= p.strings_cap && !SJ_EXPBIT(p, 6)) {
-                u8 *dst = p.str_out + g;
+                u8 *dst = arr_at(p.str_out, g, total);
                 const u32 q16 = total >> 4;
                 for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
                     *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
@@ -669,7 +674,7 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
     uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
     if (base + RD_ITEMS <= n) {
-        kv = *reinterpret_cast<const uint4 *>(p.kind + base);
+        kv = *reinterpret_cast<const uint4 *>(arr_at(p.kind, base, 16));
     } else if (base < n) {
         u32 d[4] = {NL4, NL4, NL4, NL4};
         for (u32 j = 0; base + j < n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[base + j] << (8 * (j & 3)));
@@ -686,20 +691,23 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
     for (int k = 0; k < RD_ITEMS; k++) copied[k] = 0;
     const u32 kd4[4] = {kv.x, kv.y, kv.z, kv.w};
     if (p.sv.qm && !p.copy_strings) {
-        // the emit masks are there (the string half ran as a launch of its own in front of this one): unescaped length
-        // and "did unescaping change it" of every string without a walk (sj_strings.h string_measure_masks)
+        // selective copy on the emit masks: k_str_measure has left the length of every string (one 64-byte load of the
+        // thread's sixteen entries; entries of other tokens are not read)
+        u32 dv[RD_ITEMS];
+        if (base + RD_ITEMS <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
+                dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RD_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < RD_ITEMS; k++) {
-            if (base + k >= n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
-            const u64 a0 = (u64)p.pos[base + k] + p.sv.lead + 1;
-            const u64 a1 = (base + k + 1 < n ? (u64)p.pos[base + k + 1] : p.len) + p.sv.lead;
-            const StrMeasure sm = string_measure_masks(p.sv, p.rec, p.unit_cnt, a0, a1);
-            u32 out = DLEN_INVALID;
-            if (sm.ok) {
-                out = sm.dl | (sm.copied ? DLEN_COPY : 0u);
-                copied[k] = sm.copied ? sm.dl : 0u;
-            }
-            p.dlen[base + k] = out;
+            const bool str = base + k < n && ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) == K_STRING;
+            copied[k] = (str && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
         }
     } else if (!p.sv.qm) {
         const MsgView mv{p.msg, p.len};
@@ -740,6 +748,51 @@ __device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
     }
 }
 
+// ---- selective copy on the emit masks: the length of every string, one string per lane ------------------------------
+// 1024 tokens per block: the string tokens are compacted into an LDS queue (a wave ballot per 64 tokens) and measured
+// with the lanes packed densely (sj_strings.h string_measure_masks: two record gathers and the closing quote).  Runs
+// between the string half and the token half of k_measure.
+__global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
+    __shared__ u32 s_q[1024];
+    __shared__ u32 s_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 n = token_count(p);
+    const u32 t0 = blockIdx.x * 1024u;
+    if (t0 >= n) return;  // (the grid is sized for the upper bound)
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    u32 kv = 0;
+    const u32 i0 = t0 + (u32)tid * 4u;
+    if (i0 + 4 <= n) kv = *reinterpret_cast<const u32 *>(arr_at(p.kind, i0, 4));
+    else
+        for (u32 j = 0; i0 + j < n; j++) kv |= (u32)p.kind[i0 + j] << (8 * j);
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt += ((kv >> (8 * j)) & 0xffu) == K_STRING ? 1u : 0u;
+    // queue slots: wave scan of the counts, one atomic per wave
+    u32 incl = cnt;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const u32 o = __shfl_up(incl, sft, 64);
+        if (lane >= sft) incl += o;
+    }
+    u32 wb = 0;
+    if (lane == 63 && incl) wb = atomicAdd(&s_n, incl);
+    u32 slot = (u32)__shfl((int)wb, 63, 64) + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (((kv >> (8 * j)) & 0xffu) == K_STRING) s_q[slot++] = i0 + (u32)j;
+    __syncthreads();
+    const u32 ns = s_n;
+    for (u32 j = (u32)tid; j < ns; j += 256) {
+        const u32 i = s_q[j];
+        const u64 a0 = (u64)p.pos[i] + p.sv.lead + 1;
+        const u64 a1 = (i + 1 < n ? (u64)p.pos[i + 1] : p.len) + p.sv.lead;
+        const StrMeasure sm = string_measure_masks(p.sv, p.rec, p.unit_cnt, a0, a1);
+        p.dlen[i] = sm.ok ? (sm.dl | (sm.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
+    }
+}
+
 // Both measuring passes in one launch (they are independent and neither fills the device on its own): blocks below
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
@@ -775,7 +828,7 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p), tiles = (u32)(((u64)n + S2_TILE - 1) / S2_TILE);
     u64 lo64, hi64;
-    seg_range(tiles, 64, seg, lo64, hi64);
+    seg_range(tiles, 64, seg, p.scan_segs, lo64, hi64);
     const u32 lo = (u32)lo64, hi = (u32)hi64;
     // pass 1: the segment's aggregate (32-bit fields wrap; the two sizes are also summed in 64 bits)
     Agg seg_acc = agg_identity();  // meaningful in every thread after the loop
@@ -814,7 +867,7 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
         const SegSum before = seg_lookback(p.seg_tiles, seg, lane, p.st);
         if (lane == 0) {
             s_before = before;
-            if (seg == SCAN_SEGS - 1) {
+            if (seg == p.scan_segs - 1) {
                 const Agg tot = agg_combine(before.a, seg_acc);
                 const unsigned long long words64 = before.w + w64, bytes64 = before.s + s64;
                 p.st->final_depth = tot.d;
@@ -871,8 +924,8 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
 // the tile aggregates (as two launches each cost its ~10 us of fixed latency).
 __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
     if (p.sv.qm) {
-        if (blockIdx.x < SCAN_SEGS) str_scan_body(p, (int)blockIdx.x);
-        else scan_tiles_body(p, (int)blockIdx.x - SCAN_SEGS);
+        if ((int)blockIdx.x < p.scan_segs) str_scan_body(p, (int)blockIdx.x);
+        else scan_tiles_body(p, (int)blockIdx.x - p.scan_segs);
     } else {
         scan_tiles_body(p, (int)blockIdx.x);
     }
@@ -884,8 +937,10 @@ __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
 // Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
 // MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
 // lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
+// (selective copy carries the Strings.B byte count through the scan and the measured lengths in registers: it is given
+// 96 registers -- five waves per SIMD -- instead of spilling at 64)
 template <bool MASKS>
-__global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
+__global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
     __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
@@ -893,7 +948,7 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
     // the tile's strings (from the front) and its atoms and numbers (from the back) in one array -- a tile has 4096
     // tokens, so the two never meet: token index | tape offset inside the tile << 12 | kind << 26
     __shared__ u32 s_q[S2_TILE];
-    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill;
+    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill, s_sbase;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
@@ -908,10 +963,10 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
     u32 pp[S2_ITEMS];
     u32 kv[2] = {NL4, NL4};
     if (base + S2_ITEMS <= n) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(p.pos + base), b = *reinterpret_cast<const uint4 *>(p.pos + base + 4);
+        const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base, 4)), b = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base + 4, 4));
         pp[0] = a.x; pp[1] = a.y; pp[2] = a.z; pp[3] = a.w;
         pp[4] = b.x; pp[5] = b.y; pp[6] = b.z; pp[7] = b.w;
-        const uint2 k2 = *reinterpret_cast<const uint2 *>(p.kind + base);
+        const uint2 k2 = *reinterpret_cast<const uint2 *>(arr_at(p.kind, base, 8));
         kv[0] = k2.x;
         kv[1] = k2.y;
     } else {
@@ -982,7 +1037,7 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         nnum += kd[k] == K_NUM ? 1u : 0u;
-        nstr += (MASKS && is_str[k]) ? 1u : 0u;
+        nstr += (MASKS ? is_str[k] : copied[k] != 0u) ? 1u : 0u;  // selective copy: the strings k_emit_strings will copy
         natom += is_atom[k] ? 1u : 0u;
     }
     // queue slots: the counts of a wave are summed with a DPP scan and one lane draws the wave's ranges (an LDS atomic
@@ -1011,6 +1066,13 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
         dslot = db + ((ex >> 10) & 0x3ffu);
     }
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
+    u32 strq_base = 0;
+    if (!MASKS) {  // the tile's range in the queue of strings to copy (block-uniform count: every wave has added its share)
+        __syncthreads();
+        if (tid == 0 && s_scnt != 0) s_sbase = atomicAdd(&p.st->str_count, s_scnt);
+        __syncthreads();
+        strq_base = s_sbase;
+    }
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 lo = lp.x & 0x3fffu;  // tape words of the tile in front of this token
@@ -1023,8 +1085,14 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
             const bool cp = (dl[k] & DLEN_COPY) != 0;
             if (dl[k] != DLEN_INVALID) {
                 const u64 w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1), w1 = dl[k] & ~DLEN_COPY;
-                *reinterpret_cast<uint4 *>(p.tape + o) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
                 p.str_off[base + k] = tp.s + lp.s;
+                // queued for k_emit_strings with everything it needs (one coalesced 16-byte entry instead of three
+                // gathers per string); a document with more strings than n/2 is invalid: its entries are dropped
+                if (cp && copied[k] != 0u) {
+                    const u32 slot = strq_base + sslot++;
+                    if (slot < p.strq_cap) p.strq[slot] = make_uint4(pp[k], tp.s + lp.s, dl[k] & ~DLEN_COPY, 0u);
+                }
             }
         }
         if (is_atom[k] || (kd[k] == K_NUM && !SJ_EXPBIT(p, 9))) s_q[S2_TILE - 1 - dslot++] = qe | ((u32)kd[k] << 26);
@@ -1056,7 +1124,7 @@ __global__ __launch_bounds__(S2_BLOCK, 8) void k_s2_emit(S2Dev p) {
             const u64 se = c1 + (u64)popc64(r1.em & ~(~0ull << b1));
             const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
             if (!SJ_EXPBIT(p, 2))
-                *reinterpret_cast<uint4 *>(p.tape + T0 + (v >> 12)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
         }
     }
     // ---- atoms: validated from the 8 message bytes at the token; numbers move to the global queue (k_numbers parses
@@ -1136,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
         const u64 rest = p.len - at;
         u32 *w = s_nb[threadIdx.x];
         if (rest >= 32) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(p.msg + at), b = *reinterpret_cast<const uint4 *>(p.msg + at + 16);
+            const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.msg, at, 16)), b = *reinterpret_cast<const uint4 *>(arr_at(p.msg, at + 16, 16));
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
             w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         } else {
@@ -1145,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
         }
         u64 tag = 0, val = 0;
         u32 numlen = 0;
-        const int st = parse_number_head32(reinterpret_cast<const u8 *>(w), p.msg + at, rest, &tag, &val, &numlen);
+        const int st = parse_number_head32(reinterpret_cast<const u8 *>(w), arr_at(p.msg, at, rest), rest, &tag, &val, &numlen);
         if (st == NUM_FAIL) {
             bad = true;
         } else {
@@ -1330,8 +1398,8 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
             const u64 wj = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
             if (dep == 0) {  // a record: the root word in front of its open bracket and the one behind its close bracket
                 const u64 ro = ((u64)'r' << 56) | (p.tape_base + oc + 2), rc = ((u64)'r' << 56) | (p.tape_base + oj - 1);
-                *reinterpret_cast<uint4 *>(p.tape + oj - 1) = make_uint4((u32)ro, (u32)(ro >> 32), (u32)wj, (u32)(wj >> 32));
-                *reinterpret_cast<uint4 *>(p.tape + oc) = make_uint4((u32)wc, (u32)(wc >> 32), (u32)rc, (u32)(rc >> 32));
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, (u64)oj - 1, 2)) = make_uint4((u32)ro, (u32)(ro >> 32), (u32)wj, (u32)(wj >> 32));
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, oc, 2)) = make_uint4((u32)wc, (u32)(wc >> 32), (u32)rc, (u32)(rc >> 32));
             } else {
                 p.tape[oc] = wc;
                 p.tape[oj] = wj;
@@ -1343,25 +1411,33 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
 
 // ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
 __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
+    if (p.sv.qm) {
+        // on the emit masks: the unescaped bytes of every string wait in k_str_emit's compaction (str_out), the strings
+        // that changed were queued by k_s2_emit: one string per lane, grid-stride over the queue
+        u32 cnt = p.st->str_count;
+        if (cnt > p.strq_cap) cnt = p.strq_cap;
+        for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
+            const uint4 e = p.strq[j];
+            const u32 n = e.z, so = e.y;
+            if ((u64)so + n > p.strings_cap) continue;
+            const u8 *src = arr_at(p.str_out, emitted_before(p.unit_cnt, p.rec, (u64)e.x + p.sv.lead + 1), (u64)n + 8);  // (the tail reads 8)
+            u8 *dst = arr_at(p.strings, so, n);
+            u32 b = 0;
+            for (; b + 8 <= n; b += 8) store_u64(dst + b, load_u64(src + b));  // (neither side is aligned: fine on gfx950)
+            if (b < n) store_bytes(dst + b, load_u64(src + b), n - b);  // (the scratch buffer has 64 bytes of slack)
+        }
+        return;
+    }
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= token_count(p)) return;
     if (p.kind[i] != K_STRING) return;
     const u32 dl = p.dlen[i];
     if (dl == DLEN_INVALID || !(dl & DLEN_COPY)) return;
     const u32 so = p.str_off[i];
-    const u32 n = dl & ~DLEN_COPY;
-    if ((u64)so + n > p.strings_cap) return;
-    if (p.sv.qm) {  // the unescaped bytes of every string wait in k_str_emit's compaction: E(first content byte) on
-        const u8 *src = p.str_out + emitted_before(p.unit_cnt, p.rec, (u64)p.pos[i] + p.sv.lead + 1);
-        u8 *dst = p.strings + so;
-        u32 j = 0;
-        for (; j + 8 <= n; j += 8) store_u64(dst + j, load_u64(src + j));  // (neither side is aligned: fine on gfx950)
-        for (; j < n; j++) dst[j] = src[j];
-        return;
-    }
+    if ((u64)so + (dl & ~DLEN_COPY) > p.strings_cap) return;
     const MsgView mv{p.msg, p.len};
     u32 sl, dl2;
-    string_walk(mv, p.pos[i], p.strings + so, &sl, &dl2);
+    string_walk(mv, p.pos[i], arr_at(p.strings, so, dl & ~DLEN_COPY), &sl, &dl2);
 }
 
 // ---- exact tie-break for >19-digit mantissas whose neighbours disagree --------------------------------------------
@@ -1372,10 +1448,10 @@ __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
         const u32 at = p.bigq[2 * q], o = p.bigq[2 * q + 1];
         u64 tag, val;
         u32 numlen = 0;
-        (void)parse_number(p.msg + at, (u32)(p.len - at), &tag, &val, &numlen);
+        (void)parse_number(arr_at(p.msg, at, p.len - at), (u32)(p.len - at), &tag, &val, &numlen);
         const u64 cand = p.tape[o + 1];
         const u64 sign = cand & 0x8000000000000000ull;
-        const u64 r = bignum_round(p.msg + at, numlen, cand & ~0x8000000000000000ull, X, Y);
+        const u64 r = bignum_round(arr_at(p.msg, at, numlen), numlen, cand & ~0x8000000000000000ull, X, Y);
         if (r == 0x7ff0000000000000ull) atomicOr(&p.st->err, 1u);  // strconv.ErrRange
         p.tape[o + 1] = r | sign;
     }
@@ -1403,6 +1479,7 @@ size_t stage2_workspace_bytes(size_t n) {
     size_t b = 256;
     b += align_up(n + 16, 256);                     // br_info
     b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
+    b += align_up((n / 2 + 8) * 16, 256);           // strq
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
@@ -1426,25 +1503,28 @@ static S2Dev stage2_view(const S2Args &a) {
     p.st = reinterpret_cast<S2State *>(a.ws_zero);
     p.seg_units = reinterpret_cast<SegSlot *>(reinterpret_cast<char *>(a.ws_zero) + sizeof(S2State));
     p.seg_tiles = p.seg_units + SCAN_SEGS;
-    p.msg = reinterpret_cast<const u8 *>(a.d_msg);
+    p.msg = SJ_ARR(reinterpret_cast<const u8 *>(a.d_msg), a.len, A_MSG);
     p.len = a.len;
-    p.pos = a.d_pos;
+    p.pos = SJ_ARR(a.d_pos, n, A_POS);
     p.n = (u32)n;
     p.n_dev = a.n_dev;
     p.ndjson = a.flags & 1u;
     p.copy_strings = (a.flags >> 1) & 1u;
     p.no_abs = (a.flags & S2_FLAG_NO_ABS) ? 1u : 0u;
-    p.kind = a.d_kind;
-    p.br_info = reinterpret_cast<u8 *>(carve(n + 16));
-    p.dlen = reinterpret_cast<u32 *>(carve(n * 4));
-    p.str_off = reinterpret_cast<u32 *>(carve(n * 4));
-    p.nl_off = reinterpret_cast<u32 *>(carve(n * 4));
-    p.numq = reinterpret_cast<uint2 *>(carve(n * 8));
-    p.bigq = reinterpret_cast<u32 *>(carve(n * 8));
-    p.br_depth = reinterpret_cast<i32 *>(carve(n * 4));
-    p.br_off = reinterpret_cast<u32 *>(carve(n * 4));
+    p.kind = SJ_ARR(a.d_kind, n, A_KIND);
+    p.br_info = SJ_ARR(reinterpret_cast<u8 *>(carve(n + 16)), n + 16, A_BR_INFO);
+    p.dlen = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_DLEN);
+    p.str_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_STR_OFF);
+    p.nl_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_NL_OFF);
+    p.numq = SJ_ARR(reinterpret_cast<uint2 *>(carve(n * 8)), n, A_NUMQ);
+    p.bigq = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 8)), 2 * n, A_BIGQ);
+    p.strq_cap = (u32)(n / 2 + 8);
+    p.strq = SJ_ARR(reinterpret_cast<uint4 *>(carve((size_t)p.strq_cap * 16)), p.strq_cap, A_STRQ);
+    p.br_depth = SJ_ARR(reinterpret_cast<i32 *>(carve(n * 4)), n, A_BR_DEPTH);
+    p.br_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_BR_OFF);
     p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
-    p.agg = reinterpret_cast<TileAgg *>(carve((size_t)(p.tiles + 1) * sizeof(TileAgg)));
+    p.scan_segs = (a.len <= ((size_t)32 << 20) && p.tiles <= 8192) ? 1 : SCAN_SEGS;  // 8192 units / 8192 tiles: one round of one block
+    p.agg = SJ_ARR(reinterpret_cast<TileAgg *>(carve((size_t)(p.tiles + 1) * sizeof(TileAgg))), p.tiles + 1, A_AGG);
     p.nlev = 1;
     p.lev[0] = nullptr;
     p.lev_size[0] = n;
@@ -1452,13 +1532,13 @@ static S2Dev stage2_view(const S2Args &a) {
         u64 sz = n;
         while (sz > 64 && p.nlev < MinTree::MAXLEV) {
             sz = (sz + 63) / 64;
-            p.lev[p.nlev] = reinterpret_cast<i32 *>(carve(sz * 4));
+            p.lev[p.nlev] = SJ_ARR(reinterpret_cast<i32 *>(carve(sz * 4)), sz, A_LEV);
             p.lev_size[p.nlev] = sz;
             p.nlev++;
         }
     }
-    p.tape = a.d_tape;
-    p.strings = a.d_strings;
+    p.tape = SJ_ARR(a.d_tape, a.tape_cap, A_TAPE);
+    p.strings = SJ_ARR(a.d_strings, a.strings_cap, A_STRINGS);
     p.tape_cap = a.tape_cap;
     p.strings_cap = a.strings_cap;
     p.tape_base = a.tape_base;
@@ -1466,9 +1546,10 @@ static S2Dev stage2_view(const S2Args &a) {
     p.msg_base = a.msg_base;
     // byte-parallel strings: only when every string is copied and stage 1 left its masks
     const uintptr_t addr = reinterpret_cast<uintptr_t>(a.d_msg);
-    p.sv.base = reinterpret_cast<const u8 *>(addr & ~(uintptr_t)63);
     p.sv.lead = addr & 63;
     p.sv.end = p.sv.lead + a.len;
+    // (k_str_emit reads whole 64-byte chunks: the arenas and the callers' device buffers carry that much slack)
+    p.sv.base = SJ_ARR(reinterpret_cast<const u8 *>(addr & ~(uintptr_t)63), (p.sv.end + 63) / 64 * 64, A_SV_BASE);
     p.sv.qm = p.sv.q = p.sv.st = nullptr;
     p.sv.unit_h = nullptr;
     p.sv.unit_slow = nullptr;
@@ -1479,17 +1560,17 @@ static S2Dev stage2_view(const S2Args &a) {
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
 #endif
-    p.str_out = a.d_strings;
-    if (a.str_aux && !p.copy_strings) p.str_out = a.d_strings_tmp;
+    p.str_out = p.strings;
+    if (a.str_aux && !p.copy_strings) p.str_out = SJ_ARR(a.d_strings_tmp, a.strings_cap, A_STR_OUT);
     if (a.str_aux && (p.copy_strings || a.d_strings_tmp)) {
         const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
-        p.sv.qm = x.qm;
-        p.sv.q = x.q;
-        p.sv.st = x.st;
-        p.sv.unit_h = x.unit_h;
-        p.sv.unit_slow = x.unit_slow;
-        p.rec = reinterpret_cast<ChunkRec *>(x.rec);
-        p.unit_cnt = x.unit_cnt;
+        p.sv.qm = SJ_ARR((const u64 *)x.qm, x.chunks, A_SV_QM);
+        p.sv.q = SJ_ARR((const u64 *)x.q, x.chunks, A_SV_Q);
+        p.sv.st = SJ_ARR((const u64 *)x.st, x.chunks, A_SV_ST);
+        p.sv.unit_h = SJ_ARR((const u8 *)x.unit_h, x.units, A_SV_UNIT_H);
+        p.sv.unit_slow = SJ_ARR((const u64 *)x.unit_slow, x.units, A_SV_UNIT_SLOW);
+        p.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(x.rec), x.chunks, A_REC);
+        p.unit_cnt = SJ_ARR(x.unit_cnt, x.units, A_UNIT_CNT);
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
     return p;
@@ -1501,7 +1582,7 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
     a.n = n_tokens;
     a.ws = ws;
     const S2Dev p = stage2_view(a);
-    *nl_off = p.nl_off;
+    *nl_off = arr_raw(p.nl_off);
 }
 
 // Phase 1: string masks, tile aggregates and the two device-wide scans.  Afterwards S2State holds tape_len /
@@ -1513,12 +1594,13 @@ hipError_t stage2_launch_measure(const S2Args &a) {
         // selective copy: the token half measures every string from the records of the string half
         const u32 mblocks = persistent_blocks(k_measure, (p.units + 3) / 4);
         hipLaunchKernelGGL(k_measure, dim3(mblocks), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
+        hipLaunchKernelGGL(k_str_measure, dim3((u32)((a.n + 1023) / 1024)), dim3(256), 0, a.stream, p);
         hipLaunchKernelGGL(k_measure, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p, 0u);
     } else {
         const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
         hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
     }
-    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * SCAN_SEGS : SCAN_SEGS), dim3(1024), 0, a.stream, p);
+    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * p.scan_segs : p.scan_segs), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
 }
 
@@ -1561,7 +1643,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
         const u32 lblocks = (u32)(want < 2048 ? want : 2048);
         hipLaunchKernelGGL(k_numbers, dim3(nblocks + lblocks), dim3(256), 0, a.stream, p, nblocks);
     }
-    if (!masks_copy) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
+    if (!masks_copy) hipLaunchKernelGGL(k_emit_strings, dim3(p.sv.qm ? (gb < 2048 ? gb : 2048) : gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 2048 ? gb : 2048), dim3(256), 0, a.stream, p);  // (8 waves per SIMD resident)
     if (beside) {
@@ -1595,6 +1677,58 @@ hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap) {
     hipLaunchKernelGGL(k_pack, dim3(128), dim3(256), 0, a.stream, (const S2State *)a.ws_zero, (const u64 *)a.d_tape, (const u8 *)a.d_strings,
                        (a.str_aux && (a.flags & 2u)) ? 1u : 0u, (u8 *)h_dst, (u64)cap);
     return hipGetLastError();
+}
+
+// ---- debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): the record of the first out-of-bounds access, read and cleared -------
+// returns 0 in the product build; 1 in the debug build with *hits = accesses that were out of bounds since the last call
+int stage2_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size) {
+    *hits = *id = 0;
+    *index = *size = 0;
+#if defined(SJ_DEBUG_BOUNDS)
+    BoundsHit h = {};
+    if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_bounds_hit), sizeof h) != hipSuccess) return 1;
+    if (h.hits) {
+        const BoundsHit zero = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_hit), &zero, sizeof zero);
+    }
+    *hits = h.hits;
+    *id = h.id;
+    *index = h.index;
+    *size = h.size;
+    return 1;
+#else
+    return 0;
+#endif
+}
+#if defined(SJ_DEBUG_BOUNDS)
+__global__ void k_bounds_selftest(Arr<u32> a, u32 *out) {
+    u32 v = a[3];               // in bounds
+    v += a[16];                 // one behind the end: recorded, redirected to a[15]
+    v += *arr_at(a, 14, 4);     // elements 14..17: recorded, redirected to 12..15
+    *out = v;
+}
+#endif
+// the checker checked: -1 in the product build, else the number of violations a kernel with two deliberate ones recorded
+int stage2_debug_bounds_selftest() {
+#if defined(SJ_DEBUG_BOUNDS)
+    u32 *d = nullptr, host[17];
+    for (u32 k = 0; k < 17; k++) host[k] = k;
+    if (hipMalloc((void **)&d, sizeof host) != hipSuccess) return -2;
+    (void)hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice);
+    unsigned hits, id;
+    unsigned long long index, size;
+    (void)stage2_debug_bounds(&hits, &id, &index, &size);  // clear
+    hipLaunchKernelGGL(k_bounds_selftest, dim3(1), dim3(1), 0, 0, Arr<u32>(d, 16, A_SELFTEST), d + 16);
+    (void)hipDeviceSynchronize();
+    u32 out = 0;
+    (void)hipMemcpy(&out, d + 16, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)stage2_debug_bounds(&hits, &id, &index, &size);
+    if (out != 3 + 15 + 12 || id != A_SELFTEST || index != 16 || size != 16) return -3;
+    return (int)hits;
+#else
+    return -1;
+#endif
 }
 
 // exact tie-break of the queued numbers (S2State::bignum_count != 0 after the emit phase: rare)

@@ -73,6 +73,7 @@ SYMBOLS = {
     "sjhip_stream_set_filter": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "sjhip_stream_release": (C.c_int, [C.c_void_p]),
     "sjhip_stage1_set_variant": (C.c_int, [C.c_int]),
+    "sjhip_debug_bounds_selftest": (C.c_int, []),
     "sjhip_stage1_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_uint), intp, intp]),
     "sjhip_find_odd_backslash_sequences": (C.c_int, [C.c_void_p, C.c_char_p, u64p, u64p]),

@@ -1,0 +1,58 @@
+"""The bounds-checked debug build (csrc/sj_bounds.h, -DSJ_DEBUG_BOUNDS -> libsjhip_dbg.so): every array of the parse
+path behind a checked view, a violation fails the parse.  CPU: the product build says it is not a debug build and the
+parse kernels compile under the flag.  GPU: the debug library's self-test records its two deliberate violations, and
+documents of every kind parse to the oracle's result with no violation (tools/gpu_debug_bounds.sh runs the whole GPU
+suite on that build; profiles/r04_debug_bounds.txt keeps the run)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "simdjson-go_amd")
+
+
+def test_product_build_is_not_a_debug_build():
+    import sjhip
+    assert sjhip.lib().sjhip_debug_bounds_selftest() == -1
+
+
+def test_parse_kernels_compile_under_the_flag(tmp_path):
+    out = tmp_path / "stage2_dbg.o"
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O1", "-std=c++17",
+                           "-DSJ_DEBUG_BOUNDS", "-c", os.path.join(PKG, "csrc", "stage2.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    assert out.stat().st_size > 0
+
+
+@pytest.mark.gpu
+def test_debug_build_on_the_gpu():
+    import __graft_entry__ as G
+    lib = G.build_lib(debug_bounds=True)
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import fixtures, oracle_lib as O, sjhip
+assert sjhip.lib().sjhip_debug_bounds_selftest() == 2
+ctx = sjhip.Context(0)
+docs = [(fixtures.load(n), n == "parking-citations") for n in ("twitter", "twitterescaped", "canada", "parking-citations", "marine_ik", "payload-small")]
+docs += [(b"[" + b",".join([b"1"] * 40000) + b"]", False), (fixtures.load("parking-citations") * 40, True), (b'{"a":"\\ud83d\\ude00\\u00e9"}', False)]
+for data, nd in docs:
+    for copy in (True, False):
+        ref = O.parse(data, ndjson=nd, copy_strings=copy)
+        pj = ctx.parse(data, ndjson=nd, copy_strings=copy)
+        assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
+for bad in (b'{"a":[1,2}', b'{"a":"x', b'["\\uZZZZ"]', b"[" * 5000):
+    try:
+        ctx.parse(bad)
+        raise SystemExit("accepted " + repr(bad[:20]))
+    except sjhip.ParseError as e:
+        assert e.code in (1, 2), (bad[:20], e.code, str(e))
+print("OK")
+''' % (PKG, HERE)
+    env = dict(os.environ, SJHIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith(b"OK"), (out.stdout[-2000:], out.stderr[-3000:])

@@ -1,4 +1,4 @@
-"""Whole parse of one BASELINE workload in a loop (for rocprofv3): python tools/parse_loop.py twitter|parking [iters]"""
+"""Whole parse of one BASELINE workload in a loop (for rocprofv3): python tools/parse_loop.py twitter|parking [iters] [nocopy]"""
 import os
 import sys
 
@@ -11,6 +11,7 @@ import workloads  # noqa: E402
 
 which = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+copy = not (len(sys.argv) > 3 and sys.argv[3] == "nocopy")
 if which == "twitter":
     doc, nd = workloads.c2_twitter_array(426), False
 else:
@@ -20,5 +21,5 @@ d[:len(doc)].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
 torch.cuda.synchronize()
 ctx = sjhip.Context(0)
 for _ in range(iters + 1):
-    tl, sl = ctx.parse_device(d.data_ptr(), len(doc), ndjson=nd, copy_strings=True)
+    tl, sl = ctx.parse_device(d.data_ptr(), len(doc), ndjson=nd, copy_strings=copy)
 print(which, len(doc), tl, sl)
