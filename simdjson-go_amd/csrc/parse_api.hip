@@ -234,6 +234,15 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     };
     int rc = run();
     if (rc) return rc;
+    {  // debug build: an out-of-bounds access anywhere in the stage-2 kernels fails the parse, whatever its verdict
+        unsigned hits = 0, id = 0;
+        unsigned long long index = 0, size = 0;
+        if (stage2_debug_bounds(&hits, &id, &index, &size) && hits) {
+            ctx_set_error(ctx, "bounds check: %u out-of-bounds accesses, the first to array %u (sj_bounds.h ArrId) at element %llu of %llu",
+                          hits, id, index, size);
+            return SJHIP_ERR_HIP;
+        }
+    }
     if (ctx->p_deferred) {  // stage 1's verdict first, as in parseMessage (parse_json_amd64.go:97-105,123-126)
         size_t n = 0;
         int ok = 0;
@@ -251,15 +260,6 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         HIPCHK(stage2_launch_measure(s2_args(ctx, tape_base, strings_base, msg_base)), "stage2 launch (measure, per-string)");
         rc = run();
         if (rc) return rc;
-    }
-    {  // debug build: an out-of-bounds access anywhere in the stage-2 kernels fails the parse, whatever its verdict
-        unsigned hits = 0, id = 0;
-        unsigned long long index = 0, size = 0;
-        if (stage2_debug_bounds(&hits, &id, &index, &size) && hits) {
-            ctx_set_error(ctx, "bounds check: %u out-of-bounds accesses, the first to array %u (sj_bounds.h ArrId) at element %llu of %llu",
-                          hits, id, index, size);
-            return SJHIP_ERR_HIP;
-        }
     }
     if (hs->err & 8u) {  // a bounded spin loop of a scan kernel ran out: internal error, never a verdict
         ctx_set_error(ctx, "stage-2 scan aborted (internal synchronisation timeout)");

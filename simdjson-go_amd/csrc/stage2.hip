@@ -477,7 +477,11 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         return x;
     };
     auto load_chunk = [&](u64 u, u64 em, u32 (&w)[16]) {
-        if (u < p.units && em != 0 && !SJ_EXPBIT(p, 5)) {  // the chunk holds message bytes: its 64-byte line is readable
+        // The chunk must hold message bytes: then its 64-byte line is readable.  An emit mask alone does not say so: a
+        // document that ends inside a string (a stage-1 error) is "in a string" through the blanks stage 1 pads its last
+        // unit with, up to 4 KiB behind the message -- found by the bounds-checked build (sj_bounds.h); in the product
+        // build those reads went past the end of the caller's buffer.
+        if (u < p.units && em != 0 && (u * 64 + lane) * 64 < p.sv.end && !SJ_EXPBIT(p, 5)) {
             const uint4 *src = reinterpret_cast<const uint4 *>(arr_at(p.sv.base, (u * 64 + lane) * 64, 64));
 #pragma unroll
             for (int q = 0; q < 4; q++) {

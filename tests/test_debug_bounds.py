@@ -45,7 +45,10 @@ for data, nd in docs:
         ref = O.parse(data, ndjson=nd, copy_strings=copy)
         pj = ctx.parse(data, ndjson=nd, copy_strings=copy)
         assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
-for bad in (b'{"a":[1,2}', b'{"a":"x', b'["\\uZZZZ"]', b"[" * 5000):
+# documents that end inside a string: stage 1 pads the last 4 KiB unit with blanks, which are then "in the string" -- the
+# string kernel used to read the message up to 4 KiB past its end for them (found by this build, fixed in k_str_emit)
+unterminated = [b'{"a":"x', b'["', b'{"a":"' + b"x" * 5000, b'{"k":[1,2,"' + b"y" * 70, fixtures.load("twitter")[:300001] + b'"']
+for bad in [b'{"a":[1,2}', b'["\\uZZZZ"]', b"[" * 5000] + unterminated:
     try:
         ctx.parse(bad)
         raise SystemExit("accepted " + repr(bad[:20]))
