@@ -131,6 +131,13 @@ extern "C" int sj_selftest_parse_number(const uint8_t *buf, size_t len, uint64_t
     return st;
 }
 
+// the integer fast path of k_s2_emit on its own: 1 and *val if it takes the number at buf[0..len), else 0
+extern "C" int sj_selftest_int_fast(const uint8_t *buf, size_t len, uint64_t *val) {
+    u64 w[3] = {0, 0, 0};
+    for (size_t k = 0; k < 24 && k < len; k++) w[k >> 3] |= (u64)buf[k] << (8 * (k & 7));
+    return parse_int_fast(w[0], w[1], w[2], val) ? 1 : 0;
+}
+
 // ---- whole parse replay: stage 1 + the data-parallel stage 2 of sj_stage2.h ---------------------
 // Every "kernel" of stage2.hip is a plain loop over the same per-token functions here; the scans
 // are sequential sums.  Used by the CPU test-suite to check the algorithm against the oracle.
@@ -362,7 +369,14 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         } else if (k == K_NUM) {
             u64 tag, val;
             int ub;
-            if (!sj_selftest_parse_number(msg + pos[i], len - pos[i], &tag, &val, &ub)) bad = 1;
+            const bool okn = sj_selftest_parse_number(msg + pos[i], len - pos[i], &tag, &val, &ub) != 0;
+            {  // the integer fast path of k_s2_emit decides nothing the general routine decides differently
+                u64 fv = 0;
+                if (parse_int_fast(load8_guarded(mv, pos[i]), load8_guarded(mv, (u64)pos[i] + 8), load8_guarded(mv, (u64)pos[i] + 16), &fv) &&
+                    (!okn || tag != ((u64)'l' << 56) || val != fv))
+                    return 98;
+            }
+            if (!okn) bad = 1;
             else {
                 tape[toff[i]] = tag;
                 tape[toff[i] + 1] = val;

@@ -206,6 +206,56 @@ SJ_HD u64 double_to_bits(double d) {
 
 enum NumStatus : int { NUM_FAIL = 0, NUM_OK = 1, NUM_NEEDS_BIGNUM = 2 };
 
+// ---- the common case in the token kernel: a plain integer of up to 18 digits ------------------------------------------
+// parseNumber (parse_number.go:65-135) turns [-]digits without '.', 'e', 'E' into an int64 when strconv.ParseInt takes
+// it; up to 18 digits always fit.  k_s2_emit has the token's position anyway: with the first 24 bytes of the number in
+// three words (first byte = lowest byte of w0, zero behind the end of the message) this decides in registers whether
+// the number is of that shape -- optional '-', 1..18 digits, no leading zero in front of another digit, and then one of
+// the bytes that end a value for parseNumber (',' '}' ']' ' ' '\t' '\r' '\n' ':', :75-84) -- and returns its value.  Every
+// other number (floats, 19 and 20 digit integers, anything malformed) is left to the general routine (k_numbers), so
+// nothing is decided here that parse_number would decide differently; the host replay compares the two on every number.
+SJ_HD u64 digits8(u64 d) {  // eight digit VALUES (0..9) per byte, first digit in the lowest byte -> their decimal value
+    d = (d * 2561u) >> 8;                                       // pairs: 10 * a + b
+    d = ((d & 0x00ff00ff00ff00ffull) * 6553601u) >> 16;         // quads
+    return ((d & 0x0000ffff0000ffffull) * 42949672960001ull) >> 32;
+}
+SJ_HD bool parse_int_fast(u64 w0, u64 w1, u64 w2, u64 *val) {
+    const bool neg = (u8)w0 == '-';
+    if (neg) {  // drop the sign byte: the window moves one byte down
+        w0 = (w0 >> 8) | (w1 << 56);
+        w1 = (w1 >> 8) | (w2 << 56);
+        w2 >>= 8;
+    }
+    const u64 Z = 0x3030303030303030ull, K7 = 0x7f7f7f7f7f7f7f7full, K76 = 0x7676767676767676ull, H = 0x8080808080808080ull;
+    const u64 d0 = w0 ^ Z, d1 = w1 ^ Z, d2 = w2 ^ Z;
+    // 0x80 in every byte that is not a digit (exact: no carry crosses a byte)
+    const u64 n0 = (((d0 & K7) + K76) | d0) & H, n1 = (((d1 & K7) + K76) | d1) & H, n2 = (((d2 & K7) + K76) | d2) & H;
+    u32 n;  // digits in front of the first other byte
+    if (n0) n = (u32)ctz64(n0) >> 3;
+    else if (n1) n = 8u + ((u32)ctz64(n1) >> 3);
+    else if (n2) n = 16u + ((u32)ctz64(n2) >> 3);
+    else return false;
+    if (n == 0 || n > 18) return false;
+    if (n > 1 && (u8)w0 == '0') return false;  // "0123": the general routine rejects it
+    const u8 t = n < 8 ? (u8)(w0 >> (8 * n)) : (n < 16 ? (u8)(w1 >> (8 * (n - 8))) : (u8)(w2 >> (8 * (n - 16))));
+    if (!(t == ',' || t == '}' || t == ']' || t == ' ' || t == '\t' || t == '\r' || t == '\n' || t == ':')) return false;
+    // value: the digits of a partly filled word are moved to its high bytes (the low bytes become leading zeros)
+    u64 v;
+    if (n <= 8) {
+        v = digits8(d0 << (8 * (8 - n)));
+    } else if (n <= 16) {
+        const u32 k = n - 8;  // 1..8 digits in the second word
+        u64 p10 = 10;
+        for (u32 i = 1; i < k; i++) p10 *= 10;
+        v = digits8(d0) * p10 + digits8(d1 << (8 * (8 - k)));
+    } else {
+        const u32 k = n - 16;  // 1..2
+        v = (digits8(d0) * 100000000ull + digits8(d1)) * (k == 1 ? 10ull : 100ull) + digits8(d2 << (8 * (8 - k)));
+    }
+    *val = neg ? (u64)0 - v : v;
+    return true;
+}
+
 // ParseFloat(s, 64) on a syntactically scanned decimal.  *bits excludes nothing (sign applied).
 // NUM_NEEDS_BIGNUM: *bits holds the candidate for the truncated mantissa (the lower neighbour).
 SJ_HD int decimal_to_double(const Decimal &d, u64 *bits) {

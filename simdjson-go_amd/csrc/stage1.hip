@@ -971,7 +971,7 @@ struct S1Variant {
     int depth;  // 0: the barrier kernel; otherwise tiles in flight of the barrier-free kernel
 };
 static const S1Variant S1_VARIANTS[] = {{512, 2, 4, 0}, {1024, 2, 4, 0}, {768, 2, 3, 0},
-                                        {1024, 2, 4, 2}, {1024, 2, 4, 3}};
+                                        {1024, 2, 4, 2}, {1024, 2, 4, 3}, {1024, 1, 4, 0}};
 static constexpr int S1_NVARIANTS = (int)(sizeof S1_VARIANTS / sizeof S1_VARIANTS[0]);
 static int g_s1_variant = -1;
 int stage1_set_variant(int v) {  // -1: back to SJHIP_S1_VARIANT / the default; returns the variant in effect
@@ -1137,7 +1137,8 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         if (v.depth == 2) S1_LAUNCH_NB(1024, 2, 2, 4);
         else S1_LAUNCH_NB(1024, 2, 3, 4);
     } else {
-        if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
+        if (v.block == 1024 && v.ch == 1) S1_LAUNCH(stage1_kernel, 1024, 1, 4);
+        else if (v.block == 1024) S1_LAUNCH(stage1_kernel, 1024, 2, 4);
         else if (v.block == 768) S1_LAUNCH(stage1_kernel, 768, 2, 3);
         else S1_LAUNCH(stage1_kernel, 512, 2, 4);
     }

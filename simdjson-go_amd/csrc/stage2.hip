@@ -92,8 +92,8 @@ struct S2Dev {
     int nlev;
     S2State *st;
     SegSlot *seg_units, *seg_tiles;  // [SCAN_SEGS] segment aggregates of the two multi-block scans (zeroed with st)
-    int scan_segs;                   // blocks per scan: SCAN_SEGS, or 1 for documents one block scans in a single round
-                                     // (no aggregates to publish or wait for: k_scans costs a small document 4 us, not 9-17)
+    int unit_segs, tile_segs;        // blocks of the unit scan / of the tile scan: SCAN_SEGS, or 1 where one block is through in
+                                     // a single short round (<= 16 384 units, <= 1024 tiles): nothing to publish or wait for
     Arr<u64> tape;
     Arr<u8> strings;
     Arr<u8> str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
@@ -344,7 +344,7 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Arr<u32> data = p.unit_cnt;
     u64 lo, hi;
-    seg_range(p.units, 1024, seg, p.scan_segs, lo, hi);
+    seg_range(p.units, 1024, seg, p.unit_segs, lo, hi);
     // pass 1: the segment's byte count
     unsigned long long mine = 0;
     for (u64 start = lo; start < hi; start += 16384) {
@@ -368,7 +368,7 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
         const SegSum before = seg_lookback(p.seg_units, seg, lane, p.st);
         if (lane == 0) {
             s_prefix = before.s;
-            if (seg == p.scan_segs - 1) p.st->strings_len_masks = before.s + tot;
+            if (seg == p.unit_segs - 1) p.st->strings_len_masks = before.s + tot;
         }
     }
     __syncthreads();
@@ -832,7 +832,7 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p), tiles = (u32)(((u64)n + S2_TILE - 1) / S2_TILE);
     u64 lo64, hi64;
-    seg_range(tiles, 64, seg, p.scan_segs, lo64, hi64);
+    seg_range(tiles, 64, seg, p.tile_segs, lo64, hi64);
     const u32 lo = (u32)lo64, hi = (u32)hi64;
     // pass 1: the segment's aggregate (32-bit fields wrap; the two sizes are also summed in 64 bits)
     Agg seg_acc = agg_identity();  // meaningful in every thread after the loop
@@ -871,7 +871,7 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
         const SegSum before = seg_lookback(p.seg_tiles, seg, lane, p.st);
         if (lane == 0) {
             s_before = before;
-            if (seg == p.scan_segs - 1) {
+            if (seg == p.tile_segs - 1) {
                 const Agg tot = agg_combine(before.a, seg_acc);
                 const unsigned long long words64 = before.w + w64, bytes64 = before.s + s64;
                 p.st->final_depth = tot.d;
@@ -928,8 +928,8 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
 // the tile aggregates (as two launches each cost its ~10 us of fixed latency).
 __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
     if (p.sv.qm) {
-        if ((int)blockIdx.x < p.scan_segs) str_scan_body(p, (int)blockIdx.x);
-        else scan_tiles_body(p, (int)blockIdx.x - p.scan_segs);
+        if ((int)blockIdx.x < p.unit_segs) str_scan_body(p, (int)blockIdx.x);
+        else scan_tiles_body(p, (int)blockIdx.x - p.unit_segs);
     } else {
         scan_tiles_body(p, (int)blockIdx.x);
     }
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
             if (dl[k] != DLEN_INVALID) {
                 const u64 w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1), w1 = dl[k] & ~DLEN_COPY;
                 *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-                p.str_off[base + k] = tp.s + lp.s;
+                if (!p.sv.qm) p.str_off[base + k] = tp.s + lp.s;  // (per-string walks: k_emit_strings looks the offset up per token)
                 // queued for k_emit_strings with everything it needs (one coalesced 16-byte entry instead of three
                 // gathers per string); a document with more strings than n/2 is invalid: its entries are dropped
                 if (cp && copied[k] != 0u) {
@@ -1142,7 +1142,18 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
             const u32 v = s_q[S2_TILE - 1 - j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x3fffu);
             const u8 ak = (u8)(v >> 26);
             if (ak == K_NUM) {
-                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(at, o);
+                // A plain integer of up to 18 digits is parsed here, from three 8-byte loads, and its two words leave with
+                // the tile's own stretch of the tape (sj_number.h parse_int_fast); everything else is queued for
+                // k_numbers (the slots of the numbers taken here stay unused: k_numbers skips them).  twitter.json holds
+                // 2 840 numbers, all but a handful such integers: a queue entry written and read, a 64-byte sector of the
+                // message fetched a second time and a 16-byte tape store on its own sector less for each of them.
+                u64 iv = 0;
+                const bool fast = !SJ_EXPBIT(p, 9) && parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
+                if (fast) {
+                    const u64 tw = (u64)'l' << 56;
+                    if (!SJ_EXPBIT(p, 2)) *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
+                }
+                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(fast ? 0xffffffffu : at, o);
             } else {
                 bad |= !atom_valid_word(SJ_EXPBIT(p, 1) ? 0ull : load8_guarded(mv, at), p.len - at, ak);
                 if (!SJ_EXPBIT(p, 2)) p.tape[o] = atom_word(ak);
@@ -1159,15 +1170,15 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
 // only need k_s2_emit's output; as launches of their own they cost 25 us): a block takes 4096 depths -- one level-2
 // entry -- at a time, one wave per 64 of them (a level-1 entry), and folds the 64 minima through LDS.
 __device__ __forceinline__ MinTree make_tree(const S2Dev &p);
-__global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
-    __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
-    if (blockIdx.x >= nblocks) {
+// bid / nb: this block's index among the nb blocks that share the role (several roles run in one launch)
+__device__ __forceinline__ void tree12_body(const S2Dev &p, u32 bid, u32 nb) {
+    __shared__ i32 s_min[4];
+    {
         const MinTree mt = make_tree(p);
         if (mt.nlev < 2) return;
-        i32 *s_min = reinterpret_cast<i32 *>(&s_nb[0][0]);  // [4]
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const u64 n2 = (mt.size[1] + 63) / 64;  // level-2 entries (also when the tree has no level 2: one pass)
-        for (u64 b = blockIdx.x - nblocks; b < n2; b += gridDim.x - nblocks) {
+        for (u64 b = bid; b < n2; b += nb) {
             i32 wmin = 0x7fffffff;
             i32 dv[16];  // the sixteen groups of the wave: all loads first (one round trip instead of sixteen)
 #pragma unroll
@@ -1198,13 +1209,16 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
                 }
             }
         }
-        return;
     }
+}
+__device__ __forceinline__ void numbers_body(const S2Dev &p, u32 bid, u32 nblocks) {
+    __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
     const u32 cnt = p.st->num_count;
     bool bad = false;
-    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += nblocks * 256) {
+    for (u32 j = bid * 256 + threadIdx.x; j < cnt; j += nblocks * 256) {
         const uint2 q = p.numq[j];
         const u32 at = q.x;
+        if (at == 0xffffffffu) continue;  // an integer k_s2_emit has parsed itself
         const u64 rest = p.len - at;
         u32 *w = s_nb[threadIdx.x];
         if (rest >= 32) {
@@ -1231,6 +1245,10 @@ __global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
         }
     }
     if (bad) atomicOr(&p.st->err, 1u);
+}
+__global__ __launch_bounds__(256) void k_numbers(S2Dev p, u32 nblocks) {
+    if (blockIdx.x >= nblocks) tree12_body(p, blockIdx.x - nblocks, gridDim.x - nblocks);
+    else numbers_body(p, blockIdx.x, nblocks);
 }
 
 // ---- kernel 6: one level of the 64-ary min tree over br_depth[] (one wave per group) -----------------------
@@ -1314,12 +1332,12 @@ __device__ i64 wave_psv_tree(const MinTree &mt, int L, u64 idx, i32 v, int lane)
 // A close writes both tape words of its pair; a pair at depth 0 is a record (or the document) and also writes the root
 // words around it: the open-root word in front of it points behind its close-root word and vice versa (startContinue
 // :196-221, succeed :428-442) -- the same lines of the tape, one 16-byte store each.
-__global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
+__device__ __forceinline__ void br_match_body(const S2Dev &p, u32 bid, u32 nb) {
     const u32 n_br = p.st->n_br;
     const MinTree mt = make_tree(p);
     const int lane = threadIdx.x & 63;
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
-    const u32 waves = gridDim.x * 4;
+    const u32 waves = nb * 4;
     const bool store = p.st->tape_len <= p.tape_cap;  // (cannot fail: the launcher sizes the tape for 2n+2 words)
     bool bad = false;
     // everything that does not depend on an answer is requested together -- the group's depths, kinds and tape offsets,
@@ -1344,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
         }
         return r;
     };
-    u32 g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    u32 g = bid * 4 + (threadIdx.x >> 6);
     Group nx = load_group(g);
     for (; (u64)g * 64 < n_br; g += waves) {  // wave-uniform
         const u32 c = g * 64 + (u32)lane;
@@ -1412,7 +1430,7 @@ __global__ __launch_bounds__(256) void k_br_match(S2Dev p) {
     }
     if (bad) atomicOr(&p.st->err, 1u);
 }
-
+__global__ __launch_bounds__(256) void k_br_match(S2Dev p) { br_match_body(p, blockIdx.x, gridDim.x); }
 // ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
 __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
     if (p.sv.qm) {
@@ -1527,7 +1545,13 @@ static S2Dev stage2_view(const S2Args &a) {
     p.br_depth = SJ_ARR(reinterpret_cast<i32 *>(carve(n * 4)), n, A_BR_DEPTH);
     p.br_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_BR_OFF);
     p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
-    p.scan_segs = (a.len <= ((size_t)32 << 20) && p.tiles <= 8192) ? 1 : SCAN_SEGS;  // 8192 units / 8192 tiles: one round of one block
+    {
+        const u64 us = ((u64)a.len + 64 + 4095) / 4096;
+        // (one CU moves ~60 GB/s: a single block only where its share is a few tens of kilobytes -- measured: one block
+        // for configs[4]'s 19 500 tile aggregates took 73 us, 32 blocks 18)
+        p.unit_segs = us <= 16384 ? 1 : SCAN_SEGS;
+        p.tile_segs = p.tiles <= 1024 ? 1 : SCAN_SEGS;
+    }
     p.agg = SJ_ARR(reinterpret_cast<TileAgg *>(carve((size_t)(p.tiles + 1) * sizeof(TileAgg))), p.tiles + 1, A_AGG);
     p.nlev = 1;
     p.lev[0] = nullptr;
@@ -1604,7 +1628,7 @@ hipError_t stage2_launch_measure(const S2Args &a) {
         const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
         hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
     }
-    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? 2 * p.scan_segs : p.scan_segs), dim3(1024), 0, a.stream, p);
+    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? p.unit_segs + p.tile_segs : p.tile_segs), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
 }
 
@@ -1641,7 +1665,9 @@ hipError_t stage2_launch_emit(const S2Args &a) {
         const hipError_t e = fork_strings();
         if (e != hipSuccess) return e;
     }
-    {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count)
+    {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count).
+        // (Measured and dropped in round 4: the numbers beside the bracket matcher instead -- both wait on dependent
+        // loads, but one launch of the two took 97 + 15 us for the tree levels where the two launches take 50 + 49.)
         const u32 nblocks = gb < 2048 ? gb : 2048;
         const u64 want = p.nlev > 1 ? (p.lev_size[1] + 63) / 64 : 0;  // one block per 4096 depths at a time
         const u32 lblocks = (u32)(want < 2048 ? want : 2048);

@@ -204,3 +204,40 @@ def surrogate_run_docs():
 def test_long_surrogate_runs(L):
     for doc, what in surrogate_run_docs():
         check(L, doc, False, what)
+
+
+def test_integer_fast_path_decides_like_the_general_routine(L):
+    """sj_number.h parse_int_fast (what k_s2_emit runs on number tokens before it queues them for k_numbers): whenever it
+    takes a number, the oracle's parseNumber gives an int64 of that value; it never takes floats, integers of more than
+    18 digits, leading zeros or numbers with a stray byte behind them; and it does take every plain integer of up to 18
+    digits that is followed by a byte that ends a value."""
+    OL = O.lib()
+    L.sj_selftest_int_fast.argtypes = [C.c_char_p, C.c_size_t, u64p]
+    rnd = random.Random(7)
+    ends = [b",", b"}", b"]", b" ", b"\t", b"\r", b"\n", b":"]
+    others = [b".", b"e", b"E", b"-", b"+", b"a", b"\x00", b'"', b"{", b"[", b"/", b"9" * 3 + b"."]
+    cases = []
+    for nd in range(1, 22):
+        for _ in range(40):
+            digits = str(rnd.randrange(10 ** (nd - 1), 10 ** nd)) if nd > 1 else str(rnd.randrange(10))
+            for sign in ("", "-"):
+                for tail in (rnd.choice(ends), rnd.choice(ends) + b"123", rnd.choice(others) + b"5]", b""):
+                    cases.append((sign + digits).encode() + tail)
+        cases += [b"0" * nd + b",", b"-" + b"0" * nd + b"]", b"0" + b"7" * nd + b" ", b"9" * nd + b",", b"-" + b"9" * nd + b"}"]
+    cases += [b"-,", b"-", b"", b",", b"--1,", b"1-2,", b"9223372036854775807,", b"-9223372036854775808,", b"999999999999999999,",
+              b"1000000000000000000,", b"-999999999999999999:", b"12345678,", b"123456789,", b"1234567890123456,", b"12345678901234567,"]
+    took = 0
+    for s in cases:
+        v = C.c_uint64()
+        fast = L.sj_selftest_int_fast(s, len(s), C.byref(v))
+        rv = C.c_uint64()
+        tag = OL.sjo_parse_number(s, len(s), C.byref(rv))
+        body = s.lstrip(b"-")
+        ndig = len(body) - len(body.lstrip(b"0123456789"))
+        plain = 1 <= ndig <= 18 and len(s) - len(body) <= 1 and not (ndig > 1 and body[:1] == b"0") and body[ndig:ndig + 1] in ends
+        assert bool(fast) == plain, (s, fast, plain)
+        if fast:
+            took += 1
+            assert tag == (ord("l") << 56) and rv.value == v.value, (s, hex(tag), rv.value, v.value)
+            assert v.value == int(s[:len(s) - len(body) + ndig]) % (1 << 64), s
+    assert took > 1000
