@@ -8,6 +8,10 @@
  * to run.  `dedup` = 1 restates the algorithm with FNV-1a in its place (same table size, same replace-on-miss
  * policy); `dedup` = 0 appends every string (the columns a parser-order Strings.B gives directly).  What the reference
  * pins (parsed_serialize_test.go:220-340) is the round trip: Deserialize(Serialize(pj)) marshals to the same JSON.
+ * The framing itself is pinned by tests/golden/serialize_v3_vectors.py: five streams written out by hand from the format
+ * comment and the encoding loop (:201-236, :283-341, :376-431) for documents whose bytes do not depend on the hash
+ * (distinct strings are never merged, an immediately repeated one always is); this file must reproduce them byte for
+ * byte (tests/test_oracle_serialize.py).
  */
 #include "sjo.h"
 
