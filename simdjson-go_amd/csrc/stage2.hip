@@ -942,9 +942,9 @@ __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
 // MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
 // lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
 // (selective copy carries the Strings.B byte count through the scan and the measured lengths in registers: it is given
-// 96 registers -- five waves per SIMD -- instead of spilling at 64)
+// 80 registers -- six waves per SIMD, three blocks per CU -- instead of spilling at 64)
 template <bool MASKS>
-__global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
+__global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 6) void k_s2_emit(S2Dev p) {
     __shared__ u32 s_elut[LUT_SIZE];
     __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
     // the tile's strings (from the front) and its atoms and numbers (from the back) in one array -- a tile has 4096
     // tokens, so the two never meet: token index | tape offset inside the tile << 12 | kind << 26
     __shared__ u32 s_q[S2_TILE];
-    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill, s_sbase;
+    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill, s_ccnt, s_cbase, s_cfill;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
     s_elut[tid] = c_elut.v[tid];
-    if (tid == 0) s_cnt = s_scnt = s_dcnt = s_fill = 0;
+    if (tid == 0) s_cnt = s_scnt = s_dcnt = s_fill = s_ccnt = s_cfill = 0;
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
@@ -1003,10 +1003,20 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
         is_str[k] = kd[k] == K_STRING;
         is_atom[k] = (u32)(kd[k] - K_TRUE) < 3u;
         dl[k] = copied[k] = 0;
-        if (!MASKS && is_str[k]) {
-            dl[k] = p.dlen[base + k];
-            copied[k] = (dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
+    }
+    if (!MASKS) {  // the measured lengths: the thread's eight entries as two 16-byte loads (only string entries are defined)
+        if (base + S2_ITEMS <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base, 4)), b = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4, 4));
+            dl[0] = a.x; dl[1] = a.y; dl[2] = a.z; dl[3] = a.w;
+            dl[4] = b.x; dl[5] = b.y; dl[6] = b.z; dl[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < S2_ITEMS; k++)
+                if (base + k < n) dl[k] = p.dlen[base + k];
         }
+#pragma unroll
+        for (int k = 0; k < S2_ITEMS; k++)
+            copied[k] = (is_str[k] && dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
     }
     __syncthreads();
     // ---- elements and the scan inside the tile
@@ -1041,7 +1051,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         nnum += kd[k] == K_NUM ? 1u : 0u;
-        nstr += (MASKS ? is_str[k] : copied[k] != 0u) ? 1u : 0u;  // selective copy: the strings k_emit_strings will copy
+        nstr += is_str[k] ? 1u : 0u;
         natom += is_atom[k] ? 1u : 0u;
     }
     // queue slots: the counts of a wave are summed with a DPP scan and one lane draws the wave's ranges (an LDS atomic
@@ -1068,36 +1078,30 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
         const u32 ex = incl - pk;
         sslot = sb + (ex & 0x3ffu);
         dslot = db + ((ex >> 10) & 0x3ffu);
+        if (!MASKS) {  // selective copy: the tile's strings that k_emit_strings will copy (one global atomic per tile below)
+            u32 nc = 0;
+#pragma unroll
+            for (int k = 0; k < S2_ITEMS; k++) nc += copied[k] != 0u ? 1u : 0u;
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x111, 0xf, 0xf, false);
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x112, 0xf, 0xf, false);
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x114, 0xf, 0xf, false);
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x118, 0xf, 0xf, false);
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x142, 0xa, 0xf, false);
+            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x143, 0xc, 0xf, false);
+            if (lane == 63 && nc) atomicAdd(&s_ccnt, nc);
+        }
     }
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
-    u32 strq_base = 0;
-    if (!MASKS) {  // the tile's range in the queue of strings to copy (block-uniform count: every wave has added its share)
-        __syncthreads();
-        if (tid == 0 && s_scnt != 0) s_sbase = atomicAdd(&p.st->str_count, s_scnt);
-        __syncthreads();
-        strq_base = s_sbase;
-    }
 #pragma unroll
     for (int k = 0; k < S2_ITEMS; k++) {
         const u32 lo = lp.x & 0x3fffu;  // tape words of the tile in front of this token
         const u32 o = T0 + lo;
         const u32 qe = (u32)(tid * S2_ITEMS + k) | (lo << 12);
         bad |= am_value(e[k].z) == 0;  // legal in no context at all
-        if (MASKS) {
-            if (is_str[k]) s_q[sslot++] = qe;
-        } else if (is_str[k]) {  // selective copy: the lengths were measured by k_s2_reduce, the scan carries the offsets
-            const bool cp = (dl[k] & DLEN_COPY) != 0;
-            if (dl[k] != DLEN_INVALID) {
-                const u64 w0 = string_word(cp, p.strings_base + tp.s + lp.s, p.msg_base + pp[k] + 1), w1 = dl[k] & ~DLEN_COPY;
-                *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-                if (!p.sv.qm) p.str_off[base + k] = tp.s + lp.s;  // (per-string walks: k_emit_strings looks the offset up per token)
-                // queued for k_emit_strings with everything it needs (one coalesced 16-byte entry instead of three
-                // gathers per string); a document with more strings than n/2 is invalid: its entries are dropped
-                if (cp && copied[k] != 0u) {
-                    const u32 slot = strq_base + sslot++;
-                    if (slot < p.strq_cap) p.strq[slot] = make_uint4(pp[k], tp.s + lp.s, dl[k] & ~DLEN_COPY, 0u);
-                }
-            }
+        if (is_str[k]) {  // worked on densely below; selective copy: the scan has the Strings.B offset, keep it for then
+            s_q[sslot++] = qe;
+            // (in the slot of the token's own position, which the dense pass reads back from memory: no LDS of its own)
+            if (!MASKS) s_pos[tid * S2_ITEMS + k] = lp.s;
         }
         if (is_atom[k] || (kd[k] == K_NUM && !SJ_EXPBIT(p, 9))) s_q[S2_TILE - 1 - dslot++] = qe | ((u32)kd[k] << 26);
         if ((u32)(kd[k] - K_OPEN_OBJ) < 4u && !SJ_EXPBIT(p, 3)) {
@@ -1129,6 +1133,43 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 5) void k_s2_emit(S2Dev p) {
             const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
             if (!SJ_EXPBIT(p, 2))
                 *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+        }
+    }
+    // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
+    // a string that unescaping changed points into Strings.B and is queued for k_emit_strings with everything that kernel
+    // needs, the others point into the message (parseString, stage2_build_tape_amd64.go:90-109)
+    if (!MASKS) {
+        const u32 ns = s_scnt;
+        if (tid == 0 && s_ccnt != 0 && p.sv.qm) s_cbase = atomicAdd(&p.st->str_count, s_ccnt);
+        __syncthreads();
+        for (u32 j0 = 0; j0 < ns; j0 += S2_BLOCK) {  // (block-uniform trip count: the ballots below want whole waves)
+            const u32 j = j0 + (u32)tid;
+            bool queue = false;
+            u32 at = 0, so = 0, len = 0;
+            if (j < ns) {
+                const u32 v = s_q[j], idx = v & 0xfffu;
+                const u32 dlw = p.dlen[t0 + idx];
+                at = p.pos[t0 + idx];
+                so = tp.s + s_pos[idx];
+                if (dlw != DLEN_INVALID) {
+                    const bool cp = (dlw & DLEN_COPY) != 0;
+                    len = dlw & ~DLEN_COPY;
+                    const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = len;
+                    *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                    if (!p.sv.qm) p.str_off[t0 + idx] = so;  // (per-string walks: k_emit_strings looks the offset up per token)
+                    queue = cp && len != 0 && p.sv.qm;
+                }
+            }
+            // queue slots inside the tile's range: one LDS atomic per wave and pass, the lanes take consecutive entries
+            // (a global atomic per wave instead -- 46 000 on one word for configs[1] -- took the kernel from 0.2 to 1.07 ms)
+            const u64 qm = __ballot(queue);
+            if (qm != 0) {
+                u32 qbase = 0;
+                if (lane == 0) qbase = atomicAdd(&s_cfill, (u32)__popcll(qm));
+                qbase = s_cbase + (u32)__builtin_amdgcn_readfirstlane((int)qbase);
+                const u32 slot = qbase + (u32)__popcll(qm & ((1ull << lane) - 1ull));
+                if (queue && slot < p.strq_cap) p.strq[slot] = make_uint4(at, so, len, 0u);
+            }
         }
     }
     // ---- atoms: validated from the 8 message bytes at the token; numbers move to the global queue (k_numbers parses
