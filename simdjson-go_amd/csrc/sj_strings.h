@@ -361,19 +361,21 @@ struct StrMeasure {
     u32 dl;
     bool copied, ok;
 };
-SJ_HD StrMeasure string_measure_masks(const StrView &m, Arr<const ChunkRec> rec, Arr<const u32> unit_counts, u64 a0, u64 a1) {
+// (r0 = rec[a0 >> 6], r1 = rec[a1 >> 6], q1 = m.q[a1 >> 6] are handed in: k_str_measure requests them for two strings at a
+// time before it uses any of them)
+SJ_HD StrMeasure string_measure_loaded(const StrView &m, Arr<const u32> unit_counts, u64 a0, u64 a1, const ChunkRec &r0,
+                                       const ChunkRec &r1, u64 q1) {
     StrMeasure r{0u, false, false};
     if (a1 <= a0) return r;  // (the quote is the last byte: nothing closes it)
     const u64 c0 = a0 >> 6, c1 = a1 >> 6;
     const u32 b0 = (u32)(a0 & 63), b1 = (u32)(a1 & 63);
     const u64 below0 = b0 ? ~0ull >> (64 - b0) : 0ull, below1 = b1 ? ~0ull >> (64 - b1) : 0ull;
-    const ChunkRec r0 = rec[c0], r1 = rec[c1];
     u64 n = (u64)(r1.pre & CHUNK_PRE_MASK) + (u64)popc64(r1.em & below1) - ((u64)(r0.pre & CHUNK_PRE_MASK) + (u64)popc64(r0.em & below0));
     for (u64 u = a0 >> 12; u < (a1 >> 12); u++) n += unit_counts[u];  // (a string that leaves its 4 KiB unit: rare)
     r.dl = (u32)n;
-    u64 c = c1, mask = below1;
+    u64 c = c1, mask = below1, qw = q1;
     for (;;) {
-        u64 qb = m.q[c] & mask;
+        u64 qb = qw & mask;
         if (c == c0) qb &= ~below0;
         if (qb != 0) {
             const u64 cq = c * 64 + (u64)(63 - clz64(qb));
@@ -384,7 +386,12 @@ SJ_HD StrMeasure string_measure_masks(const StrView &m, Arr<const ChunkRec> rec,
         if (c == c0) return r;
         c--;
         mask = ~0ull;
+        qw = m.q[c];
     }
+}
+SJ_HD StrMeasure string_measure_masks(const StrView &m, Arr<const ChunkRec> rec, Arr<const u32> unit_counts, u64 a0, u64 a1) {
+    if (a1 <= a0) return StrMeasure{0u, false, false};
+    return string_measure_loaded(m, unit_counts, a0, a1, rec[a0 >> 6], rec[a1 >> 6], m.q[a1 >> 6]);
 }
 
 // the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)

@@ -787,13 +787,22 @@ __global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
     for (int j = 0; j < 4; j++)
         if (((kv >> (8 * j)) & 0xffu) == K_STRING) s_q[slot++] = i0 + (u32)j;
     __syncthreads();
+    // Two strings per lane and round, every load of both requested before the first use: the kernel is bound by the chain
+    // kinds -> queue -> positions -> records -> store of a block, not by instructions (one string per lane and round:
+    // 84 us on configs[1], 300 us on configs[4]'s 30 M strings)
     const u32 ns = s_n;
-    for (u32 j = (u32)tid; j < ns; j += 256) {
-        const u32 i = s_q[j];
-        const u64 a0 = (u64)p.pos[i] + p.sv.lead + 1;
-        const u64 a1 = (i + 1 < n ? (u64)p.pos[i + 1] : p.len) + p.sv.lead;
-        const StrMeasure sm = string_measure_masks(p.sv, p.rec, p.unit_cnt, a0, a1);
-        p.dlen[i] = sm.ok ? (sm.dl | (sm.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
+    for (u32 j = (u32)tid; j < ns; j += 512) {
+        const bool two = j + 256 < ns;
+        const u32 i0 = s_q[j], i1 = two ? s_q[j + 256] : i0;
+        const u64 pa0 = p.pos[i0], pb0 = i0 + 1 < n ? (u64)p.pos[i0 + 1] : p.len;
+        const u64 pa1 = p.pos[i1], pb1 = i1 + 1 < n ? (u64)p.pos[i1 + 1] : p.len;
+        const u64 a00 = pa0 + p.sv.lead + 1, a01 = pb0 + p.sv.lead, a10 = pa1 + p.sv.lead + 1, a11 = pb1 + p.sv.lead;
+        const ChunkRec r00 = p.rec[a00 >> 6], r01 = p.rec[a01 >> 6], r10 = p.rec[a10 >> 6], r11 = p.rec[a11 >> 6];
+        const u64 q0 = p.sv.q[a01 >> 6], q1 = p.sv.q[a11 >> 6];
+        const StrMeasure m0 = string_measure_loaded(p.sv, p.unit_cnt, a00, a01, r00, r01, q0);
+        const StrMeasure m1 = string_measure_loaded(p.sv, p.unit_cnt, a10, a11, r10, r11, q1);
+        p.dlen[i0] = m0.ok ? (m0.dl | (m0.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
+        if (two) p.dlen[i1] = m1.ok ? (m1.dl | (m1.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
     }
 }
 
@@ -1479,15 +1488,37 @@ __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
         // that changed were queued by k_s2_emit: one string per lane, grid-stride over the queue
         u32 cnt = p.st->str_count;
         if (cnt > p.strq_cap) cnt = p.strq_cap;
-        for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
-            const uint4 e = p.strq[j];
-            const u32 n = e.z, so = e.y;
-            if ((u64)so + n > p.strings_cap) continue;
-            const u8 *src = arr_at(p.str_out, emitted_before(p.unit_cnt, p.rec, (u64)e.x + p.sv.lead + 1), (u64)n + 8);  // (the tail reads 8)
-            u8 *dst = arr_at(p.strings, so, n);
-            u32 b = 0;
-            for (; b + 8 <= n; b += 8) store_u64(dst + b, load_u64(src + b));  // (neither side is aligned: fine on gfx950)
-            if (b < n) store_bytes(dst + b, load_u64(src + b), n - b);  // (the scratch buffer has 64 bytes of slack)
+        // two strings per lane and round, their entries, records and first eight bytes requested together (the kernel waits
+        // on dependent loads: entry -> record -> bytes)
+        const u32 stride = gridDim.x * 256;
+        for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += 2 * stride) {
+            const bool two = j + stride < cnt;
+            const uint4 e0 = p.strq[j], e1 = two ? p.strq[j + stride] : e0;
+            const u64 a0 = (u64)e0.x + p.sv.lead + 1, a1 = (u64)e1.x + p.sv.lead + 1;
+            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];
+            const u32 u0 = p.unit_cnt[a0 >> 12], u1 = p.unit_cnt[a1 >> 12];
+            const u32 b0 = (u32)(a0 & 63), b1 = (u32)(a1 & 63);
+            const u64 s0 = (u64)u0 + (r0.pre & CHUNK_PRE_MASK) + (u64)popc64(b0 ? r0.em & (~0ull >> (64 - b0)) : 0ull);  // emitted_before()
+            const u64 s1 = (u64)u1 + (r1.pre & CHUNK_PRE_MASK) + (u64)popc64(b1 ? r1.em & (~0ull >> (64 - b1)) : 0ull);
+            const bool ok0 = (u64)e0.y + e0.z <= p.strings_cap, ok1 = two && (u64)e1.y + e1.z <= p.strings_cap;
+            const u8 *src0 = arr_at(p.str_out, s0, (u64)e0.z + 8), *src1 = arr_at(p.str_out, s1, (u64)e1.z + 8);  // (the tail reads 8:
+            const u64 h0 = load_u64(src0), h1 = load_u64(src1);                                                   // 64 bytes of slack)
+            if (ok0) {
+                u8 *dst = arr_at(p.strings, e0.y, e0.z);
+                const u32 n = e0.z;
+                u32 b = 0;
+                u64 w = h0;
+                for (; b + 8 <= n; b += 8, w = load_u64(src0 + b)) store_u64(dst + b, w);  // (neither side is aligned: fine on gfx950)
+                if (b < n) store_bytes(dst + b, w, n - b);
+            }
+            if (ok1) {
+                u8 *dst = arr_at(p.strings, e1.y, e1.z);
+                const u32 n = e1.z;
+                u32 b = 0;
+                u64 w = h1;
+                for (; b + 8 <= n; b += 8, w = load_u64(src1 + b)) store_u64(dst + b, w);
+                if (b < n) store_bytes(dst + b, w, n - b);
+            }
         }
         return;
     }
