@@ -48,7 +48,12 @@ int sj::arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes) {
     b.cap = 0;
     size_t want = bytes + bytes / 8 + 4096;
     hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) return ctx_hip_fail(ctx, e, "hipMalloc");
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (the runtime keeps the error until somebody asks: the next launch check would)
+        b.p = nullptr;
+        ctx_set_error(ctx, "hipMalloc of %zu bytes for a device arena: %s", want, hipGetErrorString(e));
+        return SJHIP_ERR_HIP;
+    }
     b.cap = want;
     return SJHIP_OK;
 }

@@ -613,3 +613,36 @@ def test_small_documents_denser_than_the_deferred_layout(ctx):
         check(ctx, fixtures.load("payload-small"), what="sparse after dense")
     check(ctx, b"[" + b",".join([b"1"] * 40000) + b",]", what="dense, stage-2 error")
     check(ctx, b"[" + b",".join([b"1"] * 40000), what="dense, stage-1 error")
+
+
+def test_arena_allocation_failure_is_an_error_not_a_verdict():
+    """A context's arenas are grown with hipMalloc when a larger document comes along.  When the device has no room the
+    call returns SJHIP_ERR_HIP with the allocation in its message -- not a parse verdict -- and the context works again
+    once memory is there (the failed arena starts from scratch)."""
+    import torch
+    import sjhip
+    c = sjhip.Context(0)
+    doc = workloads.c2_twitter_array(40)                      # 25 MB: its arenas need a few hundred MB
+    dev = _device_doc(doc)
+    small = fixtures.load("payload-small")
+    assert c.parse(small).Tape.size > 0                         # streams, scratch and small arenas exist before the squeeze
+    hog = []
+    try:
+        free, _ = torch.cuda.mem_get_info()
+        while free > (96 << 20):                                # leave less than the parse needs
+            take = min(free - (64 << 20), 32 << 30)
+            if take < (16 << 20):
+                break
+            hog.append(torch.empty(take, dtype=torch.uint8, device="cuda:0"))
+            free, _ = torch.cuda.mem_get_info()
+        with pytest.raises(sjhip.ParseError) as e:
+            c.parse_device(dev.data_ptr(), len(doc))
+        assert e.value.code == -1 and "hipMalloc" in str(e.value), (e.value.code, str(e.value))
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    ref = O.parse(doc)
+    tl, sl = c.parse_device(dev.data_ptr(), len(doc))           # the same context, now with room
+    tape, strings = c.fetch(tl, sl)
+    assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings)
+    c.close()
