@@ -646,3 +646,15 @@ def test_arena_allocation_failure_is_an_error_not_a_verdict():
     tape, strings = c.fetch(tl, sl)
     assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings)
     c.close()
+
+
+def test_strings_on_chunk_and_unit_boundaries(ctx):
+    """tests/workloads.py string_boundary_documents through the kernels, both copy modes: string ends, escapes and the
+    blanks between a closing quote and the next token on 64-byte and 4 KiB seams (the selective copy finds the closing
+    quote by walking back from the next token, possibly over whole chunks of blanks)."""
+    docs = workloads.string_boundary_documents()
+    for what, d in docs:
+        check(ctx, d, False, what)
+    # all of them as one ND message, and inside one large array (many tiles, unaligned starts)
+    check(ctx, b"\n".join(d for _, d in docs), True, "boundaries/nd")
+    check(ctx, b"[" + b",".join(d for _, d in docs) + b"]", False, "boundaries/array")

@@ -241,3 +241,15 @@ def test_integer_fast_path_decides_like_the_general_routine(L):
             assert tag == (ord("l") << 56) and rv.value == v.value, (s, hex(tag), rv.value, v.value)
             assert v.value == int(s[:len(s) - len(body) + ndig]) % (1 << 64), s
     assert took > 1000
+
+
+def test_strings_on_chunk_and_unit_boundaries(L):
+    """tests/workloads.py string_boundary_documents: the host replay (which also runs the emit-mask form of the selective
+    copy beside the per-string walks, host_selftest.cpp) against the oracle in both copy modes."""
+    import workloads
+    docs = workloads.string_boundary_documents()
+    assert len(docs) > 1000
+    for what, d in docs[::3]:
+        check(L, d, False, what)
+    nd = b"\n".join(d for _, d in docs[1::40])
+    check(L, nd, True, "boundaries/nd")
