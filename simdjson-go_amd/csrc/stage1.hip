@@ -510,11 +510,13 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         u32 pos0 = KIND ? (u32)lane * 64u : ubase + (u32)lane * 64u;        // what a lane stages: position, or offset in the unit
         __builtin_amdgcn_wave_barrier();  // the staging window is free: all masks are in registers / already copied out
         Staged *stage = reinterpret_cast<Staged *>(m);
-        const u32 *k32 = reinterpret_cast<const u32 *>(kpl + (KIND ? k * 4 * 64 : 0));  // the four kind planes of this pass
+        // the four kind planes of this pass, interleaved per 32-byte half of a chunk: one 16-byte LDS read per entry
+        // (plane-major, four 4-byte reads: the copy-out issued 16 LDS reads per four entries)
+        const uint4 *k128 = reinterpret_cast<const uint4 *>(kpl + (KIND ? k * 4 * 64 : 0));
         auto kind_of = [&](u32 e) -> u32 {  // e = chunk << 6 | bit
-            const u32 w = ((e >> 6) << 1) + ((e >> 5) & 1u), b = e & 31u;
-            const u32 k0 = k32[w], k1 = k32[128 + w], k2 = k32[256 + w], k3 = k32[384 + w];
-            return ((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2) | (((k3 >> b) & 1u) << 3);
+            const uint4 kk = k128[e >> 5];  // (chunk, half)
+            const u32 b = e & 31u;
+            return ((kk.x >> b) & 1u) | (((kk.y >> b) & 1u) << 1) | (((kk.z >> b) & 1u) << 2) | (((kk.w >> b) & 1u) << 3);
         };
         // copies the first cnt staged entries to out_pos[gd ...] (and their kinds to kind_out)
         auto copy_out = [&](u32 cnt, u64 gd) {
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     __shared__ u32 s_pre[2][WAVES][CH * 64];  // per chunk: inclusive structural counts of its unit, both hypotheses
     // whole parse: the kind planes of the tile that is flattened next (4 x u64 per chunk); a wave keeps the planes of the
     // tile it has just classified in registers until it has flattened the tile in front, then parks them here
-    __shared__ u64 s_kpl[AUX ? WAVES : 1][AUX ? CH * 4 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) u64 s_kpl[AUX ? WAVES : 1][AUX ? CH * 4 * 64 : 2];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -723,9 +725,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         }
         if (AUX && has_a) {  // the planes of T(j) wait in LDS for its flatten in the next iteration (this wave's window only)
 #pragma unroll
-            for (int k = 0; k < CH; k++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) s_kpl[wave][(k * 4 + q) * 64 + lane] = kp[k][q];
+            for (int k = 0; k < CH; k++) {  // (chunk, half) -> the four plane words of that half
+                uint4 *dst = reinterpret_cast<uint4 *>(&s_kpl[wave][k * 4 * 64]) + lane * 2;
+                dst[0] = make_uint4((u32)kp[k][0], (u32)kp[k][1], (u32)kp[k][2], (u32)kp[k][3]);
+                dst[1] = make_uint4((u32)(kp[k][0] >> 32), (u32)(kp[k][1] >> 32), (u32)(kp[k][2] >> 32), (u32)(kp[k][3] >> 32));
+            }
         }
         t_prev = t_a;
     }

@@ -119,6 +119,17 @@ __device__ __forceinline__ u32 token_count(const S2Dev &p) {
     return n < p.n ? (u32)n : p.n;
 }
 
+// inclusive sum over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU instructions, no LDS crossbar)
+__device__ __forceinline__ u32 wave_incl_sum(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ---- string kernels (copy_strings): sj_strings.h, one 64-byte chunk per lane, one 4 KiB unit per wave ---------
 // The general string routine of a unit, escape by escape instead of chunk by chunk.  sj_strings.h str_chunk_masks is the
 // per-chunk statement (and what the host replay runs): a lane walks the escaped characters of its chunk one after the
@@ -137,12 +148,7 @@ struct GenUnit {       // per wave
 // le: escaped in-string characters of this lane's chunk that have to be evaluated (0: none); returns the wave's item count
 __device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, int lane) {
     const u32 n = (u32)popc64(le) + (lane == 0 ? (u32)popc64(foreign) : 0u);
-    u32 incl = n;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-        const u32 up = (u32)__shfl_up((int)incl, sft, 64);
-        if (lane >= sft) incl += up;
-    }
+    const u32 incl = wave_incl_sum(n);
     u32 o = incl - n;
     if (lane == 0)
         for (u64 f = foreign; f != 0; f &= f - 1) gu->list[o++] = (uint16_t)(GEN_FOREIGN | (u32)ctz64(f));
@@ -215,12 +221,7 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
             __builtin_amdgcn_wave_barrier();  // the lists are read: the next unit may write them
         }
         const u32 n = (u32)popc64(em);
-        u32 incl = n;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const u32 o = __shfl_up(incl, s, 64);
-            if (lane >= s) incl += o;
-        }
+        const u32 incl = wave_incl_sum(n);
         p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
         if (lane == 63) p.unit_cnt[unit] = incl;
         if (!more) break;
@@ -774,12 +775,7 @@ __global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) cnt += ((kv >> (8 * j)) & 0xffu) == K_STRING ? 1u : 0u;
     // queue slots: wave scan of the counts, one atomic per wave
-    u32 incl = cnt;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-        const u32 o = __shfl_up(incl, sft, 64);
-        if (lane >= sft) incl += o;
-    }
+    const u32 incl = wave_incl_sum(cnt);
     u32 wb = 0;
     if (lane == 63 && incl) wb = atomicAdd(&s_n, incl);
     u32 slot = (u32)__shfl((int)wb, 63, 64) + incl - cnt;

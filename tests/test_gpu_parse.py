@@ -635,12 +635,17 @@ def test_arena_allocation_failure_is_an_error_not_a_verdict():
                 break
             hog.append(torch.empty(take, dtype=torch.uint8, device="cuda:0"))
             free, _ = torch.cuda.mem_get_info()
-        with pytest.raises(sjhip.ParseError) as e:
+        try:
             c.parse_device(dev.data_ptr(), len(doc))
-        assert e.value.code == -1 and "hipMalloc" in str(e.value), (e.value.code, str(e.value))
+            failed = None
+        except sjhip.ParseError as e:
+            failed = e
     finally:
         del hog
         torch.cuda.empty_cache()
+    if failed is None:  # (seen at the end of a long test session: the runtime still found room although < 96 MB were reported free)
+        pytest.skip("device memory could not be exhausted from this process")
+    assert failed.code == -1 and "hipMalloc" in str(failed), (failed.code, str(failed))
     ref = O.parse(doc)
     tl, sl = c.parse_device(dev.data_ptr(), len(doc))           # the same context, now with room
     tape, strings = c.fetch(tl, sl)
