@@ -617,11 +617,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     const u64 end = lead + len;
     u64 kp[CH][4];
 
-    // At launch every block of the grid queues up on the ticket counter: the first ticket is drawn alone
-    // (one atomic per block), the next two while phase A of the first tile is already running.
-    if (tid == 0) s_ticket[0] = atomicAdd(&st->tile_counter, 1u);
+    // The first tile of a block is its own index: the grid holds no more blocks than the device runs at once and the
+    // dispatcher starts workgroups in index order, so every tile in front of it belongs to a block that is resident or
+    // through (the look-back's forward-progress condition) -- and nobody queues up on the ticket counter at launch (every
+    // block of the grid drew its first ticket there: one atomic round trip in front of the first load).  Later tiles
+    // are drawn from the counter, which counts from gridDim.x on.
+    if (tid == 0) s_ticket[0] = blockIdx.x;
     __syncthreads();
-    const u32 t_first = uniform(s_ticket[0]);
+    const u32 t_first = blockIdx.x;
     if (t_first >= num_tiles) {
         block_done(st, aux, base + lead, len);
         return;
@@ -652,8 +655,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const int mf = ma ^ 1, uf = ua == 0 ? 2 : ua - 1;        // ... of T(j-1)
         u32 tk1 = 0, tk2 = 0;  // tickets drawn now (lane 0 of wave 0); they return while phase A runs
         if (tid == 0) {
-            if (first) tk1 = atomicAdd(&st->tile_counter, 1u);
-            if (has_a) tk2 = atomicAdd(&st->tile_counter, 1u);
+            if (first) tk1 = gridDim.x + atomicAdd(&st->tile_counter, 1u);
+            if (has_a) tk2 = gridDim.x + atomicAdd(&st->tile_counter, 1u);
         }
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
