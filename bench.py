@@ -325,6 +325,9 @@ def main():
                     tl1, sl1 = ctx.parse_device(d_one.data_ptr(), len(raw), ndjson=False, copy_strings=True)
                 t_dev = timed(one, 50)
                 t_h2h_nc = timed(lambda: ctx.parse(arr, reuse=reuse, copy_strings=False), 50)
+                # the result read in place: Tape / Strings are views of the context's pinned block (sjhip_fetch_view),
+                # the reference's `reuse` contract (overwritten by the next parse)
+                t_view = timed(lambda: ctx.parse(arr, view=True), 50)
 
                 def one_nc():
                     ctx.parse_device(d_one.data_ptr(), len(raw), ndjson=False, copy_strings=False)
@@ -334,6 +337,7 @@ def main():
                 singles[key] = {"workload": f"Parse({name}.json), {len(raw)} B, every string copied", "structurals": s_one,
                                 "tape_words": tl1, "strings_bytes": sl1,
                                 "host_to_host_us": round(t_h2h * 1e6, 1), "host_to_host_GBps": round(len(raw) / t_h2h / 1e9, 2),
+                                "host_to_view_us": round(t_view * 1e6, 1), "host_to_view_GBps": round(len(raw) / t_view / 1e9, 2),
                                 "device_us": round(t_dev * 1e6, 1), "device_GBps": round(len(raw) / t_dev / 1e9, 2),
                                 "nocopy_host_to_host_us": round(t_h2h_nc * 1e6, 1), "nocopy_host_to_host_GBps": round(len(raw) / t_h2h_nc / 1e9, 2),
                                 "nocopy_device_us": round(t_dev_nc * 1e6, 1), "nocopy_device_GBps": round(len(raw) / t_dev_nc / 1e9, 2),
@@ -459,8 +463,14 @@ def main():
                                               "built on the device, Strings.B as the string column", "ms": round(t_s * 1e3, 3),
                                   "GBps_of_input": round(len(shard) / t_s / 1e9, 1), "stream_bytes": ser["stream"],
                                   "columns": {k: ser[k] for k in ("tags", "values", "strings")}}
-            extra["marshal_json"] = {"workload": "Iter.MarshalJSON of configs[4]'s tape on the device", "ms": round(t_m * 1e3, 3),
-                                     "GBps_of_input": round(len(shard) / t_m / 1e9, 1), "text_bytes": n_text}
+            # ... and of a parse that left the key flags behind (SJHIP_FLAG_KEY_FLAGS: three launches less; what the parse pays)
+            t_nd_kf = timed(lambda: ctx.parse_device(d_nd.data_ptr(), len(shard), ndjson=True, copy_strings=True, key_flags=True), 3)
+            assert ctx.marshal_json(fetch=False) == n_text
+            t_mk = timed(lambda: ctx.marshal_json(fetch=False), 3)
+            extra["marshal_json"] = {"workload": "Iter.MarshalJSON of configs[4]'s tape on the device; parse with SJHIP_FLAG_KEY_FLAGS "
+                                                 "(the parser leaves the key flags MarshalJSON needs)", "ms": round(t_mk * 1e3, 3),
+                                     "GBps_of_input": round(len(shard) / t_mk / 1e9, 1), "text_bytes": n_text,
+                                     "ms_without_key_flags": round(t_m * 1e3, 3), "parse_ms_with_key_flags": round(t_nd_kf * 1e3, 3)}
             del d_nd
             torch.cuda.empty_cache()
             # ---- N1: ParseNDStream through the library, host memory -> host memory

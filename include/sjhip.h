@@ -33,6 +33,10 @@ typedef struct sjhip_ctx sjhip_ctx;
 /* flags for sjhip_parse: parse_json_amd64.go:58-62 (ndjson) and options.go:13 (WithCopyStrings) */
 #define SJHIP_FLAG_NDJSON 1u
 #define SJHIP_FLAG_COPY_STRINGS 2u
+/* The caller is going to call sjhip_marshal_json on this result: the parse also leaves, on the device, one byte per
+ * string entry of the tape saying whether it is an object key (the parser knows: the token behind it is ':'), and
+ * MarshalJSON does not have to recover that from the token array (three launches less).  No effect on the result. */
+#define SJHIP_FLAG_KEY_FLAGS 4u
 
 /* return codes */
 #define SJHIP_OK 0
@@ -65,6 +69,15 @@ int sjhip_ctx_set_stream(sjhip_ctx *ctx, void *hip_stream);
 int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, size_t *tape_len,
                 size_t *strings_len, size_t *msg_off, size_t *msg_len);
 int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
+/* The same result WITHOUT the copy into caller memory: *tape / *strings point at tape_len words / strings_len bytes in
+ * pinned host memory that the context owns, valid until the next call that parses on this context (or destroys it).
+ * This is what `reuse *ParsedJson` means in the reference (simdjson_amd64.go:46-51: the arrays of the recycled
+ * ParsedJson are overwritten by the next parse): a binding that keeps one context per recycled ParsedJson hands these
+ * pointers out as pj.Tape / pj.Strings.  A small document parsed by sjhip_parse is
+ * already there (its last kernel wrote the result over PCIe); anything else is copied device -> pinned block here
+ * (the block grows on demand, SJHIP_ERR_TOOBIG beyond SJHIP_VIEW_LIMIT_BYTES, default 4 GiB: use sjhip_fetch).
+ * Either pointer is NULL when its length is 0. */
+int sjhip_fetch_view(sjhip_ctx *ctx, const uint64_t **tape, const uint8_t **strings);
 
 /* Same parse on a message that is already resident in device memory (already trimmed). Used by
  * bench.py (inputs in HBM before the timed region) and by the multi-GPU shard path. */

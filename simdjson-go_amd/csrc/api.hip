@@ -92,13 +92,15 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings, &ctx->d_strtmp};
+                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings, &ctx->d_strtmp,
+                      &ctx->d_keyflag};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     sj::release_nd_big(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    if (ctx->h_view) (void)hipHostFree(ctx->h_view);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);

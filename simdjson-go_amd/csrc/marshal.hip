@@ -16,6 +16,7 @@
 // string entry k of the tape, and it is a key iff the token behind it is ':' (k_ms_keys).
 // Tag words are told from raw words (the second word of a string / number entry) with the parity rule of sj_tapewalk.h.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/sjhip.h"
@@ -46,6 +47,7 @@ struct MsView {
     unsigned long long *cnt_s;   // [tiles] string entries of the tile       -> exclusive prefix
     unsigned long long *totals;  // text bytes, string entries, error flag
     const u8 *keyflag;           // [string entries] 1: the string is an object key
+    const u8 *kf_tape;           // null, or the flags the parser left (SJHIP_FLAG_KEY_FLAGS): [tape index of the entry >> 1]
     u32 *slen;                   // [tiles][1024] escaped length of the tile's k-th string (counting pass -> writing pass)
     const u8 *strings_end, *msg_end;  // ends of the buffers the strings live in (8-byte loads stop there)
     u8 *text;
@@ -62,6 +64,11 @@ struct KeyView {
 __device__ __forceinline__ const u8 *entry_string(const MsView &p, u64 word) {
     const u64 v = word & TW_PAYLOAD;
     return (v & STRINGBUFBIT) ? p.strings + (v & (STRINGBUFBIT - 1)) : p.msg + v;
+}
+
+// e: queue entry of a string (its ordinal inside the tile in bits 11..20), at: its tape index
+__device__ __forceinline__ bool entry_is_key(const MsView &p, u64 key_base, u32 e, u64 at) {
+    return (p.kf_tape ? p.kf_tape[at >> 1] : p.keyflag[key_base + ((e >> 11) & 0x3ffu)]) != 0;
 }
 
 // escapeBytes: bytes below 0x20, '"' and '\\' are escaped (shouldEscape, parsed_json.go:1171-1186)
@@ -139,7 +146,8 @@ __global__ __launch_bounds__(1024) void k_ms_scan(unsigned long long *a, unsigne
 //      entry inside the tile's text (s_len turns into offsets), literals and brackets are written right there
 //   4. write, queue by queue, into the tile's LDS window (or straight to memory when the tile's text is larger), then
 //      the block copies the window out with coalesced stores.
-static constexpr u32 MS_WINDOW = 32768;  // bytes of text a tile stages in LDS (48 KB per block with the queues: 3 blocks per CU)
+static constexpr u32 MS_WINDOW = 32768;  // bytes of text a tile stages in LDS at most (the launcher picks 16 KiB: 36 KB per block
+                                         // with the queues, 4 blocks per CU)
 static constexpr u32 MS_LONG = 64;       // strings from this length on are measured / written by a whole wave
 static constexpr u32 MS_QCAP = TW_TILE / 2;  // a string or a number takes two words
 
@@ -182,8 +190,9 @@ __device__ __forceinline__ u8 *write_esc8(u8 *o, u64 w, u32 valid) {
     return o;
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
+// WPE: waves per SIMD the register allocation aims at (launch bound), WINDOW: bytes of text a tile stages in LDS
+template <bool EMIT, int WPE, u32 WINDOW>
+__global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     __shared__ long long s_l[TW_THREADS / 64];
     __shared__ unsigned long long s_s[TW_THREADS / 64];
     __shared__ u32 s_len[TW_TILE];   // per word: text bytes of the entry that starts there (0: none); writing pass: then its offset
@@ -191,15 +200,23 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     // length << 23 (short ones) | offset << 32: a short string needs no second look at the tape
     __shared__ u64 s_qs[MS_QCAP];
     __shared__ u32 s_qn[MS_QCAP];    // numbers: integers from the front, floats from the back; idx | sep << 11
-    __shared__ u32 s_cnt[4];         // short strings, long strings, integers, floats
-    __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? MS_WINDOW : 16];
+    __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? WINDOW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 tb = (u64)blockIdx.x * TW_TILE;
     const u64 base = tb + (u64)tid * TW_ITEMS;
-    if (tid < 4) s_cnt[tid] = 0;
     u64 w[TW_ITEMS + 2];  // the thread's words and the two behind them (an entry's second word, the next entry's tag)
+    if (base + TW_ITEMS + 2 <= p.n) {  // five 16-byte loads (the tape arena is 256-byte aligned, base a multiple of 8 words)
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(p.tape + base);
 #pragma unroll
-    for (int k = 0; k < TW_ITEMS + 2; k++) w[k] = base + k < p.n ? p.tape[base + k] : 0;
+        for (int k = 0; k < (TW_ITEMS + 2) / 2; k++) {
+            const uint4 v = q4[k];
+            w[2 * k] = (u64)v.x | ((u64)v.y << 32);
+            w[2 * k + 1] = (u64)v.z | ((u64)v.w << 32);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TW_ITEMS + 2; k++) w[k] = base + k < p.n ? p.tape[base + k] : 0;
+    }
     long long last = -1;
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++)
@@ -209,6 +226,11 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
     __shared__ long long s_carry;
     const long long carry = p.tile_last ? p.tile_last[blockIdx.x] : tw_local_anchor(p.tape, tb, tid, &s_carry);
+    // queue slots are drawn with LDS atomics, in whatever order the lanes arrive.  (Slots in document order from one packed
+    // block scan -- no atomics, adjacent lanes on adjacent strings -- were measured twice: configs[4] 2.01 instead of
+    // 1.75 ms, configs[1] 1.32 instead of 1.34, tools/gpu_ab_marshal.sh.)
+    __shared__ u32 s_cnt[4];         // short strings, long strings, integers, floats
+    if (tid < 4) s_cnt[tid] = 0;
     long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0)
     if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
         if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     // that cost a fraction of scattered global ones) and copies the window out with coalesced 4-byte stores; a tile
     // with more text (long strings) writes straight to memory.
     const u64 tile_bytes = tot;
-    const bool staged = tile_bytes <= MS_WINDOW;  // block-uniform
+    const bool staged = tile_bytes <= WINDOW;  // block-uniform
     u8 *const gdst = p.text + p.cnt_b[blockIdx.x];
     u8 *const tbase = staged ? s_text : gdst;
     {
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
         for (u32 q = 0; q < nl; q++) o[q] = tmp[q];
         if ((e >> 11) & 1u) o[nl] = ',';
     }
-    const u64 key_base = p.cnt_s[blockIdx.x];
+    const u64 key_base = p.kf_tape ? 0 : p.cnt_s[blockIdx.x];
     for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
         const u64 e64 = s_qs[j];
         const u32 e = (u32)e64, idx = e & 0x7ffu;
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
         *o++ = '"';
         for (u64 q = 0; q < len; q += 8) o = write_esc8(o, str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
         *o++ = '"';
-        if ((e >> 21) & 1u) *o = p.keyflag[key_base + ((e >> 11) & 0x3ffu)] ? ':' : ',';
+        if ((e >> 21) & 1u) *o = entry_is_key(p, key_base, e, tb + idx) ? ':' : ',';
     }
     for (u32 j = (u32)wave; j < n_long; j += TW_THREADS / 64) {  // one wave per long string: 512 bytes per step
         const u64 e64 = s_qs[MS_QCAP - 1 - j];
@@ -446,7 +468,7 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
         }
         if (lane == 0) {
             *o++ = '"';
-            if ((e >> 21) & 1u) *o = p.keyflag[key_base + ((e >> 11) & 0x3ffu)] ? ':' : ',';
+            if ((e >> 21) & 1u) *o = entry_is_key(p, key_base, e, tb + idx) ? ':' : ',';
         }
     }
     if (staged) {
@@ -459,6 +481,28 @@ __global__ __launch_bounds__(TW_THREADS) void k_ms_tile(MsView p) {
     }
 }
 
+// SJHIP_MS_VARIANT (experiments): register budget / LDS window of the tile kernel
+static int ms_variant() {
+    static const int v = [] {
+        const char *e = getenv("SJHIP_MS_VARIANT");
+        return e ? atoi(e) : 3;
+    }();
+    return v;
+}
+// Measured on configs[4] / configs[1] (tools/gpu_marshal_variants.sh, key flags from the parser): (4 waves, 32 KiB) 1.94 /
+// 1.54 ms, (6, 32 KiB) 1.93 / 1.47, (6, 16 KiB) 1.74 / 1.32, (6 -- 8 is not reachable with this much LDS --, 8 KiB) 1.80 / 1.38:
+// a tile of parking-citations is 9.5 KB of text, one of twitter.json 19 KB; four blocks per CU instead of three in the
+// writing pass pay for the tiles that no longer fit the window.
+template <bool EMIT>
+static void launch_ms_tile(const MsView &p, hipStream_t st) {
+    const dim3 g(p.tiles), b(TW_THREADS);
+    switch (ms_variant()) {
+        case 0: hipLaunchKernelGGL((k_ms_tile<EMIT, 4, MS_WINDOW>), g, b, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW>), g, b, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
+    }
+}
 }  // namespace
 
 int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
@@ -506,11 +550,14 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     p.slen = (u32 *)w;
     p.text = nullptr;
     HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
-    // keys from the token array of the parse
-    hipLaunchKernelGGL(k_ms_keys<false>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
-    hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, kv.cnt, (unsigned long long *)nullptr, kv.tiles,
-                       (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
+    // keys: the flags the parser left (SJHIP_FLAG_KEY_FLAGS), or from the token array of the parse (three launches)
+    p.kf_tape = (ctx->kf_valid && ctx->q_valid) ? (const u8 *)ctx->d_keyflag.p : nullptr;
+    if (!p.kf_tape) {
+        hipLaunchKernelGGL(k_ms_keys<false>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
+        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, kv.cnt, (unsigned long long *)nullptr, kv.tiles,
+                           (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
+    }
     // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
     long long *const tile_last = p.tile_last;
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
@@ -523,8 +570,10 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
             hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
             hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
         }
-        hipLaunchKernelGGL(k_ms_tile<false>, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p);
-        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.cnt_s, p.tiles, p.totals);
+        launch_ms_tile<false>(p, ctx->stream);
+        // (the prefix of the string counts is only needed to index the recovered key flags)
+        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.kf_tape ? (unsigned long long *)nullptr : p.cnt_s,
+                           p.tiles, p.totals);
         HIPCHK(hipGetLastError(), "marshal launch");
         HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
         HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
@@ -541,7 +590,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     rc = arena_reserve(ctx, ctx->d_qtape, (size_t)h[0] + 64);
     if (rc) return rc;
     p.text = (u8 *)ctx->d_qtape.p;
-    hipLaunchKernelGGL(k_ms_tile<true>, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p);
+    launch_ms_tile<true>(p, ctx->stream);
     HIPCHK(hipGetLastError(), "marshal emit launch");
     ctx->ms_len = (size_t)h[0];
     ctx->ms_valid = 1;

@@ -75,6 +75,7 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.strings_base = strings_base;
     a.msg_base = msg_base;
     a.str_aux = ctx->p_aux;
+    a.d_keyflag = (ctx->p_flags & SJHIP_FLAG_KEY_FLAGS) ? (uint8_t *)ctx->d_keyflag.p : nullptr;
     a.stream = ctx->stream;
     return a;
 }
@@ -105,6 +106,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->pending = 0;
     ctx->pack_valid = 0;
     ctx->q_valid = 0;
+    ctx->kf_valid = 0;
     ctx->ser_valid = 0;
     ctx->ms_valid = 0;
     ctx->f_valid = 0;
@@ -169,6 +171,10 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_strings, len + 64);
     if (rc) return rc;
+    if (flags & SJHIP_FLAG_KEY_FLAGS) {
+        rc = arena_reserve(ctx, ctx->d_keyflag, n + 1 + 8);  // tape_cap / 2 + 8
+        if (rc) return rc;
+    }
     ctx->p_aux = aux;
     ctx->pending = 1;
     ctx->p_msg = d_msg;
@@ -274,6 +280,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     ctx->strings_len = (ctx->p_aux && (ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
     ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
+    ctx->kf_valid = ctx->q_valid && (ctx->p_flags & SJHIP_FLAG_KEY_FLAGS) && ctx->d_keyflag.p;
     if (tape_len) *tape_len = ctx->tape_len;
     if (strings_len) *strings_len = ctx->strings_len;
     return SJHIP_OK;
@@ -383,5 +390,53 @@ int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
         HIPCHK(hipMemcpyAsync(strings_dst, ctx->d_strings.p, ctx->strings_len, hipMemcpyDeviceToHost, ctx->stream),
                "D2H strings");
     HIPCHK(hipStreamSynchronize(ctx->stream), "fetch sync");
+    return SJHIP_OK;
+}
+
+static size_t view_limit_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("SJHIP_VIEW_LIMIT_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)4 << 30;
+    }();
+    return v;
+}
+
+int sjhip_fetch_view(sjhip_ctx *ctx, const uint64_t **tape, const uint8_t **strings) {
+    if (!ctx || !tape || !strings) return SJHIP_ERR_ARG;
+    *tape = nullptr;
+    *strings = nullptr;
+    const size_t tb = ctx->tape_len * sizeof(uint64_t), sb = ctx->strings_len;
+    if (!ctx->big_valid && ctx->pack_valid && ctx->h_pack) {  // a small sjhip_parse: nothing to move
+        if (tb) *tape = (const uint64_t *)(ctx->h_pack + STAGE2_PACK_HEAD);
+        if (sb) *strings = ctx->h_pack + STAGE2_PACK_HEAD + tb;
+        return SJHIP_OK;
+    }
+    const size_t need = tb + sb + 64;
+    if (need > view_limit_bytes()) {
+        ctx_set_error(ctx, "sjhip_fetch_view: a result of %zu bytes is beyond SJHIP_VIEW_LIMIT_BYTES (%zu): use sjhip_fetch", tb + sb,
+                      view_limit_bytes());
+        return SJHIP_ERR_TOOBIG;
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (need > ctx->h_view_cap) {
+        if (ctx->h_view) (void)hipHostFree(ctx->h_view);
+        ctx->h_view = nullptr;
+        ctx->h_view_cap = 0;
+        const size_t cap = (need + need / 4 + ((size_t)1 << 20)) & ~(size_t)4095;
+        const hipError_t e = sj::pinned_alloc((void **)&ctx->h_view, cap);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->h_view = nullptr;
+            ctx_set_error(ctx, "hipHostMalloc of %zu bytes for the result view: %s", cap, hipGetErrorString(e));
+            return SJHIP_ERR_HIP;
+        }
+        ctx->h_view_cap = cap;
+    }
+    uint64_t *const t = (uint64_t *)ctx->h_view;
+    uint8_t *const st = ctx->h_view + tb;
+    const int rc = sjhip_fetch(ctx, tb ? t : nullptr, sb ? st : nullptr);  // (sharded big ND results included)
+    if (rc) return rc;
+    if (tb) *tape = t;
+    if (sb) *strings = st;
     return SJHIP_OK;
 }

@@ -554,7 +554,7 @@ bool get_block(const uint8_t *src, size_t len, size_t *o, uint64_t *size, size_t
 
 int sjhip_deserialize(sjhip_ctx *ctx, const uint8_t *stream, size_t len, size_t *tape_len, size_t *strings_len, size_t *message_len) {
     if (!ctx || !stream) return SJHIP_ERR_ARG;
-    ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = 0;
+    ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->kf_valid = 0;
     ctx->pending = 0;
     ctx->pack_valid = 0;
     ctx->tape_len = ctx->strings_len = 0;

@@ -23,7 +23,7 @@ namespace sj {
 enum ArrId : uint32_t {
     A_NONE = 0, A_MSG, A_POS, A_KIND, A_DLEN, A_STR_OFF, A_NL_OFF, A_NUMQ, A_BIGQ, A_STRQ, A_BR_DEPTH, A_BR_OFF, A_BR_INFO, A_AGG,
     A_LEV, A_TAPE, A_STRINGS, A_STR_OUT, A_REC, A_UNIT_CNT, A_SV_BASE, A_SV_QM, A_SV_Q, A_SV_ST, A_SV_UNIT_H, A_SV_UNIT_SLOW,
-    A_SELFTEST
+    A_SELFTEST, A_KEYFLAG
 };
 
 #if defined(SJ_DEBUG_BOUNDS)

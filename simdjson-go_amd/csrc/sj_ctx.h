@@ -26,9 +26,13 @@ struct sjhip_ctx {
     uint8_t *h_pack = nullptr;
     int want_pack = 0;                 // set by sjhip_parse for the parse it starts
     int pack_valid = 0;                // h_pack holds the result of the last parse
+    uint8_t *h_view = nullptr;         // sjhip_fetch_view of results that did not travel with the last launch (grows)
+    size_t h_view_cap = 0;
     uint8_t *h_stage = nullptr;        // pinned staging of sjhip_parse_batch: runs of small documents travel as one copy
     size_t h_stage_cap = 0;
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
+    sj::DevBuf d_keyflag;              // SJHIP_FLAG_KEY_FLAGS: key flags of the string entries, for marshal.hip
+    int kf_valid = 0;                  // ... and they belong to the resident result
     sj::DevBuf d_strtmp;               // WithCopyStrings(false): the unescaped bytes of all strings (parse_api.hip)
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B

@@ -63,6 +63,8 @@ struct S2Args {
     size_t strings_cap;
     uint64_t tape_base, strings_base, msg_base;
     void *str_aux;          // string masks of stage 1 (str_aux_layout) or null: per-string walks
+    uint8_t *d_keyflag;     // null, or tape_cap / 2 + 8 bytes: [tape index of a string entry >> 1] = 1 iff it is an object key
+                            // (SJHIP_FLAG_KEY_FLAGS; indices inside this parse's tape, without tape_base)
     hipStream_t stream;
     // null, or a second stream + two events: the string bytes (k_str_emit) run beside the tape kernels (stage2_launch_emit)
     hipStream_t side;

@@ -93,7 +93,16 @@ __device__ __forceinline__ long long block1024_scan_array(long long *a, u32 n, l
     const u32 per = ((n + 15u) / 16u + 63u) / 64u * 64u;
     const u32 lo = (u32)wave * per < n ? (u32)wave * per : n, hi = lo + per < n ? lo + per : n;
     long long acc = id;
-    for (u32 i = lo + (u32)lane; i < hi; i += 64) acc = op(acc, a[i]);
+    for (u32 c0 = lo; c0 < hi; c0 += 64 * 8) {  // (eight loads in flight: one at a time is a memory round trip per 64 entries)
+        long long v8[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const u32 i = c0 + (u32)g * 64u + (u32)lane;
+            v8[g] = i < hi ? a[i] : id;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; g++) acc = op(acc, v8[g]);
+    }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc = op(acc, __shfl_xor(acc, s, 64));
     if (lane == 0) s_w[wave] = acc;
@@ -104,19 +113,27 @@ __device__ __forceinline__ long long block1024_scan_array(long long *a, u32 n, l
         if (w < wave) carry = op(carry, x);
         total = op(total, x);
     }
-    for (u32 c = lo; c < hi; c += 64) {
-        const u32 i = c + (u32)lane;
-        const long long v = i < hi ? a[i] : id;
-        long long incl = v;
+    for (u32 c0 = lo; c0 < hi; c0 += 64 * 8) {  // eight groups of 64 at a time: their loads are one round trip, not eight
+        long long v8[8];
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const long long o = __shfl_up(incl, s, 64);
-            if (lane >= s) incl = op(o, incl);
+        for (int g = 0; g < 8; g++) {
+            const u32 i = c0 + (u32)g * 64u + (u32)lane;
+            v8[g] = i < hi ? a[i] : id;
         }
-        long long ex = __shfl_up(incl, 1, 64);
-        if (lane == 0) ex = id;
-        if (i < hi) a[i] = op(carry, ex);
-        carry = op(carry, __shfl(incl, 63, 64));
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const u32 i = c0 + (u32)g * 64u + (u32)lane;
+            long long incl = v8[g];
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const long long o = __shfl_up(incl, s, 64);
+                if (lane >= s) incl = op(o, incl);
+            }
+            long long ex = __shfl_up(incl, 1, 64);
+            if (lane == 0) ex = id;
+            if (i < hi) a[i] = op(carry, ex);
+            carry = op(carry, __shfl(incl, 63, 64));
+        }
     }
     __syncthreads();  // (s_w may be used again)
     return total;

@@ -96,6 +96,8 @@ struct S2Dev {
                                      // a single short round (<= 16 384 units, <= 1024 tiles): nothing to publish or wait for
     Arr<u64> tape;
     Arr<u8> strings;
+    Arr<u8> keyflag;   // null, or [tape_cap / 2 + 8]: [tape offset of a string entry >> 1] = 1 iff the string is an object key
+                       // (SJHIP_FLAG_KEY_FLAGS: marshal.hip reads them instead of recovering them from the token kinds)
     Arr<u8> str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
                    // scratch buffer with WithCopyStrings(false), from which k_emit_strings takes the strings that changed
     u64 tape_cap, strings_cap;
@@ -1138,6 +1140,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 6) void k_s2_emit(S2Dev p) {
             const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
             if (!SJ_EXPBIT(p, 2))
                 *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+            if (p.keyflag) p.keyflag[(T0 + (v >> 12)) >> 1] = s_kind[4 + idx + 1] == K_COLON ? 1 : 0;
         }
     }
     // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 6) void k_s2_emit(S2Dev p) {
                     len = dlw & ~DLEN_COPY;
                     const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = len;
                     *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                    if (p.keyflag) p.keyflag[(T0 + (v >> 12)) >> 1] = s_kind[4 + idx + 1] == K_COLON ? 1 : 0;
                     if (!p.sv.qm) p.str_off[t0 + idx] = so;  // (per-string walks: k_emit_strings looks the offset up per token)
                     queue = cp && len != 0 && p.sv.qm;
                 }
@@ -1635,6 +1639,8 @@ static S2Dev stage2_view(const S2Args &a) {
     }
     p.tape = SJ_ARR(a.d_tape, a.tape_cap, A_TAPE);
     p.strings = SJ_ARR(a.d_strings, a.strings_cap, A_STRINGS);
+    p.keyflag = nullptr;
+    if (a.d_keyflag) p.keyflag = SJ_ARR(a.d_keyflag, a.tape_cap / 2 + 8, A_KEYFLAG);
     p.tape_cap = a.tape_cap;
     p.strings_cap = a.strings_cap;
     p.tape_base = a.tape_base;

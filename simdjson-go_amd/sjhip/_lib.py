@@ -30,6 +30,7 @@ SYMBOLS = {
     "sjhip_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp, szp, szp]),
     "sjhip_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sjhip_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
+    "sjhip_fetch_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "sjhip_parse_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_parse_shard_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "sjhip_multi_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int]),

@@ -16,6 +16,7 @@ from . import _lib
 
 FLAG_NDJSON = 1
 FLAG_COPY_STRINGS = 2
+FLAG_KEY_FLAGS = 4  # the parse leaves the key flags MarshalJSON needs (include/sjhip.h)
 
 ERR_STAGE1 = "Failed to find all structural indices for stage 1"
 ERR_STAGE2 = "Bad parsing while executing stage 2"
@@ -30,6 +31,15 @@ class ParseError(Exception):
 
 def supported() -> bool:
     return bool(_lib.lib().sjhip_supported())
+
+
+def _pinned_view(ptr, count, ctype, dtype):
+    """numpy array over `count` elements of library-owned host memory (read-only)"""
+    if not count or not ptr:
+        return np.empty(0, dtype=dtype)
+    a = np.frombuffer((ctype * count).from_address(ptr), dtype=dtype)
+    a.flags.writeable = False
+    return a
 
 
 class Context:
@@ -100,28 +110,39 @@ class Context:
         return ms.value
 
     # ---- whole parse -----------------------------------------------------------------------
-    def parse(self, data, ndjson=False, copy_strings=True, reuse=None):
+    def parse(self, data, ndjson=False, copy_strings=True, reuse=None, view=False, key_flags=False):
         """Parse / ParseND.  `reuse`: a ParsedJson whose Tape / Strings capacity is recycled (the reference's
-        `reuse *ParsedJson`, simdjson_amd64.go:46-51): its arrays are overwritten."""
+        `reuse *ParsedJson`, simdjson_amd64.go:46-51): its arrays are overwritten.
+        `view=True`: Tape / Strings are read-only views of the context's pinned result block (sjhip_fetch_view) --
+        no copy into Python-owned arrays; like a recycled ParsedJson they are overwritten by the next parse on this
+        context.  `key_flags=True`: marshal_json() of this result is going to be called (SJHIP_FLAG_KEY_FLAGS)."""
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         tl, sl, mo, ml = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
+        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0) | (FLAG_KEY_FLAGS if key_flags else 0)
         L = _lib.lib()
         rc = L.sjhip_parse(self._h, a.ctypes.data if a.size else None, a.size, flags, C.byref(tl), C.byref(sl),
                            C.byref(mo), C.byref(ml))
         self._check(rc)
+        msg = a[mo.value: mo.value + ml.value]  # (a view: no copy of the message on the parse path)
+        if view:
+            tp, sp = C.c_void_p(), C.c_void_p()
+            self._check(L.sjhip_fetch_view(self._h, C.byref(tp), C.byref(sp)))
+            tape = _pinned_view(tp.value, tl.value, C.c_uint64, np.uint64)
+            strings = _pinned_view(sp.value, sl.value, C.c_uint8, np.uint8)
+            pj = ParsedJson(msg, tape, strings)
+            pj._owner = self  # the views live in this context's pinned memory
+            return pj
         tape_buf = reuse._tape_buf if reuse is not None and reuse._tape_buf.size >= tl.value else \
             np.empty(tl.value, dtype=np.uint64)
         str_buf = reuse._str_buf if reuse is not None and reuse._str_buf.size >= sl.value else \
             np.empty(sl.value, dtype=np.uint8)
         rc = L.sjhip_fetch(self._h, tape_buf.ctypes.data, str_buf.ctypes.data)
         self._check(rc)
-        msg = a[mo.value: mo.value + ml.value]  # (a view: no copy of the message on the parse path)
         return ParsedJson(msg, tape_buf[:tl.value], str_buf[:sl.value], tape_buf, str_buf)
 
-    def parse_device(self, d_msg_ptr, length, ndjson=False, copy_strings=True):
+    def parse_device(self, d_msg_ptr, length, ndjson=False, copy_strings=True, key_flags=False):
         tl, sl = C.c_size_t(0), C.c_size_t(0)
-        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0)
+        flags = (FLAG_NDJSON if ndjson else 0) | (FLAG_COPY_STRINGS if copy_strings else 0) | (FLAG_KEY_FLAGS if key_flags else 0)
         rc = _lib.lib().sjhip_parse_device(self._h, C.c_void_p(d_msg_ptr), length, flags, C.byref(tl), C.byref(sl))
         self._check(rc)
         return tl.value, sl.value
@@ -270,7 +291,7 @@ class MultiContext:
 class ParsedJson:
     """parsed_json.go:64-71: Message / Tape / Strings."""
 
-    __slots__ = ("_msg", "Tape", "Strings", "_tape_buf", "_str_buf", "records", "device")
+    __slots__ = ("_msg", "Tape", "Strings", "_tape_buf", "_str_buf", "records", "device", "_owner")
 
     def __init__(self, message, tape, strings, tape_buf=None, str_buf=None):
         # `message`: bytes, or a uint8 view of the caller's buffer -- the reference's pj.Message ALIASES the input
@@ -282,6 +303,7 @@ class ParsedJson:
         self._str_buf = strings if str_buf is None else str_buf
         self.records = 0  # filtered streams: matching records of the block
         self.device = -1  # streams: the GPU that parsed the block
+        self._owner = None  # view=True: the Context whose pinned block Tape / Strings alias
 
     @property
     def Message(self):
@@ -300,14 +322,14 @@ def _default_ctx(device=0):
     return c
 
 
-def parse(b, reuse=None, copy_strings=True, ctx=None):
+def parse(b, reuse=None, copy_strings=True, ctx=None, view=False):
     """Parse(b, reuse, WithCopyStrings(copy_strings)) -- simdjson_amd64.go:66."""
-    return (ctx or _default_ctx()).parse(b, ndjson=False, copy_strings=copy_strings, reuse=reuse)
+    return (ctx or _default_ctx()).parse(b, ndjson=False, copy_strings=copy_strings, reuse=reuse, view=view)
 
 
-def parse_nd(b, reuse=None, copy_strings=True, ctx=None):
+def parse_nd(b, reuse=None, copy_strings=True, ctx=None, view=False):
     """ParseND(b, reuse, ...) -- simdjson_amd64.go:82."""
-    return (ctx or _default_ctx()).parse(b, ndjson=True, copy_strings=copy_strings, reuse=reuse)
+    return (ctx or _default_ctx()).parse(b, ndjson=True, copy_strings=copy_strings, reuse=reuse, view=view)
 
 
 def stage1(b, ndjson=False, ctx=None):

@@ -104,6 +104,15 @@ static int mode_parse(int argc, char **argv) {
             rc = sjhip_fetch(ctx, tl ? pj.tape : NULL, sl ? pj.strings : NULL);
         }
     }
+    if (rc == SJHIP_OK) { /* the same result read in place (sjhip_fetch_view) must be what sjhip_fetch copied out */
+        const uint64_t *vt = NULL;
+        const uint8_t *vs = NULL;
+        rc = sjhip_fetch_view(ctx, &vt, &vs);
+        if (rc == SJHIP_OK && ((tl && (!vt || memcmp(vt, pj.tape, tl * 8))) || (sl && (!vs || memcmp(vs, pj.strings, sl))))) {
+            fprintf(stderr, "sjhip_fetch_view differs from sjhip_fetch\n");
+            rc = 99;
+        }
+    }
     FILE *f = fopen(argv[3], "wb");
     dump_result(f, rc, &pj, off, ml);
     fclose(f);

@@ -20,11 +20,15 @@ def check_marshal(ctx, doc, nd, what):
         assert ref.rc == 0, what
         rc, want = O.marshal_json(ref.tape, ref.strings, doc[ref.msg_off:ref.msg_off + ref.msg_len])
         assert rc == 0, what
-        ctx.parse(doc, ndjson=nd, copy_strings=copy)
-        got = ctx.marshal_json()
-        if got != want:
-            k = next(i for i in range(min(len(got), len(want)) + 1) if got[i:i + 1] != want[i:i + 1])
-            raise AssertionError((what, copy, len(got), len(want), k, got[max(0, k - 30):k + 30], want[max(0, k - 30):k + 30]))
+        # the key flags recovered from the token kinds (three launches of marshal.hip), then left by the parser
+        # (SJHIP_FLAG_KEY_FLAGS); the parse itself must not notice the flag
+        for kf in (False, True):
+            pj = ctx.parse(doc, ndjson=nd, copy_strings=copy, key_flags=kf)
+            assert pj.Tape.tolist() == ref.tape.tolist() and pj.Strings.tobytes() == ref.strings.tobytes(), (what, copy, kf)
+            got = ctx.marshal_json()
+            if got != want:
+                k = next(i for i in range(min(len(got), len(want)) + 1) if got[i:i + 1] != want[i:i + 1])
+                raise AssertionError((what, copy, kf, len(got), len(want), k, got[max(0, k - 30):k + 30], want[max(0, k - 30):k + 30]))
     return want
 
 
@@ -100,3 +104,27 @@ def test_random_documents(ctx):
 def test_full_size_c5(ctx):
     import workloads
     check_marshal(ctx, workloads.c5_parking_nd(200), True, "parking x200")
+
+
+def test_key_flags_on_every_parse_path(ctx):
+    """SJHIP_FLAG_KEY_FLAGS on the paths a parse can take: the deferred small parse, the synchronous one (> 4 MiB), the
+    per-string fallback behind a long surrogate run (k_s2_emit<false> without string masks), and a parse without the
+    flag after one with it (stale flags must not be used)."""
+    from test_host_stage2 import surrogate_run_docs
+    fell_back = 0
+    for doc, what in surrogate_run_docs():
+        if O.parse(doc).rc == 0:
+            check_marshal(ctx, doc, False, what)
+            fell_back += doc.count(b"\\ud800") > 4096
+    assert fell_back >= 3
+    hi = b"\\ud800"
+    keys = b'{"a' + hi * 4100 + b'":{"b":"c' + hi * 4098 + b'"},"d":["e","f"]}'  # (an even run pairs up: valid)
+    assert O.parse(keys).rc == 0
+    check_marshal(ctx, keys, False, "long surrogate runs in a key and in a value")
+    big = b"[" + b",".join(b'{"id":%d,"name":"n%d","tags":["a","b",{"c":"d"}],"ok":true}' % (i, i) for i in range(120000)) + b"]"
+    assert len(big) > (4 << 20)
+    check_marshal(ctx, big, False, "synchronous path")
+    # flags of an earlier parse are not picked up by a later one without the flag
+    ctx.parse(b'{"a":"b","c":["d",{"e":"f"}]}', key_flags=True)
+    ctx.parse(b'["a","b",{"c":"d"},"e"]')
+    assert ctx.marshal_json() == b'["a","b",{"c":"d"},"e"]'

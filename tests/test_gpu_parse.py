@@ -596,6 +596,35 @@ def test_fetch_after_small_parse_paths(ctx):
                 assert np.array_equal(tape, ref.tape) and np.array_equal(strs, ref.strings), (len(doc), stage1_between)
 
 
+def test_fetch_view_equals_fetch(ctx):
+    """sjhip_fetch_view: Tape / Strings read in place from the context's pinned memory -- the packed block of a small
+    parse, the grown view block of everything else (results beyond 2 MiB, ND, nocopy, a parse that needed the bignum
+    pass) -- are the arrays sjhip_fetch copies out; the views are read-only and are overwritten by the next parse."""
+    import sjhip
+    docs = [(fixtures.load("twitter"), False), (fixtures.load("canada"), False), (fixtures.load("twitterescaped"), False),
+            (fixtures.load("parking-citations") * 9, True), (b'{"a":1}', False), (b"[]", False),
+            (b"[" + b"123456789012345678901234567890e-5," * 40 + b"1]", False),
+            (b"\n".join(b'{"k":"%d\\n","v":[%d]}' % (i, i) for i in range(30000)), True)]
+    for data, nd in docs:
+        for copy in (True, False):
+            want = ctx.parse(data, ndjson=nd, copy_strings=copy)
+            wt, ws = want.Tape.copy(), want.Strings.copy()
+            got = ctx.parse(data, ndjson=nd, copy_strings=copy, view=True)
+            assert not got.Tape.flags.writeable and (got.Strings.size == 0 or not got.Strings.flags.writeable)
+            assert np.array_equal(got.Tape, wt) and np.array_equal(got.Strings, ws), (len(data), nd, copy)
+            assert got.Message == want.Message
+    # the view of a large result, then a small one, then the large one again (the block only grows)
+    big = ctx.parse(docs[3][0], ndjson=True, view=True)
+    big_t = big.Tape.copy()
+    small = ctx.parse(b'[1,"x"]', view=True)
+    assert small.Tape.tolist() == O.parse(b'[1,"x"]').tape.tolist()
+    again = ctx.parse(docs[3][0], ndjson=True, view=True)
+    assert np.array_equal(again.Tape, big_t)
+    # a failed parse leaves no view behind
+    with pytest.raises(sjhip.ParseError):
+        ctx.parse(b'{"a":', view=True)
+
+
 def test_small_documents_denser_than_the_deferred_layout(ctx):
     """Documents up to SJHIP_SMALL_BYTES run with one host synchronisation on stage-2 arrays laid out for one token per
     four bytes (csrc/parse_api.hip); a denser document must come back through the synchronous path with the same

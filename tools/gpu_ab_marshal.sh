@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of MarshalJSON wall time between the libraries in build_ab/ (same box, interleaved twice)
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+for round in 1 2; do
+for lib in $(ls build_ab/libsjhip_ms_*.so); do
+for w in parking twitter; do
+echo -n "$lib "; SJHIP_LIB=$PWD/$lib timeout 200 python tools/marshal_loop.py $w 5 kf 2>&1 | grep marshal_json
+done; done; done

@@ -55,7 +55,16 @@ int main(int argc, char **argv) {
         sjhip_parse(ctx, doc.data(), doc.size(), flags, &tl, &sl, &mo, &ml);
         sjhip_fetch(ctx, tape.data(), strings.data());
     });
+    const uint64_t *vt = nullptr;
+    const uint8_t *vs = nullptr;
+    uint64_t sink = 0;
+    const double t_view = best_of(5, 40, [&] {
+        sjhip_parse(ctx, doc.data(), doc.size(), flags, &tl, &sl, &mo, &ml);
+        sjhip_fetch_view(ctx, &vt, &vs);
+        sink += vt ? vt[tl - 1] : 0;
+    });
     printf("%s: %zu B, tape %zu words, strings %zu B\n", argv[1], doc.size(), tl, sl);
+    printf("  sjhip_parse + sjhip_fetch_view (in place)  %8.1f us   (%llu)\n", t_view, (unsigned long long)(sink & 1));
     printf("  sjhip_parse (pageable H2D + kernels)      %8.1f us\n", t_parse);
     printf("  sjhip_parse + sjhip_fetch (pageable D2H)  %8.1f us\n", t_both);
     // the raw copies of the same sizes

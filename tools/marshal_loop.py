@@ -21,7 +21,8 @@ d = torch.empty(len(doc) + 256, dtype=torch.uint8, device="cuda:0")
 d[:len(doc)].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
 torch.cuda.synchronize()
 ctx = sjhip.Context(0)
-tl, sl = ctx.parse_device(d.data_ptr(), len(doc), ndjson=nd, copy_strings=True)
+kf = len(sys.argv) > 3 and sys.argv[3] == "kf"
+tl, sl = ctx.parse_device(d.data_ptr(), len(doc), ndjson=nd, copy_strings=True, key_flags=kf)
 ctx.marshal_json(fetch=False)
 t0 = time.perf_counter()
 for _ in range(iters):
