@@ -199,6 +199,15 @@ int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_l
         ctx_set_error(ctx, "stage-1 kernel aborted (internal synchronisation timeout)");
         return SJHIP_ERR_HIP;
     }
+    {  // debug build: an out-of-bounds store of the stage-1 kernel fails the call, whatever its verdict
+        unsigned hits = 0, id = 0;
+        unsigned long long index = 0, size = 0;
+        if (stage1_debug_bounds(&hits, &id, &index, &size) && hits) {
+            ctx_set_error(ctx, "bounds check: %u out-of-bounds accesses in stage 1, the first to array %u (sj_bounds.h ArrId) at element %llu of %llu",
+                          hits, id, index, size);
+            return SJHIP_ERR_HIP;
+        }
+    }
     *n = (size_t)hs->total;
     *ok = stage1_verdict(*hs, len, last_byte);
     return SJHIP_OK;

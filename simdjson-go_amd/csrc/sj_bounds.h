@@ -1,5 +1,6 @@
 // sj_bounds.h -- bounds-checked views of the device arenas for the debug build (-DSJ_DEBUG_BOUNDS).
 //
+// The stage-1 kernels write positions, kinds and the string masks through such views as well (stage1.hip).
 // The kernels of stage2.hip reach every array of the parse -- message, positions, kinds, the stage-2 work arrays, the
 // string masks and records, tape and Strings.B -- through the fields of S2Dev / StrView.  Those fields are declared as
 // Arr<T>: in the product build that is a plain T* (no code changes, no cost); in the debug build it is a pointer with
@@ -23,7 +24,8 @@ namespace sj {
 enum ArrId : uint32_t {
     A_NONE = 0, A_MSG, A_POS, A_KIND, A_DLEN, A_STR_OFF, A_NL_OFF, A_NUMQ, A_BIGQ, A_STRQ, A_BR_DEPTH, A_BR_OFF, A_BR_INFO, A_AGG,
     A_LEV, A_TAPE, A_STRINGS, A_STR_OUT, A_REC, A_UNIT_CNT, A_SV_BASE, A_SV_QM, A_SV_Q, A_SV_ST, A_SV_UNIT_H, A_SV_UNIT_SLOW,
-    A_SELFTEST, A_KEYFLAG
+    A_SELFTEST, A_KEYFLAG,
+    A_S1_POS, A_S1_KIND, A_S1_QM, A_S1_Q, A_S1_ST, A_S1_UNIT_H, A_S1_UNIT_SLOW  // stage 1's outputs (stage1.hip)
 };
 
 #if defined(SJ_DEBUG_BOUNDS)
@@ -82,6 +84,7 @@ SJ_HD T *arr_at(const Arr<T> &a, unsigned long long first, unsigned long long co
 template <typename T>
 SJ_HD T *arr_raw(const Arr<T> &a) { return a.p; }  // (launchers: memsets and copies of whole arrays)
 #define SJ_ARR(ptr, count, id) ::sj::Arr<typename std::remove_pointer<decltype(ptr)>::type>((ptr), (unsigned long long)(count), (id))
+#define SJ_ARR_PARAM(T) ::sj::Arr<T>  // a function parameter that is `T *__restrict__` in the product build
 
 #else  // product build: plain pointers
 
@@ -92,6 +95,7 @@ SJ_HD T *arr_at(T *a, unsigned long long first, unsigned long long) { return a +
 template <typename T>
 SJ_HD T *arr_raw(T *a) { return a; }
 #define SJ_ARR(ptr, count, id) (ptr)
+#define SJ_ARR_PARAM(T) T *__restrict__
 
 #endif
 

@@ -88,6 +88,7 @@ hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap);
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses since the last call (cleared);
 // 0 in the product build.  _selftest: -1 in the product build, else the violations recorded for two deliberate ones
 int stage2_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size);
+int stage1_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size);  // stage1.hip
 int stage2_debug_bounds_selftest();
 
 size_t stage1_workspace_bytes(size_t len);

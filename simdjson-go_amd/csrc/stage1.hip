@@ -26,6 +26,7 @@
 
 #include <type_traits>
 
+#include "sj_bounds.h"
 #include "sj_chunk.h"
 #include "sj_device.h"
 #include "sj_stage2.h"
@@ -35,14 +36,20 @@ namespace sj {
 // optional extra outputs for the whole parse (all null for stage 1 alone): per 64-byte chunk the in-string mask
 // relative to the unit start, the unescaped quotes and the escape starters; per 4 KiB unit the resolved state
 struct S1Aux {
-    u64 *qm, *q, *st;  // null unless every string is copied (byte-parallel unescape)
-    u8 *unit_h;
-    u64 *unit_slow;    // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
-    u8 *kind;          // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
+    // (Arr: sj_bounds.h -- plain pointers in the product build, bounds-checked views under -DSJ_DEBUG_BOUNDS)
+    Arr<u64> qm, q, st;  // null unless every string is copied (byte-parallel unescape)
+    Arr<u8> unit_h;
+    Arr<u64> unit_slow;  // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
+    Arr<u8> kind;        // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
 };
+#if defined(SJ_DEBUG_BOUNDS)
+#define S1_POS_VIEW(out_pos, cap) Arr<u32>((out_pos), (cap), A_S1_POS)
+#else
+#define S1_POS_VIEW(out_pos, cap) (out_pos)
+#endif
 #if defined(SJ_EXP)
 #define SJ_S1EXP(a, b) ((((a).exp >> (b)) & 1u) != 0)
 #else
@@ -465,8 +472,8 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 // configs[4], whose 78 M tokens are one gather each.)
 template <int BLOCK, int CH, bool KIND>
 __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
-                                             u64 lead, int lane, int wave, u32 *__restrict__ out_pos, u64 pos_cap,
-                                             u64 &tile_end, u8 *unit_h, u64 len_, u8 *kind_out) {
+                                             u64 lead, int lane, int wave, SJ_ARR_PARAM(u32) out_pos, u64 pos_cap,
+                                             u64 &tile_end, Arr<u8> unit_h, u64 len_, Arr<u8> kind_out) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // the window that held the masks (CH * 2 * 64 u64) stages the positions of a unit: 32-bit positions, or (KIND)
@@ -527,8 +534,8 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
                 for (u32 i = (u32)lane * 4u; i < c4; i += 256u) {
                     const uint2 e2 = *reinterpret_cast<const uint2 *>(stage + i);
                     const u32 e0 = e2.x & 0xffffu, e1 = e2.x >> 16, e3 = e2.y >> 16, e2v = e2.y & 0xffffu;
-                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = make_uint4(ubase + e0, ubase + e1, ubase + e2v, ubase + e3);
-                    *reinterpret_cast<u32 *>(kind_out + gd + i) = kind_of(e0) | (kind_of(e1) << 8) | (kind_of(e2v) << 16) | (kind_of(e3) << 24);
+                    *reinterpret_cast<uint4 *>(arr_at(out_pos, gd + i, 4)) = make_uint4(ubase + e0, ubase + e1, ubase + e2v, ubase + e3);
+                    *reinterpret_cast<u32 *>(arr_at(kind_out, gd + i, 4)) = kind_of(e0) | (kind_of(e1) << 8) | (kind_of(e2v) << 16) | (kind_of(e3) << 24);
                 }
                 for (u32 i = c4 + (u32)lane; i < cnt; i += 64) {  // the last <= 3 (or, without room for all, everything)
                     if (fits || gd + i < pos_cap) {
@@ -541,7 +548,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
                 // 16 bytes per lane (the positions are only 4-byte aligned in memory: fine on gfx950), then the rest
                 const u32 c4 = cnt & ~3u;
                 for (u32 i = (u32)lane * 4u; i < c4; i += 256u)
-                    *reinterpret_cast<uint4 *>(out_pos + gd + i) = *reinterpret_cast<const uint4 *>(stage + i);
+                    *reinterpret_cast<uint4 *>(arr_at(out_pos, gd + i, 4)) = *reinterpret_cast<const uint4 *>(stage + i);
                 if (c4 + (u32)lane < cnt) out_pos[gd + c4 + lane] = (u32)stage[c4 + lane];
             } else {
                 for (u32 i = lane; i < cnt; i += 64)
@@ -717,7 +724,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
             u64 tile_end = 0;
             err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_kpl[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
-                                           out_pos, pos_cap, tile_end, AUX ? aux.unit_h : nullptr, len, AUX ? aux.kind : nullptr);
+                                           S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, AUX ? aux.unit_h : Arr<u8>(nullptr), len,
+                                           AUX ? aux.kind : Arr<u8>(nullptr));
             if (t_prev == num_tiles - 1 && tid == 0)
                 __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
@@ -956,7 +964,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, false>(tm, s_mask[mf][wave], nullptr, s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
-                                              wave, out_pos, pos_cap, tile_end, nullptr, len, nullptr);
+                                              wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr));
         if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
@@ -1098,17 +1106,21 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
     const u32 nd = (u32)(ndjson != 0);
-    S1Aux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, d_kind, reinterpret_cast<u64 *>(d_trace), h_state, 0u};
+    S1Aux aux = {};
+    aux.kind = nullptr;
+    if (d_kind) aux.kind = SJ_ARR(d_kind, pos_cap, A_S1_KIND);
+    aux.trace = reinterpret_cast<u64 *>(d_trace);
+    aux.host = h_state;
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) aux.exp = (u32)strtoul(e, nullptr, 0);
 #endif
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
-        aux.qm = a.qm;
-        aux.q = a.q;
-        aux.st = a.st;
-        aux.unit_h = a.unit_h;
-        aux.unit_slow = a.unit_slow;
+        aux.qm = SJ_ARR(a.qm, a.chunks, A_S1_QM);
+        aux.q = SJ_ARR(a.q, a.chunks, A_S1_Q);
+        aux.st = SJ_ARR(a.st, a.chunks, A_S1_ST);
+        aux.unit_h = SJ_ARR(a.unit_h, a.units, A_S1_UNIT_H);
+        aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
@@ -1161,6 +1173,28 @@ hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, 
     hipError_t e = stage1_prepare(d_msg, len, ws, stream, zero2, zero2_bytes);
     if (e != hipSuccess) return e;
     return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
+}
+
+// debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses of the stage-1 kernels since the
+// last call (cleared); 0 in the product build
+int stage1_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size) {
+    *hits = *id = 0;
+    *index = *size = 0;
+#if defined(SJ_DEBUG_BOUNDS)
+    BoundsHit h = {};
+    if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_bounds_hit), sizeof h) != hipSuccess) return 1;
+    if (h.hits) {
+        const BoundsHit zero = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_hit), &zero, sizeof zero);
+    }
+    *hits = h.hits;
+    *id = h.id;
+    *index = h.index;
+    *size = h.size;
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 }  // namespace sj
