@@ -60,6 +60,13 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx);
 const char *sjhip_last_error(const sjhip_ctx *ctx);
 /* run the context's work on an existing HIP stream (e.g. torch's current stream); NULL = own stream */
 int sjhip_ctx_set_stream(sjhip_ctx *ctx, void *hip_stream);
+/* A context's arenas only grow (they are the capacity a recycled `reuse *ParsedJson` carries, simdjson_amd64.go:46-51),
+ * sized by the largest message it has parsed.  sjhip_ctx_device_bytes reports what it holds on the device right now;
+ * sjhip_ctx_trim gives all of it back (device arenas, the pinned result blocks, the contexts of a sharded ND parse) and
+ * drops the resident result -- a pool calls it on a context that has just parsed an unusually large message.  The
+ * next parse allocates what it needs. */
+size_t sjhip_ctx_device_bytes(const sjhip_ctx *ctx);
+int sjhip_ctx_trim(sjhip_ctx *ctx);
 
 /* ---- whole parse: replaces parseMessage (parse_json_amd64.go:52-127) ------------------------
  * msg is a HOST buffer.  The library applies bytes.TrimSpace (parse_json_amd64.go:55) and reports

@@ -87,13 +87,53 @@ sjhip_ctx *sjhip_ctx_create(int device) {
     return ctx;
 }
 
+// every device arena of a context
+#define SJ_CTX_ARENAS(ctx)                                                                                                   \
+    {&(ctx)->d_msg, &(ctx)->d_pos, &(ctx)->d_ws, &(ctx)->d_kat, &(ctx)->d_tape, &(ctx)->d_strings, &(ctx)->d_s2, &(ctx)->d_s2z, \
+     &(ctx)->d_aux, &(ctx)->d_scol, &(ctx)->d_stab, &(ctx)->d_q, &(ctx)->d_qtape, &(ctx)->d_qstrings, &(ctx)->d_strtmp,       \
+     &(ctx)->d_keyflag}
+
+size_t sjhip_ctx_device_bytes(const sjhip_ctx *ctx) {
+    if (!ctx) return 0;
+    const DevBuf *bufs[] = SJ_CTX_ARENAS(ctx);
+    size_t total = 0;
+    for (const DevBuf *b : bufs) total += b->cap;
+    return total + sj::nd_big_device_bytes(ctx);
+}
+
+static void invalidate_result(sjhip_ctx *ctx);
+
+int sjhip_ctx_trim(sjhip_ctx *ctx) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return ctx_hip_fail(ctx, hipGetLastError(), "sjhip_ctx_trim");
+    invalidate_result(ctx);
+    ctx->kf_valid = 0;
+    ctx->tape_len = ctx->strings_len = 0;
+    DevBuf *bufs[] = SJ_CTX_ARENAS(ctx);
+    for (DevBuf *b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    ctx->p_kind = nullptr;
+    ctx->p_aux = nullptr;
+    ctx->p_msg = nullptr;
+    sj::release_nd_big(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    if (ctx->h_view) (void)hipHostFree(ctx->h_view);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_pack = ctx->h_view = ctx->h_stage = nullptr;
+    ctx->h_view_cap = ctx->h_stage_cap = 0;
+    return SJHIP_OK;
+}
+
 void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_msg, &ctx->d_pos, &ctx->d_ws, &ctx->d_kat, &ctx->d_tape, &ctx->d_strings,
-                      &ctx->d_s2,  &ctx->d_s2z, &ctx->d_aux,  &ctx->d_scol, &ctx->d_stab,  &ctx->d_q,   &ctx->d_qtape, &ctx->d_qstrings, &ctx->d_strtmp,
-                      &ctx->d_keyflag};
+    DevBuf *bufs[] = SJ_CTX_ARENAS(ctx);
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     sj::release_nd_big(ctx);

@@ -310,6 +310,13 @@ int sj::fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst) {
     (void)hipSetDevice(ctx->device);
     return rc;
 }
+size_t sj::nd_big_device_bytes(const sjhip_ctx *ctx) {
+    size_t total = 0;
+    if (ctx->big)
+        for (const Shard &s : ctx->big->shards) total += sjhip_ctx_device_bytes(s.ctx);
+    return total;
+}
+
 void sj::release_nd_big(sjhip_ctx *ctx) {
     if (ctx->big) sjhip_multi_destroy(ctx->big);
     ctx->big = nullptr;

@@ -82,6 +82,7 @@ int parse_nd_big(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags,
                  size_t *tape_len, size_t *strings_len, size_t *msg_off, size_t *msg_len);  // multi_api.hip
 int fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 void release_nd_big(sjhip_ctx *ctx);
+size_t nd_big_device_bytes(const sjhip_ctx *ctx);  // arenas of the shard contexts of a sharded ND parse
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                    uint8_t *d_kind, void *zero2, size_t zero2_bytes);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);

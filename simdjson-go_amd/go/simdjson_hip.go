@@ -159,8 +159,16 @@ func (pj *internalParsedJson) parseMessageHip(msg []byte, ndjson bool) error {
 	if rc := C.sjhip_fetch(c.h, tp, sp); rc != C.SJHIP_OK {
 		return fmt.Errorf("sjhip: %s", C.GoString(C.sjhip_last_error(c.h)))
 	}
+	// a pooled context keeps arenas sized for the largest message it has seen: give them back after an unusual one
+	if uint64(C.sjhip_ctx_device_bytes(c.h)) > PoolTrimBytes {
+		C.sjhip_ctx_trim(c.h)
+	}
 	return nil
 }
+
+// PoolTrimBytes: device memory a pooled context may keep between parses (its arenas are ~13-20x the largest message
+// it has parsed, INTEGRATION.md section 3c); beyond it the context is trimmed before it goes back to the pool.
+var PoolTrimBytes uint64 = 16 << 30
 
 // ParseBatch parses many documents with one launch set (sjhip_parse_batch): the returned ParsedJson holds document i
 // as root i -- iterate with pj.Iter() / Advance() as over a ParseND result.  It replaces the goroutine-per-Parse shape

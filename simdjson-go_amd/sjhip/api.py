@@ -67,6 +67,14 @@ class Context:
     def last_error(self) -> str:
         return _lib.lib().sjhip_last_error(self._h).decode()
 
+    def device_bytes(self) -> int:
+        """bytes of device memory the context's arenas hold right now (they only grow; see trim)"""
+        return int(_lib.lib().sjhip_ctx_device_bytes(self._h))
+
+    def trim(self):
+        """give every arena back (after an unusually large message); the next parse allocates what it needs"""
+        self._check(_lib.lib().sjhip_ctx_trim(self._h))
+
     def set_stream(self, stream_ptr):
         _lib.lib().sjhip_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0))
 

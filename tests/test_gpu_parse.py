@@ -692,3 +692,43 @@ def test_strings_on_chunk_and_unit_boundaries(ctx):
     # all of them as one ND message, and inside one large array (many tiles, unaligned starts)
     check(ctx, b"\n".join(d for _, d in docs), True, "boundaries/nd")
     check(ctx, b"[" + b",".join(d for _, d in docs) + b"]", False, "boundaries/array")
+
+
+def test_trim_gives_the_arenas_back_and_the_context_keeps_working():
+    """sjhip_ctx_device_bytes / sjhip_ctx_trim: a context that has parsed a large message holds arenas sized for it; trim
+    frees them (and drops the resident result: queries and fetches of it are refused or empty), the next parses -- small
+    and large, every entry point -- allocate again and give the oracle's result."""
+    import sjhip
+    c = sjhip.Context(0)
+    assert c.device_bytes() == 0
+    small = fixtures.load("twitter")
+    big = fixtures.load("parking-citations") * 40  # 15 MB: the synchronous path
+    ref_small, ref_big = O.parse(small), O.parse(big, ndjson=True)
+    pj = c.parse(small)
+    assert np.array_equal(pj.Tape, ref_small.tape)
+    b_small = c.device_bytes()
+    assert 0 < b_small < 100 << 20
+    pj = c.parse(big, ndjson=True, view=True, key_flags=True)
+    assert np.array_equal(pj.Tape, ref_big.tape) and np.array_equal(pj.Strings, ref_big.strings)
+    b_big = c.device_bytes()
+    assert b_big > 10 * len(big)
+    c.trim()
+    assert c.device_bytes() == 0
+    with pytest.raises(sjhip.ParseError):
+        c.marshal_json()  # no resident result any more
+    for _ in range(2):
+        pj = c.parse(small, view=True)
+        assert np.array_equal(pj.Tape, ref_small.tape) and np.array_equal(pj.Strings, ref_small.strings)
+        assert c.device_bytes() <= b_small
+        c.trim()
+    pj = c.parse(big, ndjson=True, copy_strings=False)
+    ref_nc = O.parse(big, ndjson=True, copy_strings=False)
+    assert np.array_equal(pj.Tape, ref_nc.tape) and np.array_equal(pj.Strings, ref_nc.strings)
+    assert c.count_where(b"Make", b"HOND") == 116 * 40
+    ok, pos = c.stage1(small)
+    assert ok
+    n1 = int(pos.size)
+    c.trim()
+    ok, pos = c.stage1(small)
+    assert ok and int(pos.size) == n1
+    c.close()
