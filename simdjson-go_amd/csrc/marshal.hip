@@ -51,6 +51,11 @@ struct MsView {
     u32 *slen;                   // [tiles][1024] escaped length of the tile's k-th string (counting pass -> writing pass)
     const u8 *strings_end, *msg_end;  // ends of the buffers the strings live in (8-byte loads stop there)
     u8 *text;
+    // the single-pass form (k_ms_tile<2>): one descriptor per tile (0: nothing yet, MS_DESC_AGG | size, MS_DESC_PREFIX | size of
+    // everything up to and including the tile), the ticket counter that numbers the tiles, the capacity of `text`
+    unsigned long long *desc;
+    u32 *ticket;
+    u64 text_cap;
 };
 
 struct KeyView {
@@ -132,6 +137,45 @@ __global__ __launch_bounds__(1024) void k_ms_scan(unsigned long long *a, unsigne
     }
 }
 
+// ---- descriptors of the single-pass form: status in the two top bits, a byte count below -----------------------------
+static constexpr u64 MS_DESC_AGG = 1ull << 62, MS_DESC_PREFIX = 2ull << 62, MS_DESC_VALUE = (1ull << 62) - 1;
+__device__ __forceinline__ u64 ms_desc_load(const unsigned long long *d) {
+    return __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ms_desc_store(unsigned long long *d, u64 v) {
+    __hip_atomic_store(d, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One wave: publishes the tile's own size, sums the sizes of the tiles in front of it (64 descriptors per step, nearest
+// first, up to the nearest one that already holds a prefix), publishes the tile's prefix and returns the sum.  Tiles are
+// numbered by a ticket, so every tile in front is running or finished and publishes its size without waiting for anyone.
+__device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u64 own, int lane) {
+    if (lane == 0 && tile != 0) ms_desc_store(&desc[tile], MS_DESC_AGG | own);
+    u64 sum = 0;
+    long long j = (long long)tile - 1;
+    u32 spins = 0;
+    while (j >= 0) {  // (wave-uniform)
+        const long long idx = j - lane;
+        const u64 d = idx >= 0 ? ms_desc_load(&desc[idx]) : MS_DESC_PREFIX;  // in front of tile 0: nothing
+        const u32 st = (u32)(d >> 62);
+        const u64 m_pre = __ballot(st == 2), m_inv = __ballot(st == 0);
+        const int first_pre = m_pre ? (int)__builtin_ctzll(m_pre) : 64;
+        const int first_inv = m_inv ? (int)__builtin_ctzll(m_inv) : 64;
+        if (first_inv < first_pre) {  // a nearer tile has not published yet
+            if (++spins > (1u << 22)) break;  // (never: a bounded loop instead of a hang; the host sees a short text)
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        u64 v = lane <= first_pre ? (d & MS_DESC_VALUE) : 0ull;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += (u64)__shfl_xor((long long)v, sft, 64);
+        sum += v;
+        if (first_pre < 64) break;
+        j -= 64;
+    }
+    if (lane == 0) ms_desc_store(&desc[tile], MS_DESC_PREFIX | (sum + own));
+    return sum;
+}
+
 // ---- the tape pass: EMIT = false lengths, EMIT = true text ---------------------------------------------------------
 // A tile is 2048 tape words.  The entries of a tile are SORTED BY KIND into LDS queues and each queue is worked on with
 // the lanes packed densely (the first version let every thread walk its own eight words: under divergence a wave ran the
@@ -191,8 +235,13 @@ __device__ __forceinline__ u8 *write_esc8(u8 *o, u64 w, u32 valid) {
 }
 
 // WPE: waves per SIMD the register allocation aims at (launch bound), WINDOW: bytes of text a tile stages in LDS
-template <bool EMIT, int WPE, u32 WINDOW>
+// MODE 0: the counting pass (per-tile sizes; escaped lengths of the strings kept in slen), MODE 1: the writing pass of that
+// pair (sizes scanned by k_ms_scan in between), MODE 2: both in ONE pass -- a tile measures, publishes its size in a
+// descriptor, takes the sum of the tiles in front of it from their descriptors (decoupled look-back, tiles numbered by a
+// ticket so that every predecessor is running or done) and writes; the text buffer is sized by a bound (ms_text_bound).
+template <int MODE, int WPE, u32 WINDOW>
 __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
+    constexpr bool EMIT = MODE != 0, ONEPASS = MODE == 2;
     __shared__ long long s_l[TW_THREADS / 64];
     __shared__ unsigned long long s_s[TW_THREADS / 64];
     __shared__ u32 s_len[TW_TILE];   // per word: text bytes of the entry that starts there (0: none); writing pass: then its offset
@@ -202,7 +251,13 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     __shared__ u32 s_qn[MS_QCAP];    // numbers: integers from the front, floats from the back; idx | sep << 11
     __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? WINDOW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 tb = (u64)blockIdx.x * TW_TILE;
+    __shared__ u32 s_tile;
+    if (ONEPASS) {
+        if (tid == 0) s_tile = atomicAdd(p.ticket, 1u);
+        __syncthreads();
+    }
+    const u32 tile = ONEPASS ? s_tile : blockIdx.x;
+    const u64 tb = (u64)tile * TW_TILE;
     const u64 base = tb + (u64)tid * TW_ITEMS;
     u64 w[TW_ITEMS + 2];  // the thread's words and the two behind them (an entry's second word, the next entry's tag)
     if (base + TW_ITEMS + 2 <= p.n) {  // five 16-byte loads (the tape arena is 256-byte aligned, base a multiple of 8 words)
@@ -225,7 +280,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     // tape -- the closest of the 64 words in front of the tile that is not a two-word tag; a tile that finds none
     // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
     __shared__ long long s_carry;
-    const long long carry = p.tile_last ? p.tile_last[blockIdx.x] : tw_local_anchor(p.tape, tb, tid, &s_carry);
+    const long long carry = p.tile_last ? p.tile_last[tile] : tw_local_anchor(p.tape, tb, tid, &s_carry);
     // queue slots are drawn with LDS atomics, in whatever order the lanes arrive.  (Slots in document order from one packed
     // block scan -- no atomics, adjacent lanes on adjacent strings -- were measured twice: configs[4] 2.01 instead of
     // 1.75 ms, configs[1] 1.32 instead of 1.34, tools/gpu_ab_marshal.sh.)
@@ -235,7 +290,8 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
         if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
             atomicOr(&p.totals[2], 4ull);
-            if (!EMIT) p.cnt_b[blockIdx.x] = p.cnt_s[blockIdx.x] = 0;
+            if (!EMIT) p.cnt_b[tile] = p.cnt_s[tile] = 0;
+            if (ONEPASS) ms_desc_store(&p.desc[tile], MS_DESC_AGG);  // (no text: the tiles behind it must not wait for it)
         }
         return;
     }
@@ -264,7 +320,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     unsigned long long tot_s = 0;
     u32 ord = (u32)block_excl_sum(nstr, s_s, tid, &tot_s);  // ordinal of the thread's first string inside the tile
-    const u64 slen_base = (u64)blockIdx.x * MS_QCAP;
+    const u64 slen_base = (u64)tile * MS_QCAP;
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++) {
         const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
@@ -278,7 +334,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 const u64 inbuf = (v & STRINGBUFBIT) ? 1u : 0u;
                 s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) |
                              ((inbuf ? (v & (STRINGBUFBIT - 1)) : v) << 32);
-                l = 2 + sep + (EMIT ? p.slen[slen_base + ord] : 0u);
+                l = 2 + sep + (MODE == 1 ? p.slen[slen_base + ord] : 0u);
                 ord++;
             } else if (t == 'l' || t == 'u') {
                 s_qn[atomicAdd(&s_cnt[2], 1u)] = idx | (sep << 11);
@@ -319,7 +375,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         if (nl == 0) bad = true;  // Inf / NaN: "INF or NaN number found"
         s_len[idx] += nl;
     }
-    if (!EMIT) {
+    if (MODE != 1) {
         for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
             const u64 e64 = s_qs[j];
             const u32 e = (u32)e64, idx = e & 0x7ffu;
@@ -330,7 +386,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             u32 el = 0;
             for (u64 q = 0; q < len; q += 8) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
             s_len[idx] += el;
-            p.slen[slen_base + ((e >> 11) & 0x3ffu)] = el;
+            if (MODE == 0) p.slen[slen_base + ((e >> 11) & 0x3ffu)] = el;
         }
         for (u32 j = (u32)wave; j < n_long; j += TW_THREADS / 64) {  // one wave per long string
             const u64 e64 = s_qs[MS_QCAP - 1 - j];
@@ -346,7 +402,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             if (el > 0xfffffff0ull) toobig = true;  // (a single string of more than 4 GiB of text)
             if (lane == 0) {
                 s_len[idx] += (u32)el;
-                p.slen[slen_base + ((e >> 11) & 0x3ffu)] = (u32)el;
+                if (MODE == 0) p.slen[slen_base + ((e >> 11) & 0x3ffu)] = (u32)el;
             }
         }
     }
@@ -361,19 +417,36 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     if (tot > 0xfffffff0ull) toobig = true;  // entry offsets inside a tile are 32-bit
     if (!EMIT) {
         if (tid == 0) {
-            p.cnt_b[blockIdx.x] = tot;
-            p.cnt_s[blockIdx.x] = tot_s;
+            p.cnt_b[tile] = tot;
+            p.cnt_s[tile] = tot_s;
         }
         if (bad) atomicOr(&p.totals[2], 1ull);
         if (toobig) atomicOr(&p.totals[2], 2ull);
         return;
+    }
+    // one pass: where the tile's text starts = the sizes of all tiles in front of it, from their descriptors
+    __shared__ unsigned long long s_off;
+    if (ONEPASS) {
+        if (bad) atomicOr(&p.totals[2], 1ull);
+        const bool big = __syncthreads_or(toobig ? 1 : 0) != 0;  // (also: every wave is behind its last use of s_s)
+        if (big && tid == 0) atomicOr(&p.totals[2], 2ull);
+        if (wave == 0) {
+            const unsigned long long off = ms_lookback(p.desc, tile, big ? 0ull : tot, lane);
+            if (lane == 0) {
+                s_off = off;
+                if ((u64)tile + 1 == p.tiles) p.totals[0] = off + (big ? 0ull : tot);  // the length of the whole text
+                if (!big && off + tot > p.text_cap) atomicOr(&p.totals[2], 8ull);       // the bound did not hold: two passes
+            }
+        }
+        __syncthreads();
+        if (big || s_off + tot > p.text_cap) return;  // (block-uniform) nothing is written; the host reports / repeats
     }
     // The text of a tile is one contiguous range.  When it fits the window the block writes it into LDS (byte stores
     // that cost a fraction of scattered global ones) and copies the window out with coalesced 4-byte stores; a tile
     // with more text (long strings) writes straight to memory.
     const u64 tile_bytes = tot;
     const bool staged = tile_bytes <= WINDOW;  // block-uniform
-    u8 *const gdst = p.text + p.cnt_b[blockIdx.x];
+    u8 *const gdst = p.text + (ONEPASS ? s_off : p.cnt_b[tile]);
     u8 *const tbase = staged ? s_text : gdst;
     {
         u32 run = (u32)ex;
@@ -424,7 +497,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         for (u32 q = 0; q < nl; q++) o[q] = tmp[q];
         if ((e >> 11) & 1u) o[nl] = ',';
     }
-    const u64 key_base = p.kf_tape ? 0 : p.cnt_s[blockIdx.x];
+    const u64 key_base = p.kf_tape ? 0 : p.cnt_s[tile];
     for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
         const u64 e64 = s_qs[j];
         const u32 e = (u32)e64, idx = e & 0x7ffu;
@@ -493,14 +566,21 @@ static int ms_variant() {
 // 1.54 ms, (6, 32 KiB) 1.93 / 1.47, (6, 16 KiB) 1.74 / 1.32, (6 -- 8 is not reachable with this much LDS --, 8 KiB) 1.80 / 1.38:
 // a tile of parking-citations is 9.5 KB of text, one of twitter.json 19 KB; four blocks per CU instead of three in the
 // writing pass pay for the tiles that no longer fit the window.
-template <bool EMIT>
+static int ms_onepass() {  // SJHIP_MS_ONEPASS=0: always the two-pass form
+    static const int v = [] {
+        const char *e = getenv("SJHIP_MS_ONEPASS");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+template <int MODE>
 static void launch_ms_tile(const MsView &p, hipStream_t st) {
     const dim3 g(p.tiles), b(TW_THREADS);
     switch (ms_variant()) {
-        case 0: hipLaunchKernelGGL((k_ms_tile<EMIT, 4, MS_WINDOW>), g, b, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW>), g, b, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ms_tile<EMIT, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
+        case 0: hipLaunchKernelGGL((k_ms_tile<MODE, 4, MS_WINDOW>), g, b, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW>), g, b, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
     }
 }
 }  // namespace
@@ -531,7 +611,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     kv.tiles = (kv.n + 4095u) / 4096u;
     const size_t per = ((size_t)p.tiles * 8 + 255) / 256 * 256, perk = ((size_t)kv.tiles * 8 + 255) / 256 * 256;
     const size_t flags = ((size_t)kv.n + 255) / 256 * 256;
-    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 3 + perk + flags + (size_t)p.tiles * MS_QCAP * 4 + 256);
+    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 4 + 256 + perk + flags + (size_t)p.tiles * MS_QCAP * 4 + 256);
     if (rc) return rc;
     char *w = (char *)ctx->d_q.p;
     p.totals = (unsigned long long *)w;
@@ -542,6 +622,10 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     w += per;
     p.cnt_s = (unsigned long long *)w;
     w += per;
+    p.desc = (unsigned long long *)w;
+    w += per;
+    p.ticket = (u32 *)w;
+    w += 256;
     kv.cnt = (unsigned long long *)w;
     w += perk;
     kv.keyflag = (u8 *)w;
@@ -549,6 +633,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     p.keyflag = kv.keyflag;
     p.slen = (u32 *)w;
     p.text = nullptr;
+    p.text_cap = 0;
     HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
     // keys: the flags the parser left (SJHIP_FLAG_KEY_FLAGS), or from the token array of the parse (three launches)
     p.kf_tape = (ctx->kf_valid && ctx->q_valid) ? (const u8 *)ctx->d_keyflag.p : nullptr;
@@ -558,9 +643,45 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
                            (unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
     }
-    // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
     long long *const tile_last = p.tile_last;
     unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
+    // With the key flags at hand, ONE pass over the tape (k_ms_tile<2>): the text buffer is sized by a bound instead of by a
+    // counting pass.  The text of an entry is never longer than its source, except a number's: "1e20" prints as 21
+    // digits (appendFloat leaves exponent form only from 1e21 on), 17 bytes more -- strings come out as they went in or
+    // shorter (a raw control character is a stage-1 error, every escape the writer produces is at most as long as the
+    // one the parser consumed), literals and brackets as they are, separators are a subset of the source's.  A tile that
+    // would write past the bound (it cannot) or that finds no anchor raises a flag and the two-pass form below runs.
+    if (p.kf_tape && ms_onepass()) {
+        size_t bound = ctx->p_len + 20 * (p.n / 2 + 1) + 64;
+        if (const char *e = getenv("SJHIP_MS_TEST_BOUND")) bound = (size_t)strtoull(e, nullptr, 0);  // tests: make the bound fail
+        rc = arena_reserve(ctx, ctx->d_qtape, bound + 64);
+        if (rc) return rc;
+        p.tile_last = nullptr;
+        p.text = (u8 *)ctx->d_qtape.p;
+        p.text_cap = bound;
+        HIPCHK(hipMemsetAsync(p.desc, 0, per + 256, ctx->stream), "marshal memset (descriptors)");  // (and the ticket behind them)
+        launch_ms_tile<2>(p, ctx->stream);
+        HIPCHK(hipGetLastError(), "marshal launch (one pass)");
+        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
+        if (!(h[2] & (4ull | 8ull))) {
+            if (h[2] & 1ull) {
+                ctx_set_error(ctx, "INF or NaN number found");  // the reference's error (parsed_json.go:1252)
+                return SJHIP_ERR_ARG;
+            }
+            if (h[2] & 2ull) {
+                ctx_set_error(ctx, "MarshalJSON: 2048 consecutive tape words produce more than 4 GiB of text");
+                return SJHIP_ERR_TOOBIG;
+            }
+            ctx->ms_len = (size_t)h[0];
+            ctx->ms_valid = 1;
+            if (text_len) *text_len = ctx->ms_len;
+            return SJHIP_OK;
+        }
+        HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
+        p.text = nullptr;
+    }
+    // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
     for (int attempt = 0; attempt < 2; attempt++) {
         if (attempt == 0) {
             p.tile_last = nullptr;
@@ -570,7 +691,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
             hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
             hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
         }
-        launch_ms_tile<false>(p, ctx->stream);
+        launch_ms_tile<0>(p, ctx->stream);
         // (the prefix of the string counts is only needed to index the recovered key flags)
         hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.kf_tape ? (unsigned long long *)nullptr : p.cnt_s,
                            p.tiles, p.totals);
@@ -590,7 +711,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     rc = arena_reserve(ctx, ctx->d_qtape, (size_t)h[0] + 64);
     if (rc) return rc;
     p.text = (u8 *)ctx->d_qtape.p;
-    launch_ms_tile<true>(p, ctx->stream);
+    launch_ms_tile<1>(p, ctx->stream);
     HIPCHK(hipGetLastError(), "marshal emit launch");
     ctx->ms_len = (size_t)h[0];
     ctx->ms_valid = 1;

@@ -128,3 +128,44 @@ def test_key_flags_on_every_parse_path(ctx):
     ctx.parse(b'{"a":"b","c":["d",{"e":"f"}]}', key_flags=True)
     ctx.parse(b'["a","b",{"c":"d"},"e"]')
     assert ctx.marshal_json() == b'["a","b",{"c":"d"},"e"]'
+
+
+@pytest.mark.parametrize("env", [{"SJHIP_MS_TEST_BOUND": "4096"}, {"SJHIP_MS_ONEPASS": "0"}, {"SJHIP_MS_VARIANT": "0"},
+                                 {"SJHIP_MS_VARIANT": "4"}])
+def test_one_pass_fallbacks_and_variants(env):
+    """The single-pass MarshalJSON (key flags from the parser, text buffer sized by a bound) must fall back to the two-pass
+    form when a tile would write past the bound (forced here with a bound of 4 KiB) and give the same text with the
+    single pass turned off and with the other shapes of the tile kernel; the variables are read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, 'simdjson-go_amd'); sys.path.insert(0, 'tests')
+import fixtures, sjhip, oracle_lib as O, workloads
+ctx = sjhip.Context(0)
+docs = [(fixtures.load(n), n == 'parking-citations') for n in ('twitter', 'twitterescaped', 'canada', 'parking-citations', 'mesh.pretty')]
+docs.append((workloads.c5_parking_nd(30), True))
+docs.append((b'[' + b','.join([b'1e20', b'-1e20', b'1E+20', b'123456789e12'] * 3000) + b']', False))  # numbers that print longer
+for d, nd in docs:
+    ref = O.parse(d, ndjson=nd)
+    rc, want = O.marshal_json(ref.tape, ref.strings, d[ref.msg_off:ref.msg_off + ref.msg_len])
+    assert ref.rc == 0 and rc == 0
+    for kf in (True, False):
+        ctx.parse(d, ndjson=nd, key_flags=kf)
+        assert ctx.marshal_json() == want, (len(d), nd, kf)
+print('ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_numbers_that_print_longer_than_their_source(ctx):
+    """The bound of the single-pass text buffer rests on: only numbers print longer than they were written, by at most 17
+    bytes ("1e20" -> 21 digits).  Documents made of nothing but such numbers stay inside it and give the oracle's text."""
+    worst = ["1e20", "-1e20", "1E20", "9e20", "1e19", "-9.9e20", "1e-7", "2e-6", "1e300", "5e-324", "0e0", "-0.0", "1E+2", "1e0"]
+    doc = ("[" + ",".join(worst * 6000) + "]").encode()
+    check_marshal(ctx, doc, False, "expanding numbers")
+    nd = "\n".join("[" + ",".join(worst[(i + j) % len(worst)] for j in range(9)) + "]" for i in range(20000)).encode()
+    check_marshal(ctx, nd, True, "expanding numbers, nd")
