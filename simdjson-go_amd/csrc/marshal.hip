@@ -148,8 +148,8 @@ __device__ __forceinline__ void ms_desc_store(unsigned long long *d, u64 v) {
 // One wave: publishes the tile's own size, sums the sizes of the tiles in front of it (64 descriptors per step, nearest
 // first, up to the nearest one that already holds a prefix), publishes the tile's prefix and returns the sum.  Tiles are
 // numbered by a ticket, so every tile in front is running or finished and publishes its size without waiting for anyone.
+// (the tile's own size has been published before: ms_desc_store(&desc[tile], MS_DESC_AGG | own), as early as it is known)
 __device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u64 own, int lane) {
-    if (lane == 0 && tile != 0) ms_desc_store(&desc[tile], MS_DESC_AGG | own);
     u64 sum = 0;
     long long j = (long long)tile - 1;
     u32 spins = 0;
@@ -424,29 +424,42 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         if (toobig) atomicOr(&p.totals[2], 2ull);
         return;
     }
-    // one pass: where the tile's text starts = the sizes of all tiles in front of it, from their descriptors
+    // One pass: where the tile's text starts = the sizes of all tiles in front of it, from their descriptors.  The tile's own
+    // size is published at once; the sum is only needed when bytes leave the block -- behind all the writing for a tile
+    // that assembles its text in the LDS window (by then the tiles in front have published theirs: nothing to wait for),
+    // in front of it for a tile that writes straight to memory.
     __shared__ unsigned long long s_off;
-    if (ONEPASS) {
-        if (bad) atomicOr(&p.totals[2], 1ull);
-        const bool big = __syncthreads_or(toobig ? 1 : 0) != 0;  // (also: every wave is behind its last use of s_s)
-        if (big && tid == 0) atomicOr(&p.totals[2], 2ull);
+    const u64 tile_bytes = tot;
+    const bool staged = tile_bytes <= WINDOW;  // block-uniform
+    auto resolve = [&]() -> bool {  // block-uniform; false: nothing may be written
         if (wave == 0) {
-            const unsigned long long off = ms_lookback(p.desc, tile, big ? 0ull : tot, lane);
+            const unsigned long long off = ms_lookback(p.desc, tile, tot, lane);
             if (lane == 0) {
                 s_off = off;
-                if ((u64)tile + 1 == p.tiles) p.totals[0] = off + (big ? 0ull : tot);  // the length of the whole text
-                if (!big && off + tot > p.text_cap) atomicOr(&p.totals[2], 8ull);       // the bound did not hold: two passes
+                if ((u64)tile + 1 == p.tiles) p.totals[0] = off + tot;           // the length of the whole text
+                if (off + tot > p.text_cap) atomicOr(&p.totals[2], 8ull);         // the bound did not hold: two passes
             }
         }
         __syncthreads();
-        if (big || s_off + tot > p.text_cap) return;  // (block-uniform) nothing is written; the host reports / repeats
+        return s_off + tot <= p.text_cap;
+    };
+    if (ONEPASS) {
+        if (bad) atomicOr(&p.totals[2], 1ull);
+        const bool big = __syncthreads_or(toobig ? 1 : 0) != 0;  // (also: every wave is behind its last use of s_s)
+        if (big) {  // reported; the tiles behind this one must not wait for it
+            if (tid == 0) {
+                atomicOr(&p.totals[2], 2ull);
+                ms_desc_store(&p.desc[tile], MS_DESC_AGG);
+            }
+            return;
+        }
+        if (tid == 0) ms_desc_store(&p.desc[tile], (tile ? MS_DESC_AGG : MS_DESC_PREFIX) | tot);  // (tile 0 knows its prefix)
+        if (!staged && !resolve()) return;
     }
     // The text of a tile is one contiguous range.  When it fits the window the block writes it into LDS (byte stores
     // that cost a fraction of scattered global ones) and copies the window out with coalesced 4-byte stores; a tile
     // with more text (long strings) writes straight to memory.
-    const u64 tile_bytes = tot;
-    const bool staged = tile_bytes <= WINDOW;  // block-uniform
-    u8 *const gdst = p.text + (ONEPASS ? s_off : p.cnt_b[tile]);
+    u8 *gdst = ONEPASS ? (staged ? nullptr : p.text + s_off) : p.text + p.cnt_b[tile];
     u8 *const tbase = staged ? s_text : gdst;
     {
         u32 run = (u32)ex;
@@ -546,6 +559,10 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     if (staged) {
         __syncthreads();
+        if (ONEPASS) {
+            if (!resolve()) return;
+            gdst = p.text + s_off;
+        }
         const u32 nb = (u32)tile_bytes, nw = nb >> 2;
         for (u32 i = (u32)tid; i < nw; i += TW_THREADS)  // unaligned 4-byte global stores are fine on gfx950
             *reinterpret_cast<u32 *>(gdst + 4 * i) = *reinterpret_cast<const u32 *>(s_text + 4 * i);
