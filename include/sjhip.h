@@ -35,7 +35,8 @@ typedef struct sjhip_ctx sjhip_ctx;
 #define SJHIP_FLAG_COPY_STRINGS 2u
 /* The caller is going to call sjhip_marshal_json on this result: the parse also leaves, on the device, one byte per
  * string entry of the tape saying whether it is an object key (the parser knows: the token behind it is ':'), and
- * MarshalJSON does not have to recover that from the token array (three launches less).  No effect on the result. */
+ * MarshalJSON neither recovers that from the token array (three launches) nor needs its counting pass: it becomes one
+ * pass over the tape (marshal.hip).  No effect on the result of the parse. */
 #define SJHIP_FLAG_KEY_FLAGS 4u
 
 /* return codes */

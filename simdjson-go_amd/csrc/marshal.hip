@@ -2,7 +2,9 @@
 // tape + Strings.B -> compact JSON text, records separated by '\n'.
 //
 // The reference walks the tape with a stack and appends to a byte slice.  Here every tape entry computes the length of
-// its own text, a prefix sum gives every entry its position, and a second pass writes:
+// its own text, a prefix sum gives every entry its position, and the text is written -- in one pass over the tape when
+// the parser left the key flags (per-tile sizes travel through descriptors, k_ms_tile<2>), else in two (counting pass,
+// scan, writing pass):
 //   { [ } ]                 the character
 //   "..."                   '"' + escapeBytes (:1190-1238) + '"'
 //   l / u / d               strconv.AppendInt / AppendUint / appendFloat (sj_ftoa.h: the reference's Ryu copy)
