@@ -151,7 +151,7 @@ __device__ __forceinline__ void ms_desc_store(unsigned long long *d, u64 v) {
 // first, up to the nearest one that already holds a prefix), publishes the tile's prefix and returns the sum.  Tiles are
 // numbered by a ticket, so every tile in front is running or finished and publishes its size without waiting for anyone.
 // (the tile's own size has been published before: ms_desc_store(&desc[tile], MS_DESC_AGG | own), as early as it is known)
-__device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u64 own, int lane) {
+__device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u64 own, int lane, unsigned long long *flags) {
     u64 sum = 0;
     long long j = (long long)tile - 1;
     u32 spins = 0;
@@ -163,7 +163,10 @@ __device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u
         const int first_pre = m_pre ? (int)__builtin_ctzll(m_pre) : 64;
         const int first_inv = m_inv ? (int)__builtin_ctzll(m_inv) : 64;
         if (first_inv < first_pre) {  // a nearer tile has not published yet
-            if (++spins > (1u << 22)) break;  // (never: a bounded loop instead of a hang; the host sees a short text)
+            if (++spins > (1u << 22)) {  // (never: a bounded loop instead of a hang; the host reports an internal error)
+                if (lane == 0) atomicOr(flags, 16ull);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     const bool staged = tile_bytes <= WINDOW;  // block-uniform
     auto resolve = [&]() -> bool {  // block-uniform; false: nothing may be written
         if (wave == 0) {
-            const unsigned long long off = ms_lookback(p.desc, tile, tot, lane);
+            const unsigned long long off = ms_lookback(p.desc, tile, tot, lane, &p.totals[2]);
             if (lane == 0) {
                 s_off = off;
                 if ((u64)tile + 1 == p.tiles) p.totals[0] = off + tot;           // the length of the whole text
@@ -683,6 +686,10 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
         HIPCHK(hipGetLastError(), "marshal launch (one pass)");
         HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
         HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
+        if (h[2] & 16ull) {
+            ctx_set_error(ctx, "MarshalJSON: look-back aborted (internal synchronisation timeout)");
+            return SJHIP_ERR_HIP;
+        }
         if (!(h[2] & (4ull | 8ull))) {
             if (h[2] & 1ull) {
                 ctx_set_error(ctx, "INF or NaN number found");  // the reference's error (parsed_json.go:1252)
