@@ -195,7 +195,7 @@ __device__ __forceinline__ u64 ms_lookback(unsigned long long *desc, u32 tile, u
 //      entry inside the tile's text (s_len turns into offsets), literals and brackets are written right there
 //   4. write, queue by queue, into the tile's LDS window (or straight to memory when the tile's text is larger), then
 //      the block copies the window out with coalesced stores.
-static constexpr u32 MS_WINDOW = 32768;  // bytes of text a tile stages in LDS at most (the launcher picks 16 KiB: 36 KB per block
+static constexpr u32 MS_WINDOW = 32768;  // bytes of text a tile stages in LDS at most (the launcher picks 21 KiB: 39.4 KB per block
                                          // with the queues, 4 blocks per CU)
 static constexpr u32 MS_LONG = 64;       // strings from this length on are measured / written by a whole wave
 static constexpr u32 MS_QCAP = TW_TILE / 2;  // a string or a number takes two words
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     // strings: short ones from the front, long ones from the back; idx | ordinal << 11 | sep << 21 | in Strings.B << 22 |
     // length << 23 (short ones) | offset << 32: a short string needs no second look at the tape
     __shared__ u64 s_qs[MS_QCAP];
-    __shared__ u32 s_qn[MS_QCAP];    // numbers: integers from the front, floats from the back; idx | sep << 11
+    __shared__ uint16_t s_qn[MS_QCAP];  // numbers: integers from the front, floats from the back; idx | sep << 11 (12 bits)
     __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? WINDOW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ u32 s_tile;
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 l = 2 + sep + (MODE == 1 ? p.slen[slen_base + ord] : 0u);
                 ord++;
             } else if (t == 'l' || t == 'u') {
-                s_qn[atomicAdd(&s_cnt[2], 1u)] = idx | (sep << 11);
+                s_qn[atomicAdd(&s_cnt[2], 1u)] = (uint16_t)(idx | (sep << 11));
                 l = sep;
             } else if (t == 'd') {
-                s_qn[MS_QCAP - 1 - atomicAdd(&s_cnt[3], 1u)] = idx | (sep << 11);
+                s_qn[MS_QCAP - 1 - atomicAdd(&s_cnt[3], 1u)] = (uint16_t)(idx | (sep << 11));
                 l = sep;
             } else if (t == 't' || t == 'n') {
                 l = 4 + sep;
@@ -580,14 +580,16 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
 static int ms_variant() {
     static const int v = [] {
         const char *e = getenv("SJHIP_MS_VARIANT");
-        return e ? atoi(e) : 3;
+        return e ? atoi(e) : 6;
     }();
     return v;
 }
 // Measured on configs[4] / configs[1] (tools/gpu_marshal_variants.sh, key flags from the parser): (4 waves, 32 KiB) 1.94 /
 // 1.54 ms, (6, 32 KiB) 1.93 / 1.47, (6, 16 KiB) 1.74 / 1.32, (6 -- 8 is not reachable with this much LDS --, 8 KiB) 1.80 / 1.38:
 // a tile of parking-citations is 9.5 KB of text, one of twitter.json 19 KB; four blocks per CU instead of three in the
-// writing pass pay for the tiles that no longer fit the window.
+// writing pass pay for the tiles that no longer fit the window.  With the single pass (same workloads, 1.30 / 1.28 ms at
+// 16 KiB): 19 KiB 1.30 / 1.17, 21 KiB -- the largest window that leaves four blocks per CU, the number queue holding 16-bit
+// entries -- 1.31 / 1.13: every tile that assembles its text in LDS resolves its offset late and leaves with coalesced stores.
 static int ms_onepass() {  // SJHIP_MS_ONEPASS=0: always the two-pass form
     static const int v = [] {
         const char *e = getenv("SJHIP_MS_ONEPASS");
@@ -601,8 +603,10 @@ static void launch_ms_tile(const MsView &p, hipStream_t st) {
     switch (ms_variant()) {
         case 0: hipLaunchKernelGGL((k_ms_tile<MODE, 4, MS_WINDOW>), g, b, 0, st, p); break;
         case 1: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW>), g, b, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
         case 4: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((k_ms_tile<MODE, 6, 19456u>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ms_tile<MODE, 6, 21504u>), g, b, 0, st, p); break;  // the largest window with four blocks per CU
     }
 }
 }  // namespace
