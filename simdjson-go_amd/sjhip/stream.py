@@ -67,9 +67,17 @@ class Stream:
         if not self._h:
             raise ParseError("sjhip_stream_create failed (no usable device?)", 3)
         self.slots = self._L.sjhip_stream_slots(self._h)
+        self._held = False  # take(view=True): the delivered block has not been released yet
+
+    def release_held(self):
+        """Hands the block of the last take(view=True) back to the stream (its views must not be used any more)."""
+        if self._held and self._h:
+            self._L.sjhip_stream_release(self._h)
+        self._held = False
 
     def close(self):
         if self._h:
+            self.release_held()
             self._L.sjhip_stream_destroy(self._h)
             self._h = None
 
@@ -115,10 +123,13 @@ class Stream:
             raise ParseError(f"sjhip_stream_submit: {rc}", rc)
         return "more" if got == self.block_size else "last"
 
-    def take(self, reuse=None):
+    def take(self, reuse=None, view=False):
         """The oldest outstanding result as a ParsedJson (arrays owned by the caller; `reuse` recycles capacity), or
-        None when nothing is outstanding.  Raises ParseError for the block that ends the stream."""
+        None when nothing is outstanding.  Raises ParseError for the block that ends the stream.
+        `view=True`: no copy out of the stream's pinned memory -- Tape / Strings / Message are read-only views of the
+        block, valid until the next take() (or release_held() / close()), which hands the block back."""
         L = self._L
+        self.release_held()
         r = _lib.StreamResult()
         rc = L.sjhip_stream_next(self._h, C.byref(r))
         if rc == STREAM_EMPTY or rc == STREAM_CLOSED:
@@ -126,6 +137,15 @@ class Stream:
         if rc:
             msg = {1: ERR_STAGE1, 2: ERR_STAGE2}.get(rc, L.sjhip_stream_last_error(self._h).decode())
             raise ParseError("parsing input: %s" % msg, rc)
+        if view:
+            from .api import _pinned_view
+            self._held = True
+            pj = ParsedJson(_pinned_view(r.message, r.message_len, C.c_uint8, np.uint8), _pinned_view(r.tape, r.tape_len, C.c_uint64, np.uint64),
+                            _pinned_view(r.strings, r.strings_len, C.c_uint8, np.uint8))
+            pj.records = int(r.records)
+            pj.device = int(r.device)
+            pj._owner = self
+            return pj
         try:
             tl, sl = r.tape_len, r.strings_len
             tape_buf = reuse._tape_buf if reuse is not None and reuse._tape_buf.size >= tl else np.empty(tl, np.uint64)
@@ -143,7 +163,7 @@ class Stream:
         return pj
 
 
-def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=None, n_devices=1, where=None):
+def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=None, n_devices=1, where=None, view=False):
     """Generator over the ParsedJson of every block, in stream order.
 
     Mirrors `ParseNDStream(r, res, reuse)`: a block that fails to parse raises `ParseError` after all earlier
@@ -152,6 +172,8 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
     `queue.Queue`-like object the consumer puts finished ParsedJson values into; like the reference's `reuse`
     channel it is polled without blocking and the Tape / Strings capacity of what it returns is recycled.
     `inflight`: blocks in flight (0 = three per device); `n_devices` = 0 uses every visible GPU, round robin.
+    `view=True`: every ParsedJson is a set of read-only views of the stream's pinned memory, valid until the generator
+    is resumed (the Go shim's ParseNDStreamInPlace): no copy of the 2.4 result bytes per input byte.
     """
     reader = _buffered(reader, block_size)
     st = Stream(block_size, slots=max(0, int(inflight)), first_device=device, n_devices=n_devices)
@@ -173,20 +195,20 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
             # every Stream value as soon as its block is parsed (simdjson_amd64.go:193-203), so on a slow or unbounded
             # reader results must not wait for the slots to fill up.
             while st.ready():
-                pj = st.take(old())
+                pj = st.take(old(), view=view)
                 if pj is None:
                     return
                 yield pj
             state = st.feed(reader)
             if state == "full":  # every slot holds a block: deliver the oldest one
-                pj = st.take(old())
+                pj = st.take(old(), view=view)
                 if pj is None:
                     return
                 yield pj
                 continue
             more = state == "more"
         while True:
-            pj = st.take(old())
+            pj = st.take(old(), view=view)
             if pj is None:
                 return
             yield pj

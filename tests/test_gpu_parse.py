@@ -336,6 +336,23 @@ def test_parse_nd_stream():
             assert ref.rc == 0
             assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
             assert pj.Message == bytes(blk[ref.msg_off:ref.msg_off + ref.msg_len])
+    # the results read in place (views of the stream's pinned blocks, valid until the generator is resumed): the same
+    # blocks, nothing copied; with one slot, with a filter, and ended early by the consumer
+    for inflight in (1, 3):
+        n = 0
+        for pj, blk in zip(sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=inflight, view=True), blocks):
+            ref = O.parse(blk, ndjson=True, copy_strings=True)
+            assert not pj.Tape.flags.writeable
+            assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings)
+            assert pj.Message == bytes(blk[ref.msg_off:ref.msg_off + ref.msg_len])
+            n += 1
+        assert n == len(blocks)
+    it = sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=2, view=True, where=(b"Make", b"HOND"))
+    assert sum(pj.records for pj in it) == 116 * 24
+    it = sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=2, view=True)
+    first = next(it)
+    assert first.Tape.size > 0
+    it.close()  # (a held block is released, the stream destroyed)
     # a broken record in the fourth block: three results, then the error
     bad = bytearray(stream)
     at = sum(len(b) for b in blocks[:3]) + 5000
