@@ -199,12 +199,14 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
                 if pj is None:
                     return
                 yield pj
+                st.release_held()  # (view=True: the consumer is done with the block)
             state = st.feed(reader)
             if state == "full":  # every slot holds a block: deliver the oldest one
                 pj = st.take(old(), view=view)
                 if pj is None:
                     return
                 yield pj
+                st.release_held()
                 continue
             more = state == "more"
         while True:
@@ -212,5 +214,6 @@ def parse_nd_stream(reader, block_size=BLOCK_SIZE, inflight=0, device=0, reuse=N
             if pj is None:
                 return
             yield pj
+            st.release_held()
     finally:
         st.close()
