@@ -87,6 +87,12 @@ int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
  * Either pointer is NULL when its length is 0. */
 int sjhip_fetch_view(sjhip_ctx *ctx, const uint64_t **tape, const uint8_t **strings);
 
+/* A pinned host block of at least `bytes` bytes owned by the context, for callers that can read their input (a file, a
+ * socket) straight into it -- the role of the reference's tmpPool blocks in ParseNDStream (simdjson_amd64.go:127-135) for
+ * a single Parse: sjhip_parse(ctx, block, len, ...) then copies host -> device at the pinned rate (twitter.json: 19
+ * instead of 28 us).  Valid until the next sjhip_input_block call with a larger size, sjhip_ctx_trim or destroy. */
+uint8_t *sjhip_input_block(sjhip_ctx *ctx, size_t bytes);
+
 /* Same parse on a message that is already resident in device memory (already trimmed). Used by
  * bench.py (inputs in HBM before the timed region) and by the multi-GPU shard path. */
 int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t flags, size_t *tape_len,

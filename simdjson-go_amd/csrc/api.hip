@@ -124,8 +124,9 @@ int sjhip_ctx_trim(sjhip_ctx *ctx) {
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     if (ctx->h_view) (void)hipHostFree(ctx->h_view);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    ctx->h_pack = ctx->h_view = ctx->h_stage = nullptr;
-    ctx->h_view_cap = ctx->h_stage_cap = 0;
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    ctx->h_pack = ctx->h_view = ctx->h_stage = ctx->h_in = nullptr;
+    ctx->h_view_cap = ctx->h_stage_cap = ctx->h_in_cap = 0;
     return SJHIP_OK;
 }
 
@@ -142,6 +143,7 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     if (ctx->h_view) (void)hipHostFree(ctx->h_view);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->side_stream) {
@@ -152,6 +154,26 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+uint8_t *sjhip_input_block(sjhip_ctx *ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    if (bytes <= ctx->h_in_cap && ctx->h_in) return ctx->h_in;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    (void)hipStreamSynchronize(ctx->stream);  // (a copy out of the old block may still be queued)
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    ctx->h_in = nullptr;
+    ctx->h_in_cap = 0;
+    const size_t cap = (bytes + bytes / 4 + 4096) & ~(size_t)4095;
+    const hipError_t e = sj::pinned_alloc((void **)&ctx->h_in, cap);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_in = nullptr;
+        ctx_set_error(ctx, "hipHostMalloc of %zu bytes for the input block: %s", cap, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->h_in_cap = cap;
+    return ctx->h_in;
 }
 
 const char *sjhip_last_error(const sjhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }

@@ -28,6 +28,8 @@ struct sjhip_ctx {
     int pack_valid = 0;                // h_pack holds the result of the last parse
     uint8_t *h_view = nullptr;         // sjhip_fetch_view of results that did not travel with the last launch (grows)
     size_t h_view_cap = 0;
+    uint8_t *h_in = nullptr;           // sjhip_input_block: pinned block the caller reads its input into
+    size_t h_in_cap = 0;
     uint8_t *h_stage = nullptr;        // pinned staging of sjhip_parse_batch: runs of small documents travel as one copy
     size_t h_stage_cap = 0;
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;

@@ -330,6 +330,17 @@ func (v *ViewParser) parse(msg []byte, ndjson bool) (*ParsedJson, error) {
 	return pj, nil
 }
 
+// InputBlock returns n bytes of pinned host memory of the parser's context to read the next message into (a file, a
+// socket) and hand to Parse / ParseND: the copy to the device then runs at the pinned rate (sjhip_input_block).  Valid
+// until the next InputBlock call with a larger n.
+func (v *ViewParser) InputBlock(n int) []byte {
+	p := C.sjhip_input_block(v.c.h, C.size_t(n))
+	if p == nil {
+		return nil
+	}
+	return unsafe.Slice((*byte)(unsafe.Pointer(p)), n)
+}
+
 // Parse is Parse(b, reuse) with the ViewParser's own ParsedJson as `reuse`.
 func (v *ViewParser) Parse(b []byte) (*ParsedJson, error) { return v.parse(b, false) }
 

@@ -32,6 +32,7 @@ SYMBOLS = {
     "sjhip_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_ctx_device_bytes": (C.c_size_t, [C.c_void_p]),
     "sjhip_ctx_trim": (C.c_int, [C.c_void_p]),
+    "sjhip_input_block": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "sjhip_fetch_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "sjhip_parse_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, szp, szp]),
     "sjhip_parse_shard_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),

@@ -75,6 +75,14 @@ class Context:
         """give every arena back (after an unusually large message); the next parse allocates what it needs"""
         self._check(_lib.lib().sjhip_ctx_trim(self._h))
 
+    def input_block(self, nbytes):
+        """A pinned host block of the context as a writable uint8 array of `nbytes` bytes: read the input straight into
+        it (file.readinto) and hand it to parse() -- the copy to the device then runs at the pinned rate."""
+        p = _lib.lib().sjhip_input_block(self._h, nbytes)
+        if not p:
+            raise ParseError(f"sjhip_input_block: {self.last_error()}", -1)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=np.uint8)
+
     def set_stream(self, stream_ptr):
         _lib.lib().sjhip_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0))
 

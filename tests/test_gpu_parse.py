@@ -630,6 +630,13 @@ def test_fetch_view_equals_fetch(ctx):
             assert not got.Tape.flags.writeable and (got.Strings.size == 0 or not got.Strings.flags.writeable)
             assert np.array_equal(got.Tape, wt) and np.array_equal(got.Strings, ws), (len(data), nd, copy)
             assert got.Message == want.Message
+    # the input read into the context's pinned block (sjhip_input_block): same results, the block grows with the request
+    for data, nd in docs[:4]:
+        blk = ctx.input_block(len(data))
+        blk[:] = np.frombuffer(data, dtype=np.uint8)
+        got = ctx.parse(blk, ndjson=nd, view=True)
+        want = O.parse(data, ndjson=nd)
+        assert np.array_equal(got.Tape, want.tape) and np.array_equal(got.Strings, want.strings), (len(data), nd)
     # the view of a large result, then a small one, then the large one again (the block only grows)
     big = ctx.parse(docs[3][0], ndjson=True, view=True)
     big_t = big.Tape.copy()

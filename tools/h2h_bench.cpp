@@ -63,7 +63,19 @@ int main(int argc, char **argv) {
         sjhip_fetch_view(ctx, &vt, &vs);
         sink += vt ? vt[tl - 1] : 0;
     });
+    uint8_t *in = sjhip_input_block(ctx, doc.size());
+    const double t_pin_view = in ? best_of(5, 40, [&] {
+        memcpy(in, doc.data(), doc.size());  // (stands for the caller's read into the block)
+        sjhip_parse(ctx, in, doc.size(), flags, &tl, &sl, &mo, &ml);
+        sjhip_fetch_view(ctx, &vt, &vs);
+    }) : 0.0;
+    const double t_pin_view_nc = in ? best_of(5, 40, [&] {
+        sjhip_parse(ctx, in, doc.size(), flags, &tl, &sl, &mo, &ml);
+        sjhip_fetch_view(ctx, &vt, &vs);
+    }) : 0.0;
     printf("%s: %zu B, tape %zu words, strings %zu B\n", argv[1], doc.size(), tl, sl);
+    printf("  input block (memcpy in) + parse + view     %8.1f us\n", t_pin_view);
+    printf("  input block (already filled) + parse + view %7.1f us\n", t_pin_view_nc);
     printf("  sjhip_parse + sjhip_fetch_view (in place)  %8.1f us   (%llu)\n", t_view, (unsigned long long)(sink & 1));
     printf("  sjhip_parse (pageable H2D + kernels)      %8.1f us\n", t_parse);
     printf("  sjhip_parse + sjhip_fetch (pageable D2H)  %8.1f us\n", t_both);
