@@ -677,6 +677,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     // shorter (a raw control character is a stage-1 error, every escape the writer produces is at most as long as the
     // one the parser consumed), literals and brackets as they are, separators are a subset of the source's.  A tile that
     // would write past the bound (it cannot) or that finds no anchor raises a flag and the two-pass form below runs.
+    bool no_local_anchor = false;
     if (p.kf_tape && ms_onepass()) {
         size_t bound = ctx->p_len + 20 * (p.n / 2 + 1) + 64;
         if (const char *e = getenv("SJHIP_MS_TEST_BOUND")) bound = (size_t)strtoull(e, nullptr, 0);  // tests: make the bound fail
@@ -708,11 +709,12 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
             if (text_len) *text_len = ctx->ms_len;
             return SJHIP_OK;
         }
+        no_local_anchor = (h[2] & 4ull) != 0;  // (the counting pass below starts with the global anchors right away)
         HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
         p.text = nullptr;
     }
     // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = no_local_anchor ? 1 : 0; attempt < 2; attempt++) {
         if (attempt == 0) {
             p.tile_last = nullptr;
         } else {
