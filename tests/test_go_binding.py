@@ -95,6 +95,43 @@ def test_shim_uses_only_declared_c_symbols():
     assert not unknown, unknown
 
 
+def _top_level_args(text, open_at):
+    """number of top-level arguments of the call whose '(' is at text[open_at]"""
+    depth, args, seen = 0, 0, False
+    for ch in text[open_at:]:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                return args + (1 if seen else 0)
+        elif ch == "," and depth == 1:
+            args += 1
+            seen = False
+            continue
+        if depth >= 1 and not ch.isspace() and not (depth == 1 and ch == "("):
+            seen = True
+    raise AssertionError("unbalanced call")
+
+
+def test_cgo_calls_pass_as_many_arguments_as_the_header_declares():
+    """Every C.sjhip_*(...) call of the shim against the prototype in include/sjhip.h (cgo rejects a wrong count; without a
+    Go toolchain this is the part of that check that can be done here)."""
+    with open(os.path.join(ROOT, "include", "sjhip.h")) as f:
+        header = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+    arity = {}
+    for name, params in re.findall(r"\b(sjhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header):
+        params = params.strip()
+        arity[name] = 0 if params in ("", "void") else params.count(",") + 1
+    assert len(arity) > 50
+    shim = G.strip_go(_shim())
+    calls = [(m.group(1), m.end() - 1) for m in re.finditer(r"\bC\.(sjhip_[a-z0-9_]+)\s*\(", shim)]
+    assert len(calls) > 30
+    wrong = [(n, _top_level_args(shim, at), arity[n]) for n, at in calls if _top_level_args(shim, at) != arity[n]]
+    assert not wrong, wrong
+    assert _top_level_args("f(a, g(b, c), []int{1, 2})", 1) == 3 and _top_level_args("f()", 1) == 0 and _top_level_args("f( x )", 1) == 1
+
+
 def test_integration_md_lists_the_tag_edits():
     with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
         text = f.read()
