@@ -34,6 +34,29 @@ def test_library_exports_every_declared_symbol(built):
     sjhip.lib()
 
 
+def test_ctypes_bindings_match_the_prototypes():
+    """sjhip/_lib.py: as many argtypes as the header's prototype has parameters, pointers where the header has pointers,
+    and a pointer-sized result where the header returns a pointer (a c_int restype would truncate it)."""
+    hdr = open(os.path.join(ROOT, "include", "sjhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    import sjhip
+    protos = re.findall(r"([A-Za-z_][A-Za-z0-9_ \t]*?[\s\*]+)(sjhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(protos) >= 60
+    ptr_types = (C.c_void_p, C.c_char_p)
+    for ret, name, params in protos:
+        res, args = sjhip._lib.SYMBOLS[name]
+        plist = [] if params.strip() in ("", "void") else [q.strip() for q in params.split(",")]
+        assert len(args) == len(plist), (name, len(args), plist)
+        for a, q in zip(args, plist):
+            is_ptr_c = "*" in q or "[" in q  # (an array parameter is a pointer)
+            is_ptr_py = a in ptr_types or hasattr(a, "contents") or (isinstance(a, type) and issubclass(a, C._Pointer))
+            assert is_ptr_c == is_ptr_py, (name, q, a)
+        if "*" in ret:
+            assert res in ptr_types, (name, ret, res)
+        elif ret.strip().endswith("void"):
+            assert res is None, (name, res)
+
+
 def _selftest():
     L = C.CDLL(G.build_selftest())
     L.sj_selftest_stage1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
