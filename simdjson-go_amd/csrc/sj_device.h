@@ -104,6 +104,7 @@ struct StrAux {
     uint32_t *unit_cnt;
     uint8_t *unit_h;
     uint64_t *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (a \u or an invalid escape)
+    uint8_t *unit_copy;   // per unit, WithCopyStrings(false): 1 iff bytes of a string that unescaping changes lie in it (stage2.hip)
 };
 inline StrAux str_aux_layout(void *buf, size_t span) {
     StrAux a;
@@ -122,6 +123,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
     a.unit_slow = reinterpret_cast<uint64_t *>(carve(a.units * 8));
+    a.unit_copy = reinterpret_cast<uint8_t *>(carve(a.units));
     a.bytes = (size_t)(w - reinterpret_cast<char *>(buf));
     return a;
 }

@@ -106,6 +106,8 @@ struct S2Dev {
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
     Arr<ChunkRec> rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
     Arr<u32> unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
+    Arr<u8> unit_copy;        // [units]  selective copy only (else null): 1 iff the unit holds bytes of a string that unescaping
+                              // changes -- cleared with the unit's count, set by k_str_measure; k_str_emit compacts only those units
     u64 units;
     u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
 };
@@ -225,7 +227,10 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
         const u32 n = (u32)popc64(em);
         const u32 incl = wave_incl_sum(n);
         p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
-        if (lane == 63) p.unit_cnt[unit] = incl;
+        if (lane == 63) {
+            p.unit_cnt[unit] = incl;
+            if (p.unit_copy) p.unit_copy[unit] = 0;
+        }
         if (!more) break;
         unit = next;
         in = in_n;
@@ -469,11 +474,13 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         ChunkRec r;
         u32 g;  // Strings.B offset of the unit
     };
+    // (selective copy: a unit without a byte of a string that unescaping changes is not compacted -- nobody reads its
+    // stretch of the scratch buffer; its record reads as "nothing to emit")
     auto load_rec = [&](u64 u) {
         Rec x;
         x.r = ChunkRec{0, 0, 0};
         x.g = 0;
-        if (u < p.units) {
+        if (u < p.units && !(p.unit_copy && p.unit_copy[u] == 0)) {
             x.r = p.rec[u * 64 + lane];
             x.g = p.unit_cnt[u];
         }
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         const u64 g = (u64)cur.g;  // exclusive prefix: Strings.B offset of the unit
         // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
         // two record loads instead of two records + two unit prefixes
-        if (!p.no_abs) p.rec[c].abs = (u32)g + pre;
+        if (!p.no_abs && !p.unit_copy) p.rec[c].abs = (u32)g + pre;  // (selective copy takes its offsets from unit_cnt + pre)
         if (total != 0) {  // wave-uniform
             const bool mine = em != 0 && patched;
             if (mine) {
@@ -801,6 +808,11 @@ __global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
         const StrMeasure m1 = string_measure_loaded(p.sv, p.unit_cnt, a10, a11, r10, r11, q1);
         p.dlen[i0] = m0.ok ? (m0.dl | (m0.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
         if (two) p.dlen[i1] = m1.ok ? (m1.dl | (m1.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
+        // the units a string that will be copied reaches into: only those are compacted (k_str_emit)
+        if (m0.ok && m0.copied)
+            for (u64 u = a00 >> 12; u <= (a01 >> 12) && u < p.units; u++) p.unit_copy[u] = 1;
+        if (two && m1.ok && m1.copied)
+            for (u64 u = a10 >> 12; u <= (a11 >> 12) && u < p.units; u++) p.unit_copy[u] = 1;
     }
 }
 
@@ -1657,6 +1669,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.sv.unit_slow = nullptr;
     p.rec = nullptr;
     p.unit_cnt = nullptr;
+    p.unit_copy = nullptr;
     p.units = 0;
     p.exp = 0;
 #if defined(SJ_EXP)
@@ -1673,6 +1686,7 @@ static S2Dev stage2_view(const S2Args &a) {
         p.sv.unit_slow = SJ_ARR((const u64 *)x.unit_slow, x.units, A_SV_UNIT_SLOW);
         p.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(x.rec), x.chunks, A_REC);
         p.unit_cnt = SJ_ARR(x.unit_cnt, x.units, A_UNIT_CNT);
+        if (!p.copy_strings) p.unit_copy = SJ_ARR(x.unit_copy, x.units, A_UNIT_COPY);
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
     return p;
