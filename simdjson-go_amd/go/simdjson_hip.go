@@ -259,7 +259,9 @@ func Parse(b []byte, reuse *ParsedJson, opts ...ParserOption) (*ParsedJson, erro
 // result into Go memory: it owns one GPU context, and the ParsedJson it returns has Tape and Strings.B aliasing that
 // context's pinned host memory (sjhip_fetch_view) -- overwritten by the next call on the same ViewParser, exactly as a
 // recycled ParsedJson is.  The slices must not be appended to or written, and the ParsedJson must not be handed to
-// Parse / ParseND as `reuse` (they would recycle slices that are not Go memory).  One ViewParser per goroutine.
+// Parse / ParseND as `reuse` (they would recycle slices that are not Go memory).  One ViewParser per goroutine; keep it
+// reachable for as long as slices of its ParsedJson are in use (the context, and with it the pinned memory, is released
+// when the ViewParser is collected -- holding the *ParsedJson it returned is enough: it points into the ViewParser).
 // Parse(twitter.json) host to host: 152 us through Parse, ~120 us through a ViewParser (DESIGN.md section 5).
 type ViewParser struct {
 	c  *hipCtx
