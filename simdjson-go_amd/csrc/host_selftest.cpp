@@ -148,6 +148,7 @@ extern "C" int sj_selftest_int_fast(const uint8_t *buf, size_t len, uint64_t *va
 #include "sj_host.h"
 #include "sj_stage2.h"
 #include "sj_ftoa.h"
+#include "sj_planes.h"
 #include "sj_strings.h"
 
 extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
@@ -314,6 +315,31 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         const long j = (long)i + d;
         return (j < 0 || j >= (long)n) ? (u8)K_BAD : kind[(size_t)j];
     };
+    // The scan element of 64 tokens at once from the bit planes of their kinds (sj_planes.h) against the per-token
+    // statement: every group's aggregate, every token's tape offset and bracket ordinal inside its group, and the
+    // allowed contexts of the gap of every bracket
+    {
+        Agg prefix = agg_identity();
+        for (size_t g0 = 0; g0 < n; g0 += 64) {
+            const u32 cnt = (u32)(n - g0 < 64 ? n - g0 : 64);
+            const KindPlanes kp = kind_planes(kind.data() + g0, cnt);
+            const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            const GroupCarry cy{g0 >= 2 ? kind[g0 - 2] : (u8)K_NONE, g0 >= 1 ? kind[g0 - 1] : (u8)K_NONE,
+                                g0 + 64 < n ? kind[g0 + 64] : (u8)K_NL};
+            const GroupMasks gm = group_masks(kp, valid, cy, g0 == 0);
+            Agg fold = agg_identity();
+            for (u32 j = 0; j < cnt; j++) {
+                const size_t i = g0 + j;
+                const Agg e = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), 0u);
+                if (group_words_before(gm, j) != fold.w || group_brackets_before(gm, j) != fold.bc) return 91;
+                if (is_bracket(kind[i]) && group_gap_set(gm, j, prefix.am) != gap_mask(agg_combine(prefix, fold), e)) return 91;
+                fold = agg_combine(fold, e);
+            }
+            const Agg ga = group_aggregate(gm);
+            if (ga.d != fold.d || ga.w != fold.w || ga.nb != fold.nb || ga.bc != fold.bc || ga.am != fold.am) return 91;
+            prefix = agg_combine(prefix, fold);
+        }
+    }
     // k_s2_scan_tiles + k_s2_emit: the scan as a sequential sum
     std::vector<i32> br_depth;
     std::vector<u32> br_off, nl_off;
