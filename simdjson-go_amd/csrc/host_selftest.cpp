@@ -318,6 +318,8 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     // The scan element of 64 tokens at once from the bit planes of their kinds (sj_planes.h) against the per-token
     // statement: every group's aggregate, every token's tape offset and bracket ordinal inside its group, and the
     // allowed contexts of the gap of every bracket
+    std::vector<Agg> elem(n);  // (token_element once per token: the plane check and the scan below share it)
+    for (size_t i = 0; i < n; i++) elem[i] = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), 0u);
     {
         Agg prefix = agg_identity();
         for (size_t g0 = 0; g0 < n; g0 += 64) {
@@ -330,7 +332,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             Agg fold = agg_identity();
             for (u32 j = 0; j < cnt; j++) {
                 const size_t i = g0 + j;
-                const Agg e = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), 0u);
+                const Agg &e = elem[i];
                 if (group_words_before(gm, j) != fold.w || group_brackets_before(gm, j) != fold.bc) return 91;
                 if (is_bracket(kind[i]) && group_gap_set(gm, j, prefix.am) != gap_mask(agg_combine(prefix, fold), e)) return 91;
                 fold = agg_combine(fold, e);
@@ -348,7 +350,8 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     Agg run = agg_identity();
     u64 words = 0, sbytes = 0;
     for (size_t i = 0; i < n; i++) {
-        const Agg e = token_element((u32)i, (u32)n, kind[i], kind_at(i, -1), kind_at(i, -2), kind_at(i, 1), copied[i]);
+        Agg e = elem[i];
+        e.s = copied[i];
         {  // the packed table form the kernels use must be the same element
             const PAgg pe = token_pelement(ELUT.v, kind_window(kind.data(), (u32)i, (u32)n), copied[i]), want = pagg_pack(e);
             if (pe.x != want.x || pe.y != want.y || pe.z != want.z || pe.s != want.s) return 97;
