@@ -325,6 +325,12 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         for (size_t g0 = 0; g0 < n; g0 += 64) {
             const u32 cnt = (u32)(n - g0 < 64 ? n - g0 : 64);
             const KindPlanes kp = kind_planes(kind.data() + g0, cnt);
+            {  // the multiplication form of the transposition
+                u32 w16[16] = {0};
+                memcpy(w16, kind.data() + g0, cnt);
+                const KindPlanes k2 = kind_planes_words(w16);
+                if (k2.b0 != kp.b0 || k2.b1 != kp.b1 || k2.b2 != kp.b2 || k2.b3 != kp.b3) return 91;
+            }
             const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
             const GroupCarry cy{g0 >= 2 ? kind[g0 - 2] : (u8)K_NONE, g0 >= 1 ? kind[g0 - 1] : (u8)K_NONE,
                                 g0 + 64 < n ? kind[g0 + 64] : (u8)K_NL};

@@ -40,6 +40,22 @@ SJ_HD KindPlanes kind_planes(const u8 *kinds, u32 count) {
     return p;
 }
 
+// The same planes from the 64 kind bytes as sixteen little-endian words, without a loop over the tokens: bit b of the
+// four bytes of a word is isolated ((w >> b) & 0x01010101) and gathered into a nibble by one multiplication -- the
+// partial products 2^(8i) * 2^(28 - 7j) land on distinct bits, the ones with i == j on bits 28 + i (the device form;
+// count < 64: the bytes behind the end must be zero).
+SJ_HD KindPlanes kind_planes_words(const u32 *w16) {
+    u64 pl[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 16; q++) {
+        const u32 w = w16[q];
+        for (int b = 0; b < 4; b++) {
+            const u32 nib = (((w >> b) & 0x01010101u) * 0x10204080u) >> 28;
+            pl[b] |= (u64)nib << (4 * q);
+        }
+    }
+    return KindPlanes{pl[0], pl[1], pl[2], pl[3]};
+}
+
 struct KindClasses {
     u64 open_obj, open_arr, close_obj, close_arr, colon, comma, string, num, atom, nl;
     u64 open, close, bracket;
