@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of MarshalJSON wall time between the libraries in build_ab/ (same box, interleaved twice)
+# A/B of MarshalJSON wall time between the libraries in build_ab/ (same box, interleaved twice).  The variants are built by
+# hand into build_ab/libsjhip_ms_<name>.so (the objects of __graft_entry__.HIP_SOURCES with marshal.hip compiled per
+# variant; build_ab/ is git-ignored and travels with gpurun); SJHIP_LIB selects the library the Python mirror loads.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2; do
 for lib in $(ls build_ab/libsjhip_ms_*.so); do
