@@ -355,6 +355,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     std::vector<u32> toff(n), soff(n, 0);
     Agg run = agg_identity();
     u64 words = 0, sbytes = 0;
+    bool bad_ctx = false;  // a token that is legal in no context at all
     for (size_t i = 0; i < n; i++) {
         Agg e = elem[i];
         e.s = copied[i];
@@ -364,7 +365,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         }
         toff[i] = run.w + 1u;
         soff[i] = run.s;
-        if (am_value(e.am) == 0) bad = 1;
+        if (am_value(e.am) == 0) {
+            bad = 1;
+            bad_ctx = true;
+        }
         if (is_bracket(kind[i])) {
             br_depth.push_back(run.d + e.d);
             br_off.push_back(toff[i]);
@@ -374,6 +378,50 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         words += e.w;
         sbytes += e.s;
         run = agg_combine(run, e);
+    }
+    // The same pass organised the way a kernel on bit planes would run it (sj_planes.h): a tile of 4096 tokens per wave,
+    // 64 tokens per lane; a lane knows the masks of its group, the exclusive prefix over the lanes in front of it (and
+    // the tiles in front of the tile) and derives from those alone the tape offset of every token, the compact index,
+    // depth, tape offset and gap set of every bracket and the ordinal of every record-separating newline.
+    {
+        Agg tile_prefix = agg_identity();
+        bool bad_planes = false;
+        for (size_t t0 = 0; t0 < n; t0 += 4096) {
+            Agg ex = tile_prefix;
+            for (u32 l = 0; l < 64; l++) {
+                const size_t g0 = t0 + 64 * (size_t)l;
+                if (g0 >= n) break;
+                const u32 cnt = (u32)(n - g0 < 64 ? n - g0 : 64);
+                const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                const GroupCarry cy{g0 >= 2 ? kind[g0 - 2] : (u8)K_NONE, g0 >= 1 ? kind[g0 - 1] : (u8)K_NONE,
+                                    g0 + 64 < n ? kind[g0 + 64] : (u8)K_NL};
+                const GroupMasks gm = group_masks(kind_planes(kind.data() + g0, cnt), valid, cy, g0 == 0);
+                if ((~(gm.a_root | gm.a_obj | gm.a_arr) & valid) != 0) bad_planes = true;
+                for (u64 r = gm.w1 | gm.br | gm.nlr; r != 0; r &= r - 1) {  // the tokens that write something
+                    const u32 j = (u32)ctz64(r);
+                    const size_t i = g0 + j;
+                    const u32 o = ex.w + 1u + group_words_before(gm, j);
+                    if (o != toff[i]) return 90;
+                    if ((gm.br >> j) & 1u) {
+                        const u32 c = ex.bc + group_brackets_before(gm, j);
+                        const u64 upto = j == 63 ? ~0ull : ((1ull << (j + 1)) - 1ull);
+                        const i32 d = ex.d + 2 * (i32)popc64(gm.open & upto) - (i32)popc64(gm.br & upto);
+                        if (c >= br_off.size() || br_off[c] != o || br_depth[c] != d ||
+                            br_info[c] != (u8)(kind[i] | (group_gap_set(gm, j, ex.am) << 4)))
+                            return 90;
+                    }
+                    if ((gm.nlr >> j) & 1u) {
+                        const u32 r_ord = ex.nb + (u32)popc64(gm.nlr & (j ? (~0ull >> (64 - j)) : 0ull));
+                        if (r_ord >= nl_off.size() || nl_off[r_ord] != o) return 90;
+                    }
+                }
+                ex = agg_combine(ex, group_aggregate(gm));
+            }
+            tile_prefix = ex;
+        }
+        if (bad_planes != bad_ctx) return 90;
+        if (tile_prefix.d != run.d || tile_prefix.w != run.w || tile_prefix.nb != run.nb || tile_prefix.bc != run.bc || tile_prefix.am != run.am)
+            return 90;
     }
     if (copy) sbytes = masks_total;
     const u32 tlen = (u32)words + 2;  // + opening and closing root
