@@ -341,3 +341,25 @@ def test_twitterescaped_equals_twitter_in_copy_mode():
     a = O.parse(fixtures.load("twitter"))
     b = O.parse(fixtures.load("twitterescaped"))
     assert np.array_equal(a.tape, b.tape) and np.array_equal(a.strings, b.strings)
+
+
+def test_baseline_configuration_sizes():
+    """The sizes SURVEY.md section 8(d) derives for the BASELINE.json configurations (structurals, tape words, Strings.B
+    bytes, floats) hold for the oracle: C1 twitter.json (55 263 structurals is the reference's own golden,
+    find_subroutines_amd64_test.go:464), C3 canada.json, C4 twitterescaped.json in both copy modes, one file of C5."""
+    tw = O.parse(fixtures.load("twitter"))
+    assert O.stage1(fixtures.load("twitter"))[1].size == 55263
+    assert (tw.tape.size, tw.strings.size) == (49783, 367917)
+    ca = O.parse(fixtures.load("canada"))
+    assert O.stage1(fixtures.load("canada").strip())[1].size == 334373
+    assert (ca.tape.size, ca.strings.size) == (334376, 90)
+    tags, i = {}, 0
+    while i < ca.tape.size:  # entry by entry: a string / number entry is two words
+        t = chr(int(ca.tape[i]) >> 56)
+        tags[t] = tags.get(t, 0) + 1
+        i += 2 if t in 'lud"' else 1
+    assert tags["d"] + tags["l"] == 111126 and tags["l"] == 46  # 111 126 numbers, 46 of them written without a fraction
+    te = O.parse(fixtures.load("twitterescaped"), copy_strings=False)
+    assert te.strings.size == 113036 and te.tape.size == 49783
+    pk = O.parse(fixtures.load("parking-citations"), ndjson=True)
+    assert (pk.tape.size, pk.strings.size) == (80000, 256664)
