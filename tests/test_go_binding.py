@@ -132,6 +132,20 @@ def test_cgo_calls_pass_as_many_arguments_as_the_header_declares():
     assert _top_level_args("f(a, g(b, c), []int{1, 2})", 1) == 3 and _top_level_args("f()", 1) == 0 and _top_level_args("f( x )", 1) == 1
 
 
+def test_shim_brackets_balance():
+    """(no gofmt here) with comments, strings and runes stripped, every kind of bracket of the shim closes"""
+    src = G.strip_go(_shim())
+    for a, b in ("{}", "()", "[]"):
+        depth = 0
+        for ch in src:
+            if ch == a:
+                depth += 1
+            elif ch == b:
+                depth -= 1
+                assert depth >= 0, (a, b)
+        assert depth == 0, (a, b, depth)
+
+
 def test_integration_md_lists_the_tag_edits():
     with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
         text = f.read()
