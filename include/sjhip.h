@@ -81,7 +81,7 @@ int sjhip_fetch(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
  * pinned host memory that the context owns, valid until the next call that parses on this context (or destroys it).
  * This is what `reuse *ParsedJson` means in the reference (simdjson_amd64.go:46-51: the arrays of the recycled
  * ParsedJson are overwritten by the next parse): a binding that keeps one context per recycled ParsedJson hands these
- * pointers out as pj.Tape / pj.Strings (INTEGRATION.md section 2b).  A small document parsed by sjhip_parse is
+ * pointers out as pj.Tape / pj.Strings (INTEGRATION.md section 3b).  A small document parsed by sjhip_parse is
  * already there (its last kernel wrote the result over PCIe); anything else is copied device -> pinned block here
  * (the block grows on demand, SJHIP_ERR_TOOBIG beyond SJHIP_VIEW_LIMIT_BYTES, default 4 GiB: use sjhip_fetch).
  * Either pointer is NULL when its length is 0. */
