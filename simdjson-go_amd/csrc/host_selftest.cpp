@@ -149,6 +149,7 @@ extern "C" int sj_selftest_int_fast(const uint8_t *buf, size_t len, uint64_t *va
 #include "sj_stage2.h"
 #include "sj_ftoa.h"
 #include "sj_planes.h"
+#include "sj_tok16.h"
 #include "sj_strings.h"
 
 extern "C" void sj_selftest_trim(const uint8_t *msg, size_t len, size_t *off, size_t *out_len) {
@@ -345,6 +346,62 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             }
             const Agg ga = group_aggregate(gm);
             if (ga.d != fold.d || ga.w != fold.w || ga.nb != fold.nb || ga.bc != fold.bc || ga.am != fold.am) return 91;
+            prefix = agg_combine(prefix, fold);
+        }
+    }
+    // The same element for SIXTEEN tokens per lane from 19-bit windows of the kind planes (sj_tok16.h: what k_measure and
+    // k_s2_emit run since round 5): the transposition, every lane's aggregate, every writing token's tape offset, every
+    // bracket's kind and gap set, every atom's kind
+    {
+        Agg prefix = agg_identity();
+        for (size_t g0 = 0; g0 < n; g0 += 16) {
+            const u32 cnt = (u32)(n - g0 < 16 ? n - g0 : 16);
+            u8 kb[16];
+            for (u32 j = 0; j < 16; j++) kb[j] = j < cnt ? kind[g0 + j] : (u8)K_NL;
+            u32 w4[4];
+            memcpy(w4, kb, 16);
+            const Planes16 pl = planes16(w4[0], w4[1], w4[2], w4[3]);
+            for (u32 pb = 0; pb < 4; pb++) {
+                u32 want = 0;
+                for (u32 j = 0; j < 16; j++) want |= (u32)((kb[j] >> pb) & 1u) << j;
+                const u32 got = pb & 1 ? ((pb & 2 ? pl.p23 : pl.p01) >> 16) : ((pb & 2 ? pl.p23 : pl.p01) & 0xffffu);
+                if (got != want) return 89;
+            }
+            const u32 prev2 = (u32)(g0 >= 2 ? kind[g0 - 2] : (u8)K_NONE) | ((u32)(g0 >= 1 ? kind[g0 - 1] : (u8)K_NONE) << 8);
+            const u32 next1 = g0 + 16 < n ? kind[g0 + 16] : (u32)K_NL;
+            const u32 valid = cnt == 16 ? 0xffffu : ((1u << cnt) - 1u);
+            const Lane16 lm = lane16_masks(pl, prev2, next1, valid, g0 == 0);
+            Agg fold = agg_identity();
+            bool illegal = false;
+            for (u32 j = 0; j < cnt; j++) {
+                const size_t i = g0 + j;
+                const Agg &e = elem[i];
+                const u8 k = kind[i];
+                if (e.w && lane16_words_before(lm, j) != fold.w) return 89;
+                if (((lm.br >> j) & 1u) != (is_bracket(k) ? 1u : 0u) || ((lm.str >> j) & 1u) != (k == K_STRING ? 1u : 0u) ||
+                    ((lm.num >> j) & 1u) != (k == K_NUM ? 1u : 0u) || ((lm.atom >> j) & 1u) != ((k == K_TRUE || k == K_FALSE || k == K_NULL) ? 1u : 0u) ||
+                    ((lm.nlr >> j) & 1u) != e.nb)
+                    return 89;
+                if (((lm.keystr >> j) & 1u) != ((k == K_STRING && kind_at(i, 1) == K_COLON) ? 1u : 0u)) return 89;
+                if (is_bracket(k)) {
+                    if (lane16_bracket_kind(lm, j) != k) return 89;
+                    if (lane16_gap_set(lm, j, prefix.am) != gap_mask(agg_combine(prefix, fold), e)) return 89;
+                    const u32 e32 = tbr_pack(fold.w, fold.d + e.d, k, 5u);
+                    if (tbr_off(e32) != fold.w || tbr_depth(e32) != fold.d + e.d || tbr_kind(e32) != k || tbr_gap(e32) != 5u) return 89;
+                }
+                if (((lm.atom >> j) & 1u) && lane16_atom_kind(lm, j) != k) return 89;
+                illegal |= am_value(e.am) == 0;
+                fold = agg_combine(fold, e);
+            }
+            const Agg ga = pagg_unpack(lane16_pagg(lm));
+            if (ga.d != fold.d || ga.w != fold.w || ga.nb != fold.nb || ga.bc != fold.bc || ga.am != fold.am) return 89;
+            if (lane16_illegal(lm) != illegal) return 89;
+            u32 ns = 0, nd = 0;
+            for (u32 j = 0; j < cnt; j++) {
+                ns += kind[g0 + j] == K_STRING;
+                nd += kind[g0 + j] >= K_NUM && kind[g0 + j] <= K_NULL;
+            }
+            if (lane16_counts(lm) != (ns | (nd << 13))) return 89;
             prefix = agg_combine(prefix, fold);
         }
     }

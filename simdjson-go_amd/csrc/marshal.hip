@@ -678,11 +678,21 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     // one the parser consumed), literals and brackets as they are, separators are a subset of the source's.  A tile that
     // would write past the bound (it cannot) or that finds no anchor raises a flag and the two-pass form below runs.
     bool no_local_anchor = false;
-    if (p.kf_tape && ms_onepass()) {
-        size_t bound = ctx->p_len + 20 * (p.n / 2 + 1) + 64;
+    bool one_pass = p.kf_tape && ms_onepass();
+    size_t bound = ctx->p_len + 20 * (p.n / 2 + 1) + 64;
+    if (one_pass) {
+        // The bound is ~10 bytes per tape word above the real text: for a tape of several hundred million words that is
+        // gigabytes of a grow-only arena.  Beyond SJHIP_MS_BOUND_LIMIT (default 8 GiB), or when the device cannot give
+        // the block, the exact two-pass form below runs instead of failing.
+        static const size_t limit = getenv("SJHIP_MS_BOUND_LIMIT") ? (size_t)strtoull(getenv("SJHIP_MS_BOUND_LIMIT"), nullptr, 0) : (size_t)8 << 30;
         if (const char *e = getenv("SJHIP_MS_TEST_BOUND")) bound = (size_t)strtoull(e, nullptr, 0);  // tests: make the bound fail
-        rc = arena_reserve(ctx, ctx->d_qtape, bound + 64);
-        if (rc) return rc;
+        if (bound > limit) one_pass = false;
+        else if (arena_reserve(ctx, ctx->d_qtape, bound + 64) != SJHIP_OK) {
+            (void)hipGetLastError();
+            one_pass = false;
+        }
+    }
+    if (one_pass) {
         p.tile_last = nullptr;
         p.text = (u8 *)ctx->d_qtape.p;
         p.text_cap = bound;

@@ -299,8 +299,12 @@ int sj::parse_nd_big(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t fl
     }
     ctx->big_valid = 0;
     const int rc = multi_parse(ctx->big, msg, len, flags, d_resident, tape_len, strings_len, msg_off, msg_len);
-    if (rc == SJHIP_OK) ctx->big_valid = 1;
-    else if (rc != SJHIP_ERR_STAGE1 && rc != SJHIP_ERR_STAGE2) sj::ctx_set_error(ctx, "%s", sjhip_multi_last_error(ctx->big));
+    if (rc == SJHIP_OK) {
+        ctx->big_valid = 1;
+        // the totals of the merged result, for sjhip_fetch_view (which sizes its view block from the context)
+        ctx->tape_len = ctx->big->tape_len;
+        ctx->strings_len = ctx->big->strings_len;
+    } else if (rc != SJHIP_ERR_STAGE1 && rc != SJHIP_ERR_STAGE2) sj::ctx_set_error(ctx, "%s", sjhip_multi_last_error(ctx->big));
     (void)hipSetDevice(ctx->device);
     return rc;
 }

@@ -154,7 +154,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             // ~14 B of arena per message byte instead of 57.  The kernels clamp the device-side count to this layout
             // (stage2.hip token_count), so a denser document stays in bounds and is parsed again the synchronous way
             // (parse_on_device) once stage 1's real count is known.
-            n = len / 4 + 4096 < len ? len / 4 + 4096 : len;
+            n = (!ctx->p_dense && len / 4 + 4096 < len) ? len / 4 + 4096 : len;
             ok = 1;
             ctx->p_last = last_byte;
             ctx->p_have_last = have_last;
@@ -294,6 +294,7 @@ static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32
     rc = parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
     if (rc == PARSE_AGAIN_SYNCHRONOUS) {  // a small document with more than one token per four bytes
         ctx->p_no_defer = 1;
+        ctx->p_dense = 1;  // (minified numeric arrays come in series: the next ones are laid out for one token per byte)
         ctx->want_pack = want_pack;
         rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
         ctx->p_no_defer = 0;

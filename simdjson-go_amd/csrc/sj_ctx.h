@@ -55,6 +55,8 @@ struct sjhip_ctx {
     int pending = 0;
     int p_deferred = 0;   // stage 1's result has not been collected yet (small documents: one synchronisation per parse)
     int p_no_defer = 0;   // the deferred run met more tokens than its layout holds: this parse takes the synchronous path
+    int p_dense = 0;      // sticky: a document of this context was denser than one token per four bytes -- later deferred
+                          // parses are laid out for one token per byte instead of paying the second parse again
     uint8_t p_last = 0;   // ... its caller-supplied last byte
     int p_have_last = 0;
     size_t p_nlay = 0;    // the token count the stage-2 arrays were laid out for (>= p_n)

@@ -624,14 +624,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     const u64 end = lead + len;
     u64 kp[CH][4];
 
-    // The first tile of a block is its own index: the grid holds no more blocks than the device runs at once and the
-    // dispatcher starts workgroups in index order, so every tile in front of it belongs to a block that is resident or
-    // through (the look-back's forward-progress condition) -- and nobody queues up on the ticket counter at launch (every
-    // block of the grid drew its first ticket there: one atomic round trip in front of the first load).  Later tiles
-    // are drawn from the counter, which counts from gridDim.x on.
-    if (tid == 0) s_ticket[0] = blockIdx.x;
+    // The first tile of a block: its own index if the whole message is ONE round of tiles (num_tiles <= gridDim.x: every
+    // tile in front of a block's tile then belongs to a block with a lower index, which the dispatcher started earlier, so
+    // it is resident or through -- the look-back's forward-progress condition -- and nobody queues up on the ticket
+    // counter in front of its first load: -3 us per launch, which matters for exactly these documents).  A message of
+    // several rounds draws EVERY tile from the counter: tiles then start in id order whatever else runs on the device.
+    // (Round 4 gave every block a static first tile; with a second kernel holding compute units a block could then draw
+    // a later ticket and look back on tiles of blocks that had not been dispatched yet -- a bounded spin, i.e. a
+    // spurious "internal error", with several >256-tile parses in flight on one device.)
+    const bool one_round = num_tiles <= gridDim.x;  // (uniform over the grid)
+    const u32 tk_base = one_round ? gridDim.x : 0u;
+    if (tid == 0) s_ticket[0] = one_round ? blockIdx.x : atomicAdd(&st->tile_counter, 1u);
     __syncthreads();
-    const u32 t_first = blockIdx.x;
+    const u32 t_first = uniform(s_ticket[0]);
     if (t_first >= num_tiles) {
         block_done(st, aux, base + lead, len);
         return;
@@ -662,8 +667,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const int mf = ma ^ 1, uf = ua == 0 ? 2 : ua - 1;        // ... of T(j-1)
         u32 tk1 = 0, tk2 = 0;  // tickets drawn now (lane 0 of wave 0); they return while phase A runs
         if (tid == 0) {
-            if (first) tk1 = gridDim.x + atomicAdd(&st->tile_counter, 1u);
-            if (has_a) tk2 = gridDim.x + atomicAdd(&st->tile_counter, 1u);
+            if (first) tk1 = tk_base + atomicAdd(&st->tile_counter, 1u);
+            if (has_a) tk2 = tk_base + atomicAdd(&st->tile_counter, 1u);
         }
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);

@@ -32,6 +32,7 @@
 #include "sj_number.h"
 #include "sj_stage2.h"
 #include "sj_strings.h"
+#include "sj_tok16.h"
 
 namespace sj {
 
@@ -110,6 +111,7 @@ struct S2Dev {
                               // changes -- cleared with the unit's count, set by k_str_measure; k_str_emit compacts only those units
     u64 units;
     u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
+    u32 variant;  // 1 (default): the token pass on bit planes (sj_tok16.h); 0: the per-token kernels of rounds 1-4 (SJHIP_S2_VARIANT)
 };
 #if defined(SJ_EXP)
 #define SJ_EXPBIT(p, b) ((((p).exp >> (b)) & 1u) != 0)
@@ -821,11 +823,8 @@ __global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
 // to its scan aggregate.
 // (WithCopyStrings(false) launches the halves one behind the other: the token half then measures the strings from the
 // records the string half leaves.)
-__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
-    __shared__ GenUnit s_gu[RD_BLOCK / 64];
-    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
-    else s2_reduce_body(p, blockIdx.x - mblocks);
-}
+__device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block);
+__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks);
 
 // ---- pass 2: exclusive scan over the tile aggregates (in place) + totals: SCAN_SEGS blocks ---------------------
 // Inside a segment every thread owns K consecutive tiles (K <= 32 per round), so a block scans once per round
@@ -1225,6 +1224,435 @@ __global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 6) void k_s2_emit(S2Dev p) {
     if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
 }
 
+__device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); }  // m != 0
+
+// ==== round 5: the token pass on bit planes, sixteen tokens per lane (sj_tok16.h) ====================================
+// k_measure's token half and k_s2_emit in their plane form.  A tile is still 4096 tokens (the packed scan form PAgg and
+// the tile aggregates are unchanged); a block is 256 threads x 16 tokens.  What changed against the per-token kernels
+// above (kept as variant 0 for A/B runs, SJHIP_S2_VARIANT):
+//   * the scan element of a lane comes from ~150 boolean instructions on 19-bit windows of the kind planes instead of 16
+//     table look-ups (sj_tok16.h); per-token work is left only for tokens that write something;
+//   * queue slots (strings, scalars) and the tile's bracket list are ORDERED: their indices come out of the same block
+//     scan as the tape offsets -- no LDS atomics;
+//   * brackets are matched INSIDE the tile: the tile's brackets wait in LDS (one packed word each: tape offset, depth,
+//     kind, gap set), a wave answers the previous-smaller-value questions of 64 of them with ballots over the list, and a
+//     pair whose two ends lie in the tile is written here, next to the other words of its stretch of the tape (the
+//     device-wide matcher wrote every pair as two scattered 8-byte stores into lines that had long left the L2: 72 MB of
+//     sector writes and 84 MB of reads for 17 MB of words on configs[1], 95 + 28 MB on configs[4]).  Only brackets whose
+//     container starts in front of the tile stay "live" in the compact view (sj_tok16.h BR_DONE): k_br_match skips the rest.
+static constexpr int TK_BLOCK = 256, TK_ITEMS = 16, TK_WAVES = TK_BLOCK / 64;
+static_assert(TK_BLOCK * TK_ITEMS == S2_TILE, "256 lanes of sixteen tokens are one tile");
+
+struct TileLane {
+    Lane16 m;
+    u32 base;  // token index of the lane's first token
+};
+// The sixteen kinds of this thread (K_NL behind the end of the message, like token_pelement's sentinel), the neighbours'
+// kinds through s_edge (TK_BLOCK + 2 words: [1 + tid] = kind 14 | kind 15 << 8 | kind 0 << 16 of thread tid), the masks.
+// Contains one __syncthreads().
+__device__ __forceinline__ TileLane tile_lane(const S2Dev &p, u32 t0, u32 n, int tid, u32 *s_edge) {
+    TileLane r;
+    r.base = t0 + (u32)tid * TK_ITEMS;
+    constexpr u32 NL4 = 0x01010101u * K_NL;
+    uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
+    if (r.base + TK_ITEMS <= n) {
+        kv = *reinterpret_cast<const uint4 *>(arr_at(p.kind, r.base, 16));
+    } else if (r.base < n) {
+        u32 d[4] = {NL4, NL4, NL4, NL4};
+        for (u32 j = 0; r.base + j < n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[r.base + j] << (8 * (j & 3)));
+        kv = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    s_edge[1 + tid] = (kv.w >> 16) | ((kv.x & 0xffu) << 16);
+    if (tid == 0) s_edge[0] = t0 == 0 ? (u32)K_NONE | ((u32)K_NONE << 8) : (u32)p.kind[t0 - 2] | ((u32)p.kind[t0 - 1] << 8);
+    if (tid == 1) s_edge[1 + TK_BLOCK] = ((u64)t0 + S2_TILE < n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL) << 16;
+    __syncthreads();
+    const u32 prev2 = s_edge[tid] & 0xffffu, next1 = (s_edge[tid + 2] >> 16) & 0xffu;
+    const u32 cnt = n > r.base ? (n - r.base < (u32)TK_ITEMS ? n - r.base : (u32)TK_ITEMS) : 0u;
+    r.m = lane16_masks(planes16(kv.x, kv.y, kv.z, kv.w), prev2, next1, (1u << cnt) - 1u, r.base == 0 && cnt != 0);
+    return r;
+}
+
+// ---- pass 1 on planes: tile aggregates ------------------------------------------------------------------------------
+__device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
+    __shared__ u32 s_edge[TK_BLOCK + 2];
+    __shared__ PAgg s_w[TK_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 n = token_count(p);
+    if ((u64)block * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
+    const u32 t0 = block * S2_TILE;
+    const TileLane tl = tile_lane(p, t0, n, tid, s_edge);
+    const Lane16 &m = tl.m;
+    const u32 base = tl.base;
+    // selective copy (WithCopyStrings(false)): the Strings.B bytes of the strings that unescaping changes go through the
+    // scan; their lengths come from k_str_measure (emit masks) or, in the fallback, from a walk per string
+    u32 sbytes = 0;
+    if (p.sv.qm && !p.copy_strings) {
+        u32 dv[TK_ITEMS];
+        if (base + TK_ITEMS <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
+                dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TK_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; k++)
+            sbytes += (((m.str >> k) & 1u) && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
+    } else if (!p.sv.qm) {
+        const MsgView mv{p.msg, p.len};
+        for (u32 r = m.str; r != 0; r &= r - 1) {
+            const u32 k = (u32)__builtin_ctz(r);
+            u32 sl, dl, out;
+            if (!string_walk(mv, p.pos[base + k], nullptr, &sl, &dl)) {
+                out = DLEN_INVALID;
+                atomicOr(&p.st->err, 1u);
+            } else {
+                const bool cp = p.copy_strings || sl != dl;
+                out = dl | (cp ? DLEN_COPY : 0u);
+                sbytes += cp ? dl : 0u;
+            }
+            p.dlen[base + k] = out;
+        }
+    }
+    PAgg acc = lane16_pagg(m);
+    acc.s = sbytes;
+    const PAgg incl = pagg_wave_inclusive<true>(acc);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        PAgg tot = s_w[0];
+        for (int w = 1; w < TK_WAVES; w++) tot = pagg_comb<true>(tot, s_w[w]);
+        p.agg[block].a = pagg_unpack(tot);
+    }
+}
+
+__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
+    __shared__ GenUnit s_gu[RD_BLOCK / 64];
+    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
+    else if (p.variant) s2_reduce_planes(p, blockIdx.x - mblocks);
+    else s2_reduce_body(p, blockIdx.x - mblocks);
+}
+
+// ---- pass 3 on planes -----------------------------------------------------------------------------------------------
+// queue entry of a string / scalar: token index inside the tile | tape offset inside the tile << 12 | (string: object key
+// << 25) | (scalar: kind - 8 << 26)
+template <bool MASKS>
+__global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
+    __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
+    // strings [0, S) | the tile's brackets [S, S + B) | atoms and numbers [S + B, S + B + D): a tile has 4096 tokens
+    __shared__ u32 s_q[S2_TILE];
+    __shared__ u32 s_edge[TK_BLOCK + 2];
+    __shared__ PAgg s_w[TK_WAVES];
+    __shared__ u32 s_wc[TK_WAVES];
+    __shared__ i32 s_gmin[S2_TILE / 64];
+    __shared__ u32 s_nnum, s_base, s_fill, s_ccnt, s_cbase, s_cfill;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 n = token_count(p);
+    if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
+    const u32 t0 = blockIdx.x * S2_TILE;
+    const u64 tape_len = p.st->tape_len;
+    if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
+    if (tid == 0) s_nnum = s_fill = s_ccnt = s_cfill = 0;
+    const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
+    const u32 endpos = (u32)p.len;
+    {
+        const u32 base = t0 + (u32)tid * TK_ITEMS;
+        u32 pp[TK_ITEMS];
+        if (base + TK_ITEMS <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base + 4 * q, 4));
+                pp[4 * q] = a.x; pp[4 * q + 1] = a.y; pp[4 * q + 2] = a.z; pp[4 * q + 3] = a.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TK_ITEMS; k++) pp[k] = base + k < n ? p.pos[base + k] : endpos;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<uint4 *>(&s_pos[tid * TK_ITEMS + 4 * q]) = make_uint4(pp[4 * q], pp[4 * q + 1], pp[4 * q + 2], pp[4 * q + 3]);
+        if (tid == 2) s_pos[S2_TILE] = (u64)t0 + S2_TILE < n ? p.pos[t0 + S2_TILE] : endpos;
+    }
+    const TileLane tl = tile_lane(p, t0, n, tid, s_edge);  // (holds the block barrier behind the stores above)
+    const Lane16 &m = tl.m;
+    const u32 base = tl.base;
+    const MsgView mv{p.msg, p.len};
+    // selective copy: the measured lengths of the lane's strings -> Strings.B bytes of the lane, and (below) every copied
+    // string's offset
+    u32 dv[TK_ITEMS];
+    u32 sbytes = 0;
+    if (!MASKS) {
+        if (base + TK_ITEMS <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
+                dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TK_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; k++) {
+            dv[k] = (((m.str >> k) & 1u) && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
+            sbytes += dv[k];
+        }
+    }
+    // ---- the scan inside the tile: tape words, brackets, opens, records, context function (+ Strings.B bytes), and the
+    // queue slots: strings | scalars << 13
+    PAgg mine = lane16_pagg(m);
+    const u32 cnts = lane16_counts(m);
+    mine.s = MASKS ? cnts : sbytes;
+    PAgg total;
+    const PAgg ex = pagg_block_exclusive<true, TK_WAVES>(mine, s_w, lane, wave, total);
+    u32 cex = ex.s, ctot = total.s;
+    if (!MASKS) {  // the scan's s field carries bytes: the slots get a scan of their own
+        const u32 incl = wave_incl_sum(cnts);
+        if (lane == 63) s_wc[wave] = incl;
+        u32 nc = 0;
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; k++) nc += dv[k] != 0u ? 1u : 0u;
+        nc = wave_incl_sum(nc);
+        if (lane == 63 && nc) atomicAdd(&s_ccnt, nc);  // the tile's strings that k_emit_strings will copy
+        __syncthreads();
+        cex = incl - cnts;
+        ctot = 0;
+#pragma unroll
+        for (int w = 0; w < TK_WAVES; w++) {
+            const u32 x = s_wc[w];
+            cex += w < wave ? x : 0u;
+            ctot += x;
+        }
+    }
+    {  // numbers of the tile (their slots in the global queue are drawn with one atomic per tile)
+        const u32 nn = wave_incl_sum(popc32(m.num));
+        if (lane == 63 && nn) atomicAdd(&s_nnum, nn);
+    }
+    const u32 S = ctot & 0x1fffu, D = ctot >> 13, B = total.x >> 14;
+    const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
+    const u32 lane_w = ex.x & 0x3fffu, lane_bc = ex.x >> 14, lane_open = ex.y & 0x1fffu, lane_nb = ex.y >> 13;
+    bool bad = lane16_illegal(m);  // a token that is legal in no context at all
+    {
+        u32 slot = cex & 0x1fffu, run = ex.s;
+        for (u32 r = m.str; r != 0; r &= r - 1) {  // strings: worked on densely below
+            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * TK_ITEMS + j;
+            s_q[slot++] = idx | ((lane_w + lane16_words_before(m, j)) << 12) | (((m.keystr >> j) & 1u) << 25);
+            if (!MASKS) {  // the Strings.B offset of the string inside the tile, in the slot of the token's own position
+                s_pos[idx] = run;  // (the dense pass reads the position back from memory: no LDS of its own)
+                u32 c = 0;
+#pragma unroll
+                for (int k = 0; k < TK_ITEMS; k++) c = (u32)k == j ? dv[k] : c;
+                run += c;
+            }
+        }
+    }
+    {
+        u32 slot = S + B + (cex >> 13);
+        for (u32 r = m.num | m.atom; r != 0; r &= r - 1) {
+            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * TK_ITEMS + j;
+            const u32 kd = ((m.num >> j) & 1u) ? (u32)K_NUM : (u32)lane16_atom_kind(m, j);
+            s_q[slot++] = idx | ((lane_w + lane16_words_before(m, j)) << 12) | ((kd - 8u) << 26);
+        }
+    }
+    {
+        u32 slot = S + lane_bc;
+        const u32 am_in = am_combine(tp.am, ex.z);
+        for (u32 r = m.br; r != 0; r &= r - 1) {
+            const u32 j = (u32)__builtin_ctz(r), upto = (2u << j) - 1u;
+            const i32 drel = (i32)(2u * (lane_open + popc32(m.open & upto))) - (i32)(lane_bc + popc32(m.br & upto));  // behind the bracket
+            s_q[slot++] = tbr_pack(lane_w + lane16_words_before(m, j), drel, lane16_bracket_kind(m, j), lane16_gap_set(m, j, am_in));
+        }
+    }
+    for (u32 r = m.nlr; r != 0; r &= r - 1) {  // record-separating newlines leave their tape offset (query.hip)
+        const u32 j = (u32)__builtin_ctz(r);
+        p.nl_off[tp.nb + lane_nb + popc32(m.nlr & ((1u << j) - 1u))] = T0 + lane_w + lane16_words_before(m, j);
+    }
+    __syncthreads();  // the queues and the bracket list are complete
+    // ---- strings: Strings.B offset and unescaped length from the emit masks (sj_strings.h), both tape words in one
+    // 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
+    if (MASKS) {
+        for (u32 j = (u32)tid; j < S; j += TK_BLOCK) {
+            const u32 v = s_q[j], idx = v & 0xfffu, lo = (v >> 12) & 0x1fffu;
+            const u64 a0 = (u64)s_pos[idx] + p.sv.lead + 1, a1 = (u64)s_pos[idx + 1] + p.sv.lead;
+            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
+            const u32 b0 = (u32)a0 & 63u, b1 = (u32)a1 & 63u;
+            // absolute Strings.B offset of the chunk (left by k_str_emit, or unit prefix + bytes of the unit in front) + inside
+            const u64 c0 = p.no_abs ? (u64)p.unit_cnt[a0 >> 12] + (r0.pre & CHUNK_PRE_MASK) : (u64)r0.abs;
+            const u64 c1 = p.no_abs ? (u64)p.unit_cnt[a1 >> 12] + (r1.pre & CHUNK_PRE_MASK) : (u64)r1.abs;
+            const u64 so = c0 + (u64)popc64(r0.em & ~(~0ull << b0));
+            const u64 se = c1 + (u64)popc64(r1.em & ~(~0ull << b1));
+            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
+            *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+            if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
+        }
+    }
+    // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
+    // a string that unescaping changed points into Strings.B and is queued for k_emit_strings with everything that kernel
+    // needs, the others point into the message (parseString, stage2_build_tape_amd64.go:90-109)
+    if (!MASKS) {
+        if (tid == 0 && s_ccnt != 0 && p.sv.qm) s_cbase = atomicAdd(&p.st->str_count, s_ccnt);
+        __syncthreads();
+        for (u32 j0 = 0; j0 < S; j0 += TK_BLOCK) {  // (block-uniform trip count: the ballots below want whole waves)
+            const u32 j = j0 + (u32)tid;
+            bool queue = false;
+            u32 at = 0, so = 0, len = 0;
+            if (j < S) {
+                const u32 v = s_q[j], idx = v & 0xfffu, lo = (v >> 12) & 0x1fffu;
+                const u32 dlw = p.dlen[t0 + idx];
+                at = p.pos[t0 + idx];
+                so = tp.s + s_pos[idx];
+                if (dlw != DLEN_INVALID) {
+                    const bool cp = (dlw & DLEN_COPY) != 0;
+                    len = dlw & ~DLEN_COPY;
+                    const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = len;
+                    *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                    if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
+                    if (!p.sv.qm) p.str_off[t0 + idx] = so;  // (per-string walks: k_emit_strings looks the offset up per token)
+                    queue = cp && len != 0 && p.sv.qm;
+                }
+            }
+            // queue slots inside the tile's range: one LDS atomic per wave and pass, the lanes take consecutive entries
+            const u64 qm = __ballot(queue);
+            if (qm != 0) {
+                u32 qbase = 0;
+                if (lane == 0) qbase = atomicAdd(&s_cfill, (u32)__popcll(qm));
+                qbase = s_cbase + (u32)__builtin_amdgcn_readfirstlane((int)qbase);
+                const u32 slot = qbase + (u32)__popcll(qm & ((1ull << lane) - 1ull));
+                if (queue && slot < p.strq_cap) p.strq[slot] = make_uint4(at, so, len, 0u);
+            }
+        }
+    }
+    // ---- atoms: validated from the 8 message bytes at the token; numbers: a plain integer of up to 18 digits is parsed
+    // here (sj_number.h parse_int_fast), the others move to the global queue (k_numbers; the order does not matter)
+    {
+        const u32 cnt = s_nnum;
+        if (cnt != 0 && tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
+        if (cnt != 0) __syncthreads();  // (block-uniform)
+        const u32 qb = s_base;
+        for (u32 j = (u32)tid; j < D; j += TK_BLOCK) {
+            const u32 v = s_q[S + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+            const u8 ak = (u8)(8u + ((v >> 26) & 3u));
+            if (ak == K_NUM) {
+                u64 iv = 0;
+                const bool fast = parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
+                if (fast) {
+                    const u64 tw = (u64)'l' << 56;
+                    *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
+                }
+                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(fast ? 0xffffffffu : at, o);
+            } else {
+                bad |= !atom_valid_word(load8_guarded(mv, at), p.len - at, ak);
+                p.tape[o] = atom_word(ak);
+            }
+        }
+    }
+    // ---- brackets: matched inside the tile (sj_stage2.h bracket_resolve is the per-bracket statement, k_br_match the
+    // device-wide form).  One rule for every bracket: the container of the gap in front of it -- the partner of a close, the
+    // parent of an open -- is the bracket behind the last one in front with depth <= (depth in front - 1).  Depths here are
+    // relative to the tile's start; a question that no bracket of the tile answers stays for k_br_match.
+    {
+        const u32 G = (B + 63u) / 64u;
+        for (u32 g = (u32)wave; g < G; g += TK_WAVES) {  // the minimum depth of every group of 64
+            const u32 c = g * 64u + (u32)lane;
+            i32 v = c < B ? tbr_depth(s_q[S + c]) : 0x7fffffff;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const i32 o = __shfl_xor(v, sft, 64);
+                v = o < v ? o : v;
+            }
+            if (lane == 0) s_gmin[g] = v;
+        }
+        __syncthreads();
+        const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
+        for (u32 g = (u32)wave; g < G; g += TK_WAVES) {  // wave-uniform
+            const u32 c = g * 64u + (u32)lane;
+            const bool valid = c < B;
+            const u32 e = valid ? s_q[S + c] : 0u;
+            const i32 drel = valid ? tbr_depth(e) : 0x7fffffff;
+            const u8 kd = tbr_kind(e);
+            const u32 gap = tbr_gap(e), oc = T0 + tbr_off(e);
+            const bool close = is_close(kd);
+            const i32 q = close ? drel : drel - 2;  // depth in front of the bracket - 1 (relative)
+            const bool root = valid && tp.d + q < 0;  // nothing is open in front of it: the root context
+            const bool need = valid && !root;
+            i32 res = -1;      // index (inside the tile) of the bracket in front of the partner / parent
+            bool pend = need;  // not answered yet
+            // inside the group: one ballot per distinct q (the last bracket in front with depth == q, see k_br_match)
+            for (u64 pm = __ballot(pend); pm != 0;) {
+                const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pm));
+                const u64 at = __ballot(drel == v) & lt;
+                const bool mine = need && q == v;
+                if (mine && at != 0) {
+                    res = (i32)(g * 64u) + top_bit(at);
+                    pend = false;
+                }
+                pm &= ~__ballot(mine);
+            }
+            // the groups in front, nearest first -- only those that hold a depth as low as the lowest question left
+            u64 pm = __ballot(pend);
+            if (pm != 0 && g > 0) {
+                i32 qmax = pend ? q : (i32)0x80000000;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const i32 o = __shfl_xor(qmax, sft, 64);
+                    qmax = o > qmax ? o : qmax;
+                }
+                u64 cand = __ballot((u32)lane < g && s_gmin[(u32)lane < g ? lane : 0] <= qmax);
+                while (cand != 0 && pm != 0) {
+                    const u32 gp = (u32)top_bit(cand);
+                    cand &= ~(1ull << gp);
+                    const i32 dprev = tbr_depth(s_q[S + gp * 64u + (u32)lane]);  // (a group in front is full)
+                    for (u64 pp = pm; pp != 0;) {
+                        const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pp));
+                        const u64 at = __ballot(dprev <= v);
+                        const bool mine = pend && q == v;
+                        if (mine && at != 0) {
+                            res = (i32)(gp * 64u) + top_bit(at);
+                            pend = false;
+                        }
+                        pp &= ~__ballot(mine);
+                    }
+                    pm = __ballot(pend);
+                }
+            }
+            if (!valid) continue;
+            bool done = false;
+            if (root) {  // (a close is rejected here: it needs OBJ / ARR)
+                bad |= !context_allowed(gap, CTX_ROOT);
+                done = true;
+            } else if (res >= 0) {
+                const u32 ej = s_q[S + (u32)res + 1u];  // partner (close) / parent (open)
+                const u8 jk = tbr_kind(ej);
+                bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
+                done = true;
+                if (close) {  // payloads: annotate_previousloc (stage2_build_tape_amd64.go:335-336)
+                    const u32 oj = T0 + tbr_off(ej);
+                    const u64 wc = ((u64)(kd == K_CLOSE_OBJ ? '}' : ']') << 56) | (p.tape_base + oj);
+                    const u64 wj = ((u64)(jk == K_OPEN_OBJ ? '{' : '[') << 56) | (p.tape_base + oc + 1);
+                    if (tp.d + drel == 0) {  // a record: the root word in front of its open bracket and the one behind its close bracket
+                        const u64 ro = ((u64)'r' << 56) | (p.tape_base + oc + 2), rc = ((u64)'r' << 56) | (p.tape_base + oj - 1);
+                        *reinterpret_cast<uint4 *>(arr_at(p.tape, (u64)oj - 1, 2)) = make_uint4((u32)ro, (u32)(ro >> 32), (u32)wj, (u32)(wj >> 32));
+                        *reinterpret_cast<uint4 *>(arr_at(p.tape, oc, 2)) = make_uint4((u32)wc, (u32)(wc >> 32), (u32)rc, (u32)(rc >> 32));
+                    } else {
+                        p.tape[oc] = wc;
+                        p.tape[oj] = wj;
+                    }
+                }
+            }
+            // the compact bracket view of the whole message: every bracket keeps its depth (the matcher's questions pass
+            // over it), only the live ones ask and write there
+            const u32 cg = tp.bc + c;
+            p.br_depth[cg] = tp.d + drel;
+            p.br_off[cg] = oc;
+            p.br_info[cg] = (u8)(kd | (gap << 4) | (done ? BR_DONE : 0u));
+        }
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
+}
+
 // ---- numbers (parseNumber, parse_number.go:65-135): one queued number per lane ------------------------------------
 // The first 32 bytes of each number go to LDS (two unaligned 16-byte loads instead of one dependent byte load
 // per digit); longer numbers fall back to the message itself.
@@ -1359,7 +1787,6 @@ __global__ __launch_bounds__(1024) void k_min_upper(S2Dev p) {
 // in between are deeper, so a wave answers the 64 questions of one group with ballots over its own 64 depths
 // (no memory traffic, no serial walk); what is not answered inside the group is looked up in the group in
 // front and then through the min tree, the whole wave loading 64 entries per step.
-__device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); }  // m != 0
 
 // last k < `idx` with lev[L][k] <= v, resolved down to level 0 (wave-cooperative, uniform arguments); -1: none
 __device__ i64 wave_psv_tree(const MinTree &mt, int L, u64 idx, i32 v, int lane) {
@@ -1428,8 +1855,10 @@ __device__ __forceinline__ void br_match_body(const S2Dev &p, u32 bid, u32 nb) {
     Group nx = load_group(g);
     for (; (u64)g * 64 < n_br; g += waves) {  // wave-uniform
         const u32 c = g * 64 + (u32)lane;
-        const bool valid = c < n_br;
         const Group cur = nx;
+        // (a bracket whose container lies in its own tile was resolved there, k_s2_emit_planes: it keeps its depth for the
+        // questions that pass over it and asks nothing itself)
+        const bool valid = c < n_br && !(cur.info & BR_DONE);
         nx = load_group(g + waves);
         const i32 dep = cur.dep, pd = cur.pd;
         const u8 info = cur.info;
@@ -1468,7 +1897,7 @@ __device__ __forceinline__ void br_match_body(const S2Dev &p, u32 bid, u32 nb) {
             }
         }
         if (!valid) continue;
-        const u32 gap = (u32)(info >> 4);  // contexts the gap that ends with this bracket allows
+        const u32 gap = (u32)(info >> 4) & 7u;  // contexts the gap that ends with this bracket allows
         if (q < 0) {  // nothing is open in front of it: the root context (a close needs OBJ / ARR and is rejected)
             bad |= !context_allowed(gap, CTX_ROOT);
             continue;
@@ -1672,6 +2101,10 @@ static S2Dev stage2_view(const S2Args &a) {
     p.unit_copy = nullptr;
     p.units = 0;
     p.exp = 0;
+    {
+        static const int v = getenv("SJHIP_S2_VARIANT") ? atoi(getenv("SJHIP_S2_VARIANT")) : 1;
+        p.variant = v != 0;
+    }
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
 #endif
@@ -1747,8 +2180,13 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     } else if (p.sv.qm && !beside) {
         hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     }
-    if (masks_copy) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
-    else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    if (p.variant) {
+        if (masks_copy) hipLaunchKernelGGL(k_s2_emit_planes<true>, dim3(p.tiles), dim3(TK_BLOCK), 0, a.stream, p);
+        else hipLaunchKernelGGL(k_s2_emit_planes<false>, dim3(p.tiles), dim3(TK_BLOCK), 0, a.stream, p);
+    } else {
+        if (masks_copy) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+        else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
+    }
     if (late) {
         const hipError_t e = fork_strings();
         if (e != hipSuccess) return e;

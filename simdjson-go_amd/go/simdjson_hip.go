@@ -615,7 +615,13 @@ func parseNDStreamHip(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson, 
 					v.Message = unsafe.Slice((*byte)(unsafe.Pointer(out.message)), ml)
 				}
 				res <- Stream{Value: v}
-				<-reuse
+				if _, ok := <-reuse; !ok {
+					// the consumer closed `reuse` (legal with ParseNDStream): that is NOT a hand-back -- the value it
+					// still holds aliases this block, so the block must not be recycled under it.  Stop here.
+					close(stop)
+					res <- Stream{Error: errors.New("ParseNDStreamInPlace: reuse channel closed while a delivered value aliases the stream's memory")}
+					return
+				}
 				C.sjhip_stream_release(st)
 				notify(freed)
 				continue

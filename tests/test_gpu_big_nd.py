@@ -75,6 +75,12 @@ def test_sharded_inside_parse_equals_oracle(small_limits):
             if rc == 0:
                 tape, strings = ctx.fetch(tl, sl)
                 assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings), (what, copy, "device")
+    # the merged result read in place (sjhip_fetch_view sizes its view from the context: the sharded path sets the totals)
+    doc = park * 16
+    ref = O.parse(doc, ndjson=True)
+    pj = ctx.parse(doc, ndjson=True, view=True)
+    assert len(pj.Tape) == len(ref.tape) and len(pj.Strings) == len(ref.strings)
+    assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), "view of a sharded ND result"
     # below the threshold nothing changes, and the context goes back and forth between the two paths
     small = park * 2
     ref = O.parse(small, ndjson=True)
