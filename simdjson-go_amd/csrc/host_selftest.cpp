@@ -371,6 +371,21 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             const u32 next1 = g0 + 16 < n ? kind[g0 + 16] : (u32)K_NL;
             const u32 valid = cnt == 16 ? 0xffffu : ((1u << cnt) - 1u);
             const Lane16 lm = lane16_masks(pl, prev2, next1, valid, g0 == 0);
+            for (u32 h = 0; h < 2; h++) {  // the eight-token form of the lane on either half: the same masks
+                const size_t h0 = g0 + 8 * h;
+                if (h0 >= n) break;
+                const u32 c8 = (u32)(n - h0 < 8 ? n - h0 : 8);
+                const Planes16 p8 = planes16(w4[2 * h], w4[2 * h + 1], 0u, 0u);
+                const u32 pv = (u32)(h0 >= 2 ? kind[h0 - 2] : (u8)K_NONE) | ((u32)(h0 >= 1 ? kind[h0 - 1] : (u8)K_NONE) << 8);
+                const Lane16 l8 = lane16_masks<8>(p8, pv, h0 + 8 < n ? kind[h0 + 8] : (u32)K_NL, (1u << c8) - 1u, h0 == 0);
+                const u32 sh = 8 * h, mk = 0xffu;
+                if (l8.w1 != ((lm.w1 >> sh) & mk) || l8.w2 != ((lm.w2 >> sh) & mk) || l8.br != ((lm.br >> sh) & mk) || l8.open != ((lm.open >> sh) & mk) ||
+                    l8.nlr != ((lm.nlr >> sh) & mk) || (l8.a_root & mk) != ((lm.a_root >> sh) & mk) || (l8.a_obj & mk) != ((lm.a_obj >> sh) & mk) ||
+                    (l8.a_arr & mk) != ((lm.a_arr >> sh) & mk) || l8.gap_start != ((lm.gap_start >> sh) & mk) || l8.str != ((lm.str >> sh) & mk) ||
+                    l8.keystr != ((lm.keystr >> sh) & mk) || l8.num != ((lm.num >> sh) & mk) || l8.atom != ((lm.atom >> sh) & mk) ||
+                    (l8.b0 & mk) != ((lm.b0 >> sh) & mk) || (l8.b1 & mk) != ((lm.b1 >> sh) & mk) || (l8.a_root >> 8) != 0xffu)
+                    return 88;
+            }
             Agg fold = agg_identity();
             bool illegal = false;
             for (u32 j = 0; j < cnt; j++) {

@@ -61,15 +61,18 @@ struct Lane16 {  // bit j = token j of the lane (16 bits each)
     u32 b0, b1;                 // planes 0 and 1 of the own tokens (the kind of a bracket or an atom from two bits)
     u32 valid;
 };
-// prev2 = kind[-2] | kind[-1] << 8 (K_NONE in front of the message), next1 = kind[16] (K_NL behind the message);
-// valid = the lane's tokens that exist (a prefix of the 16 bits); first = token 0 of the lane is token 0 of the message
+// prev2 = kind[-2] | kind[-1] << 8 (K_NONE in front of the message), next1 = kind[N] (K_NL behind the message);
+// valid = the lane's tokens that exist (a prefix of the N bits); first = token 0 of the lane is token 0 of the message.
+// N = tokens the lane owns (16, or 8: the kinds of tokens 8 .. 15 are then zero and `valid` has at most eight bits)
+template <int N = 16>
 SJ_HD Lane16 lane16_masks(const Planes16 &pl, u32 prev2, u32 next1, u32 valid, bool first) {
+    static_assert(N == 8 || N == 16, "a lane owns eight or sixteen tokens");
     // windows: bit i = token i - 2
     u32 W[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const u32 own = p & 1 ? ((p & 2 ? pl.p23 : pl.p01) >> 16) : ((p & 2 ? pl.p23 : pl.p01) & 0xffffu);
-        const u32 nb = ((prev2 >> p) & 1u) | (((prev2 >> (8 + p)) & 1u) << 1) | (((next1 >> p) & 1u) << 18);
+        const u32 nb = ((prev2 >> p) & 1u) | (((prev2 >> (8 + p)) & 1u) << 1) | (((next1 >> p) & 1u) << (N + 2));
         W[p] = (own << 2) | nb;
     }
     const u32 b0 = W[0], b1 = W[1], b2 = W[2], b3 = W[3];

@@ -30,6 +30,7 @@
 #include "sj_chunk.h"
 #include "sj_device.h"
 #include "sj_stage2.h"
+#include "sj_strings.h"
 
 namespace sj {
 
@@ -41,6 +42,14 @@ struct S1Aux {
     Arr<u8> unit_h;
     Arr<u64> unit_slow;  // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
     Arr<u8> kind;        // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
+    // round 5: the flatten of a tile -- the first place that knows the state at the start of every unit -- also leaves what the
+    // string half of k_measure (stage2.hip str_masks_body) computed from the three masks above for every chunk without a
+    // \u escape: the 16-byte record {emit mask, emitted bytes of the unit in front of the chunk | CHUNK_SLOW} and the unit's
+    // byte count.  k_measure then only visits the units that unit_slow flags (none on twitter.json / parking-citations: the
+    // masks are never read from HBM again, and 101 + 67 MB of reads and writes of configs[1] are gone with the pass).
+    Arr<ChunkRec> rec;
+    Arr<u32> unit_cnt;
+    Arr<u8> unit_copy;   // cleared here (WithCopyStrings(false): k_str_measure marks the units to compact)
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
@@ -390,6 +399,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         u64 quote_bits = c.quote;
         u64 starters = 0;  // backslashes that begin an escape sequence
         u64 nonsimple = 0; // escaped characters other than " \\ / b f n r t
+        u32 carry_bit = 0; // the chunk's first byte is escaped by a backslash at the end of the chunk in front
         const u32 bs_any = (u32)c.bs | (u32)(c.bs >> 32);
         if (__ballot(bs_any != 0) != 0 || carry0 != 0) {  // wave-uniform: many waves see no backslash at all
             const bool all_bs = c.bs == ~0ull;
@@ -398,6 +408,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64, end);
             const u64 escaped = escaped_mask(c.bs, carry_in);
             quote_bits &= ~escaped;
+            carry_bit = carry_in & 1u;
             if (AUX) {
                 starters = c.bs & ~escaped;
                 nonsimple = escaped & ~c.esc1;
@@ -438,7 +449,9 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
                         (__ballot(((u32)in_b | (u32)(in_b >> 32)) != 0) != 0 ? 2u : 0u);
         // unit totals of both counts at once (16-bit fields: a wave holds <= 4096 bits)
         const u32 incl = wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16));
-        pre[k * 64 + lane] = incl;  // flatten needs the lane's offset inside the unit: kept instead of scanned again
+        // flatten needs the lane's offset inside the unit: kept instead of scanned again (13 bits per hypothesis; bit 15: the
+        // carry into the chunk, for the emit-mask records the whole parse leaves in flatten_tile)
+        pre[k * 64 + lane] = AUX ? incl | (carry_bit << 15) : incl;
         const u32 tot = lane63(incl);
         if (lane == 0)
             s_unit[k * WAVES + wave] =
@@ -473,7 +486,7 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 template <int BLOCK, int CH, bool KIND>
 __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, SJ_ARR_PARAM(u32) out_pos, u64 pos_cap,
-                                             u64 &tile_end, Arr<u8> unit_h, u64 len_, Arr<u8> kind_out) {
+                                             u64 &tile_end, Arr<u8> unit_h, u64 len_, Arr<u8> kind_out, const S1Aux &aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // the window that held the masks (CH * 2 * 64 u64) stages the positions of a unit: 32-bit positions, or (KIND)
@@ -491,6 +504,23 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
 
     const bool err = lane < UNITS && ((v >> (26 + hl)) & 1u) != 0;  // any lane: the caller ballots
 
+    // whole parse: the string masks this lane stored for its chunks in phase A, an iteration ago (its own stores: they
+    // come back from the L2) -- requested now, used behind the copy-out of the positions
+    u64 s_qm[CH], s_q[CH], s_st[CH];
+    const bool recs = KIND && aux.rec;  // (uniform)
+    if (recs) {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
+            s_qm[k] = s_q[k] = s_st[k] = 0;
+            if (un != VOID_UNIT && un * 4096 < lead + len_) {
+                const u64 ci = un * 64 + (u64)lane;
+                s_qm[k] = aux.qm[ci];
+                s_q[k] = aux.q[ci];
+                s_st[k] = aux.st[ci];
+            }
+        }
+    }
     u64 sel[CH];
     u32 upto[CH];  // structurals of the unit up to and including this lane's chunk
 #pragma unroll
@@ -498,7 +528,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
         sel[k] = m[(k * 2 + (int)h) * 64 + lane];
         const u32 both = pre[k * 64 + lane];
-        upto[k] = h ? both >> 16 : both & 0xffffu;
+        upto[k] = (h ? both >> 16 : both) & 0x1fffu;
         const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
         if (unit_h && lane == 0 && un * 4096 < lead + len_) unit_h[un] = (u8)h;  // (a void unit lies behind everything)
     }
@@ -590,6 +620,29 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
                 __builtin_amdgcn_wave_barrier();
                 copy_out(C - r0 < CAP ? C - r0 : CAP, g + r0);
                 __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (recs) {
+        // The emit mask of every chunk under the state that is now known (sj_strings.h str_chunk_masks_fast, the branch
+        // that does not touch the message): in-string bytes that are neither quotes nor escape starters; CHUNK_SLOW if an
+        // escaped character lies inside a string (k_str_emit translates it).  Units that hold a \u (or an invalid) escape
+        // are done again by k_measure (unit_slow).
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
+            if (un == VOID_UNIT || un * 4096 >= lead + len_) continue;  // (wave-uniform)
+            const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
+            const u32 carry = (pre[k * 64 + lane] >> 15) & 1u;
+            const u64 sm = (h ? ~s_qm[k] : s_qm[k]) & ~s_q[k];
+            const u64 em = sm & ~s_st[k];
+            const u64 e = ((s_st[k] << 1) | carry) & sm;
+            const u32 n = (u32)popc64(em);
+            const u32 incl = wave_incl_scan(n);
+            aux.rec[un * 64 + (u64)lane] = ChunkRec{em, (incl - n) | (e != 0 ? CHUNK_SLOW : 0u), 0u};
+            if (lane == 63) {
+                aux.unit_cnt[un] = incl;
+                aux.unit_copy[un] = 0;
             }
         }
     }
@@ -730,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             u64 tile_end = 0;
             err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_kpl[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
                                            S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, AUX ? aux.unit_h : Arr<u8>(nullptr), len,
-                                           AUX ? aux.kind : Arr<u8>(nullptr));
+                                           AUX ? aux.kind : Arr<u8>(nullptr), aux);
             if (t_prev == num_tiles - 1 && tid == 0)
                 __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
@@ -969,7 +1022,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, false>(tm, s_mask[mf][wave], nullptr, s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
-                                              wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr));
+                                              wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr), aux);
         if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
@@ -1126,6 +1179,9 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.st = SJ_ARR(a.st, a.chunks, A_S1_ST);
         aux.unit_h = SJ_ARR(a.unit_h, a.units, A_S1_UNIT_H);
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
+        aux.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(a.rec), a.chunks, A_S1_REC);
+        aux.unit_cnt = SJ_ARR(a.unit_cnt, a.units, A_S1_UNIT_CNT);
+        aux.unit_copy = SJ_ARR(a.unit_copy, a.units, A_S1_UNIT_COPY);
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \

@@ -187,13 +187,15 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
         r.h = p.sv.unit_h[u];
         return r;
     };
-    In in = load(unit);
-    for (;;) {
+    // Stage 1's flatten has left the record of every chunk and the count of every unit (stage1.hip flatten_tile, round 5);
+    // what is left for this pass are the units that hold an escaped character no simple escape names -- a \u, whose bytes
+    // may reach into the next chunk, or an invalid escape -- which unit_slow flags: those are done again here, whole.
+    for (;; unit += nwaves) {
+        if (unit >= p.units) return;
+        const u64 sw = p.sv.unit_slow[unit], sp = unit ? p.sv.unit_slow[unit - 1] : 0ull;
+        if (sw == 0 && (sp >> 63) == 0) continue;  // (wave-uniform)
+        const In in = load(unit);
         const u64 c = unit * 64 + lane;
-        const u64 next = unit + nwaves;
-        const bool more = next < p.units;  // wave-uniform
-        In in_n = in;
-        if (more) in_n = load(next);
         const u64 stp = in.stp >> 63;
         const bool prev_slow = lane ? ((in.slow_w >> (lane - 1)) & 1u) != 0 : (in.slow_p >> 63) != 0;
         const u64 sm = (in.h ? ~in.qm : in.qm) & ~in.q;
@@ -233,9 +235,6 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
             p.unit_cnt[unit] = incl;
             if (p.unit_copy) p.unit_copy[unit] = 0;
         }
-        if (!more) break;
-        unit = next;
-        in = in_n;
     }
 }
 
@@ -1240,6 +1239,8 @@ __device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); 
 //     device-wide matcher wrote every pair as two scattered 8-byte stores into lines that had long left the L2: 72 MB of
 //     sector writes and 84 MB of reads for 17 MB of words on configs[1], 95 + 28 MB on configs[4]).  Only brackets whose
 //     container starts in front of the tile stay "live" in the compact view (sj_tok16.h BR_DONE): k_br_match skips the rest.
+// (the reduce runs 256 lanes of sixteen tokens; the emit pass is compiled for sixteen and for eight tokens per lane --
+// 256 or 512 threads per tile -- SJHIP_S2_ITEMS)
 static constexpr int TK_BLOCK = 256, TK_ITEMS = 16, TK_WAVES = TK_BLOCK / 64;
 static_assert(TK_BLOCK * TK_ITEMS == S2_TILE, "256 lanes of sixteen tokens are one tile");
 
@@ -1250,25 +1251,33 @@ struct TileLane {
 // The sixteen kinds of this thread (K_NL behind the end of the message, like token_pelement's sentinel), the neighbours'
 // kinds through s_edge (TK_BLOCK + 2 words: [1 + tid] = kind 14 | kind 15 << 8 | kind 0 << 16 of thread tid), the masks.
 // Contains one __syncthreads().
+template <int ITEMS>
 __device__ __forceinline__ TileLane tile_lane(const S2Dev &p, u32 t0, u32 n, int tid, u32 *s_edge) {
+    constexpr int BLK = S2_TILE / ITEMS;
     TileLane r;
-    r.base = t0 + (u32)tid * TK_ITEMS;
+    r.base = t0 + (u32)tid * ITEMS;
     constexpr u32 NL4 = 0x01010101u * K_NL;
-    uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
-    if (r.base + TK_ITEMS <= n) {
-        kv = *reinterpret_cast<const uint4 *>(arr_at(p.kind, r.base, 16));
+    u32 d[4] = {NL4, NL4, ITEMS == 16 ? NL4 : 0u, ITEMS == 16 ? NL4 : 0u};
+    if (r.base + ITEMS <= n) {
+        if (ITEMS == 16) {
+            const uint4 kv = *reinterpret_cast<const uint4 *>(arr_at(p.kind, r.base, 16));
+            d[0] = kv.x; d[1] = kv.y; d[2] = kv.z; d[3] = kv.w;
+        } else {
+            const uint2 kv = *reinterpret_cast<const uint2 *>(arr_at(p.kind, r.base, 8));
+            d[0] = kv.x; d[1] = kv.y;
+        }
     } else if (r.base < n) {
-        u32 d[4] = {NL4, NL4, NL4, NL4};
-        for (u32 j = 0; r.base + j < n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[r.base + j] << (8 * (j & 3)));
-        kv = make_uint4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++)  // (constant indices: the words stay in registers)
+            if (r.base + (u32)j < n) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[r.base + j] << (8 * (j & 3)));
     }
-    s_edge[1 + tid] = (kv.w >> 16) | ((kv.x & 0xffu) << 16);
+    s_edge[1 + tid] = (d[ITEMS / 4 - 1] >> 16) | ((d[0] & 0xffu) << 16);
     if (tid == 0) s_edge[0] = t0 == 0 ? (u32)K_NONE | ((u32)K_NONE << 8) : (u32)p.kind[t0 - 2] | ((u32)p.kind[t0 - 1] << 8);
-    if (tid == 1) s_edge[1 + TK_BLOCK] = ((u64)t0 + S2_TILE < n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL) << 16;
+    if (tid == 1) s_edge[1 + BLK] = ((u64)t0 + S2_TILE < n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL) << 16;
     __syncthreads();
     const u32 prev2 = s_edge[tid] & 0xffffu, next1 = (s_edge[tid + 2] >> 16) & 0xffu;
-    const u32 cnt = n > r.base ? (n - r.base < (u32)TK_ITEMS ? n - r.base : (u32)TK_ITEMS) : 0u;
-    r.m = lane16_masks(planes16(kv.x, kv.y, kv.z, kv.w), prev2, next1, (1u << cnt) - 1u, r.base == 0 && cnt != 0);
+    const u32 cnt = n > r.base ? (n - r.base < (u32)ITEMS ? n - r.base : (u32)ITEMS) : 0u;
+    r.m = lane16_masks<ITEMS>(planes16(d[0], d[1], d[2], d[3]), prev2, next1, (1u << cnt) - 1u, r.base == 0 && cnt != 0);
     return r;
 }
 
@@ -1280,7 +1289,7 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
     const u32 n = token_count(p);
     if ((u64)block * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     const u32 t0 = block * S2_TILE;
-    const TileLane tl = tile_lane(p, t0, n, tid, s_edge);
+    const TileLane tl = tile_lane<TK_ITEMS>(p, t0, n, tid, s_edge);
     const Lane16 &m = tl.m;
     const u32 base = tl.base;
     // selective copy (WithCopyStrings(false)): the Strings.B bytes of the strings that unescaping changes go through the
@@ -1339,14 +1348,15 @@ __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
 // ---- pass 3 on planes -----------------------------------------------------------------------------------------------
 // queue entry of a string / scalar: token index inside the tile | tape offset inside the tile << 12 | (string: object key
 // << 25) | (scalar: kind - 8 << 26)
-template <bool MASKS>
-__global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
+template <bool MASKS, int ITEMS>
+__global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit_planes(S2Dev p) {
+    constexpr int BLK = S2_TILE / ITEMS, WAVES = BLK / 64;
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
     // strings [0, S) | the tile's brackets [S, S + B) | atoms and numbers [S + B, S + B + D): a tile has 4096 tokens
     __shared__ u32 s_q[S2_TILE];
-    __shared__ u32 s_edge[TK_BLOCK + 2];
-    __shared__ PAgg s_w[TK_WAVES];
-    __shared__ u32 s_wc[TK_WAVES];
+    __shared__ u32 s_edge[BLK + 2];
+    __shared__ PAgg s_w[WAVES];
+    __shared__ u32 s_wc[WAVES];
     __shared__ i32 s_gmin[S2_TILE / 64];
     __shared__ u32 s_nnum, s_base, s_fill, s_ccnt, s_cbase, s_cfill;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1359,44 +1369,44 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     {
-        const u32 base = t0 + (u32)tid * TK_ITEMS;
-        u32 pp[TK_ITEMS];
-        if (base + TK_ITEMS <= n) {
+        const u32 base = t0 + (u32)tid * ITEMS;
+        u32 pp[ITEMS];
+        if (base + ITEMS <= n) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < ITEMS / 4; q++) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base + 4 * q, 4));
                 pp[4 * q] = a.x; pp[4 * q + 1] = a.y; pp[4 * q + 2] = a.z; pp[4 * q + 3] = a.w;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < TK_ITEMS; k++) pp[k] = base + k < n ? p.pos[base + k] : endpos;
+            for (int k = 0; k < ITEMS; k++) pp[k] = base + k < n ? p.pos[base + k] : endpos;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            *reinterpret_cast<uint4 *>(&s_pos[tid * TK_ITEMS + 4 * q]) = make_uint4(pp[4 * q], pp[4 * q + 1], pp[4 * q + 2], pp[4 * q + 3]);
+        for (int q = 0; q < ITEMS / 4; q++)
+            *reinterpret_cast<uint4 *>(&s_pos[tid * ITEMS + 4 * q]) = make_uint4(pp[4 * q], pp[4 * q + 1], pp[4 * q + 2], pp[4 * q + 3]);
         if (tid == 2) s_pos[S2_TILE] = (u64)t0 + S2_TILE < n ? p.pos[t0 + S2_TILE] : endpos;
     }
-    const TileLane tl = tile_lane(p, t0, n, tid, s_edge);  // (holds the block barrier behind the stores above)
+    const TileLane tl = tile_lane<ITEMS>(p, t0, n, tid, s_edge);  // (holds the block barrier behind the stores above)
     const Lane16 &m = tl.m;
     const u32 base = tl.base;
     const MsgView mv{p.msg, p.len};
     // selective copy: the measured lengths of the lane's strings -> Strings.B bytes of the lane, and (below) every copied
     // string's offset
-    u32 dv[TK_ITEMS];
+    u32 dv[ITEMS];
     u32 sbytes = 0;
     if (!MASKS) {
-        if (base + TK_ITEMS <= n) {
+        if (base + ITEMS <= n) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < ITEMS / 4; q++) {
                 const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
                 dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < TK_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
+            for (int k = 0; k < ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < TK_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             dv[k] = (((m.str >> k) & 1u) && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
             sbytes += dv[k];
         }
@@ -1407,21 +1417,21 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     const u32 cnts = lane16_counts(m);
     mine.s = MASKS ? cnts : sbytes;
     PAgg total;
-    const PAgg ex = pagg_block_exclusive<true, TK_WAVES>(mine, s_w, lane, wave, total);
+    const PAgg ex = pagg_block_exclusive<true, WAVES>(mine, s_w, lane, wave, total);
     u32 cex = ex.s, ctot = total.s;
     if (!MASKS) {  // the scan's s field carries bytes: the slots get a scan of their own
         const u32 incl = wave_incl_sum(cnts);
         if (lane == 63) s_wc[wave] = incl;
         u32 nc = 0;
 #pragma unroll
-        for (int k = 0; k < TK_ITEMS; k++) nc += dv[k] != 0u ? 1u : 0u;
+        for (int k = 0; k < ITEMS; k++) nc += dv[k] != 0u ? 1u : 0u;
         nc = wave_incl_sum(nc);
         if (lane == 63 && nc) atomicAdd(&s_ccnt, nc);  // the tile's strings that k_emit_strings will copy
         __syncthreads();
         cex = incl - cnts;
         ctot = 0;
 #pragma unroll
-        for (int w = 0; w < TK_WAVES; w++) {
+        for (int w = 0; w < WAVES; w++) {
             const u32 x = s_wc[w];
             cex += w < wave ? x : 0u;
             ctot += x;
@@ -1438,13 +1448,13 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     {
         u32 slot = cex & 0x1fffu, run = ex.s;
         for (u32 r = m.str; r != 0; r &= r - 1) {  // strings: worked on densely below
-            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * TK_ITEMS + j;
+            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             s_q[slot++] = idx | ((lane_w + lane16_words_before(m, j)) << 12) | (((m.keystr >> j) & 1u) << 25);
             if (!MASKS) {  // the Strings.B offset of the string inside the tile, in the slot of the token's own position
                 s_pos[idx] = run;  // (the dense pass reads the position back from memory: no LDS of its own)
                 u32 c = 0;
 #pragma unroll
-                for (int k = 0; k < TK_ITEMS; k++) c = (u32)k == j ? dv[k] : c;
+                for (int k = 0; k < ITEMS; k++) c = (u32)k == j ? dv[k] : c;
                 run += c;
             }
         }
@@ -1452,7 +1462,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     {
         u32 slot = S + B + (cex >> 13);
         for (u32 r = m.num | m.atom; r != 0; r &= r - 1) {
-            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * TK_ITEMS + j;
+            const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             const u32 kd = ((m.num >> j) & 1u) ? (u32)K_NUM : (u32)lane16_atom_kind(m, j);
             s_q[slot++] = idx | ((lane_w + lane16_words_before(m, j)) << 12) | ((kd - 8u) << 26);
         }
@@ -1474,19 +1484,40 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     // ---- strings: Strings.B offset and unescaped length from the emit masks (sj_strings.h), both tape words in one
     // 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
     if (MASKS) {
-        for (u32 j = (u32)tid; j < S; j += TK_BLOCK) {
-            const u32 v = s_q[j], idx = v & 0xfffu, lo = (v >> 12) & 0x1fffu;
-            const u64 a0 = (u64)s_pos[idx] + p.sv.lead + 1, a1 = (u64)s_pos[idx + 1] + p.sv.lead;
-            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
-            const u32 b0 = (u32)a0 & 63u, b1 = (u32)a1 & 63u;
+        // two strings per thread and round, every gather of both requested before the first use (a tile's strings are a few
+        // rounds of the block: the pass is a chain of dependent round trips, not instructions)
+        struct SLoad {
+            ChunkRec r0, r1;
+            u64 c0, c1, a0, a1;
+        };
+        auto sload = [&](u32 idx) {
+            SLoad x;
+            x.a0 = (u64)s_pos[idx] + p.sv.lead + 1;
+            x.a1 = (u64)s_pos[idx + 1] + p.sv.lead;
+            x.r0 = p.rec[x.a0 >> 6];  // one 16-byte load each
+            x.r1 = p.rec[x.a1 >> 6];
             // absolute Strings.B offset of the chunk (left by k_str_emit, or unit prefix + bytes of the unit in front) + inside
-            const u64 c0 = p.no_abs ? (u64)p.unit_cnt[a0 >> 12] + (r0.pre & CHUNK_PRE_MASK) : (u64)r0.abs;
-            const u64 c1 = p.no_abs ? (u64)p.unit_cnt[a1 >> 12] + (r1.pre & CHUNK_PRE_MASK) : (u64)r1.abs;
-            const u64 so = c0 + (u64)popc64(r0.em & ~(~0ull << b0));
-            const u64 se = c1 + (u64)popc64(r1.em & ~(~0ull << b1));
+            x.c0 = p.no_abs ? (u64)p.unit_cnt[x.a0 >> 12] : 0ull;
+            x.c1 = p.no_abs ? (u64)p.unit_cnt[x.a1 >> 12] : 0ull;
+            return x;
+        };
+        auto sstore = [&](u32 v, const SLoad &x) {
+            const u32 lo = (v >> 12) & 0x1fffu;
+            const u32 b0 = (u32)x.a0 & 63u, b1 = (u32)x.a1 & 63u;
+            const u64 c0 = p.no_abs ? x.c0 + (x.r0.pre & CHUNK_PRE_MASK) : (u64)x.r0.abs;
+            const u64 c1 = p.no_abs ? x.c1 + (x.r1.pre & CHUNK_PRE_MASK) : (u64)x.r1.abs;
+            const u64 so = c0 + (u64)popc64(x.r0.em & ~(~0ull << b0));
+            const u64 se = c1 + (u64)popc64(x.r1.em & ~(~0ull << b1));
             const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
             *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
             if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
+        };
+        for (u32 j = (u32)tid; j < S; j += 2 * BLK) {
+            const bool two = j + BLK < S;
+            const u32 va = s_q[j], vb = two ? s_q[j + BLK] : va;
+            const SLoad xa = sload(va & 0xfffu), xb = sload(vb & 0xfffu);
+            sstore(va, xa);
+            if (two) sstore(vb, xb);
         }
     }
     // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
@@ -1495,7 +1526,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     if (!MASKS) {
         if (tid == 0 && s_ccnt != 0 && p.sv.qm) s_cbase = atomicAdd(&p.st->str_count, s_ccnt);
         __syncthreads();
-        for (u32 j0 = 0; j0 < S; j0 += TK_BLOCK) {  // (block-uniform trip count: the ballots below want whole waves)
+        for (u32 j0 = 0; j0 < S; j0 += BLK) {  // (block-uniform trip count: the ballots below want whole waves)
             const u32 j = j0 + (u32)tid;
             bool queue = false;
             u32 at = 0, so = 0, len = 0;
@@ -1532,7 +1563,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
         if (cnt != 0 && tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
         if (cnt != 0) __syncthreads();  // (block-uniform)
         const u32 qb = s_base;
-        for (u32 j = (u32)tid; j < D; j += TK_BLOCK) {
+        for (u32 j = (u32)tid; j < D; j += BLK) {
             const u32 v = s_q[S + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
             const u8 ak = (u8)(8u + ((v >> 26) & 3u));
             if (ak == K_NUM) {
@@ -1555,7 +1586,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
     // relative to the tile's start; a question that no bracket of the tile answers stays for k_br_match.
     {
         const u32 G = (B + 63u) / 64u;
-        for (u32 g = (u32)wave; g < G; g += TK_WAVES) {  // the minimum depth of every group of 64
+        for (u32 g = (u32)wave; g < G; g += WAVES) {  // the minimum depth of every group of 64
             const u32 c = g * 64u + (u32)lane;
             i32 v = c < B ? tbr_depth(s_q[S + c]) : 0x7fffffff;
 #pragma unroll
@@ -1567,7 +1598,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_s2_emit_planes(S2Dev p) {
         }
         __syncthreads();
         const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
-        for (u32 g = (u32)wave; g < G; g += TK_WAVES) {  // wave-uniform
+        for (u32 g = (u32)wave; g < G; g += WAVES) {  // wave-uniform
             const u32 c = g * 64u + (u32)lane;
             const bool valid = c < B;
             const u32 e = valid ? s_q[S + c] : 0u;
@@ -2181,8 +2212,14 @@ hipError_t stage2_launch_emit(const S2Args &a) {
         hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     }
     if (p.variant) {
-        if (masks_copy) hipLaunchKernelGGL(k_s2_emit_planes<true>, dim3(p.tiles), dim3(TK_BLOCK), 0, a.stream, p);
-        else hipLaunchKernelGGL(k_s2_emit_planes<false>, dim3(p.tiles), dim3(TK_BLOCK), 0, a.stream, p);
+        static const int items = getenv("SJHIP_S2_ITEMS") ? atoi(getenv("SJHIP_S2_ITEMS")) : 8;
+        if (items == 16) {
+            if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
+            else hipLaunchKernelGGL((k_s2_emit_planes<false, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
+        } else {
+            if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
+            else hipLaunchKernelGGL((k_s2_emit_planes<false, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
+        }
     } else {
         if (masks_copy) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
         else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);

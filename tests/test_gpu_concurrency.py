@@ -36,7 +36,7 @@ def test_large_parses_from_four_threads_keep_their_order():
     for copies in (107, 130):  # 64.4 MiB / 78 MiB arrays of twitter.json: 516 / 627 tiles for 256 blocks
         d = workloads.c2_twitter_array(copies)
         docs.append((d, False, workloads.c2_expected_structurals(copies), copies * 49781 + 4, copies * 367917))
-    for copies in (180, 200):  # 67 MB / 74.5 MB of parking-citations ND
+    for copies in (190, 215):  # 70.8 MB / 80 MB of parking-citations ND
         d = (park * copies).rstrip(b"\n")
         docs.append((d, True, 78 * 1000 * copies - 1, 80000 * copies, 256664 * copies))
     assert all(len(d[0]) > (64 << 20) for d in docs)
