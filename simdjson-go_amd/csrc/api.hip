@@ -76,14 +76,6 @@ sjhip_ctx *sjhip_ctx_create(int device) {
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
-    // second stream of the parse (optional: without it the kernels simply run one behind the other)
-    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-        ctx->side_stream = nullptr;
-    }
     return ctx;
 }
 
@@ -146,12 +138,6 @@ void sjhip_ctx_destroy(sjhip_ctx *ctx) {
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    if (ctx->side_stream) {
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
-    }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -223,7 +209,7 @@ static void invalidate_result(sjhip_ctx *ctx) {
 // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
 // would hand positions to other streams before they are visible there.)
 int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                       uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
+                       uint8_t *d_kind, void *zero2, size_t zero2_bytes, bool aux_records) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -234,7 +220,7 @@ int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson
     if (len > 0) {
         *(volatile unsigned long long *)ctx->h_scratch = 0;
         HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
-                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
+                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes, aux_records),
                "stage1 launch");
     }
     return SJHIP_OK;
@@ -277,8 +263,8 @@ int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_l
 
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                           uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind, void *zero2,
-                          size_t zero2_bytes) {
-    int rc = stage1_enqueue(ctx, d_msg, len, ndjson, d_pos, pos_cap, str_aux, d_kind, zero2, zero2_bytes);
+                          size_t zero2_bytes, bool aux_records) {
+    int rc = stage1_enqueue(ctx, d_msg, len, ndjson, d_pos, pos_cap, str_aux, d_kind, zero2, zero2_bytes, aux_records);
     if (rc) return rc;
     if (len > 0) HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
     return stage1_collect(ctx, len, last_byte, have_last, n, ok);

@@ -287,6 +287,43 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             masks_total += run;
         }
     }
+    // Every string copied, second half of round 5: stage 1 keeps no records.  Its phase A counts the emitted bytes and the
+    // opening quotes of every unit under both hypotheses about the state at the start of the unit (stage1.hip phase_a), the
+    // flatten picks the pair that applies; k_str_emit derives emit mask, escaped characters and opening quotes of a chunk from
+    // the three masks (sj_strings.h chunk_fast) and leaves the Strings.B offset of the k-th string of the message in soff[k]
+    // (+ the length of Strings.B behind the last one).  The replay's masks are absolute (state 0 at every unit start), so
+    // the other hypothesis is exercised on the complemented mask: both must give what the record path gives.
+    std::vector<u32> v_soff;
+    if (masks && !bad) {
+        for (size_t u = 0; u < used_units; u++) {
+            const bool slow = v_slow[u] != 0 || (u > 0 && (v_slow[u - 1] >> 63) != 0);  // k_measure's general routine has the unit
+            u32 nstr = 0;
+            for (u32 hyp = 0; hyp < 2; hyp++) {
+                u32 cA = 0, cAB = 0, oA = 0, oAB = 0;
+                for (size_t c = u * 64; c < u * 64 + 64; c++) {
+                    const u64 qmr = hyp ? ~v_qm[c] : v_qm[c];  // the mask relative to a unit that starts inside a string
+                    const u64 nqst = ~v_q[c] & ~v_st[c];
+                    cA += (u32)popc64(qmr & nqst);
+                    cAB += (u32)popc64(nqst);
+                    oA += (u32)popc64(qmr & v_q[c]);
+                    oAB += (u32)popc64(v_q[c]);
+                    const ChunkFast f = chunk_fast(qmr, v_q[c], v_st[c], c ? v_st[c - 1] : 0ull, hyp);
+                    if (!slow && (f.em != v_em[c] || (f.esc != 0 ? CHUNK_SLOW : 0u) != v_flags[c])) return 87;
+                    if (f.oq != (v_q[c] & v_qm[c])) return 87;
+                    if (slow && (((v_st[c] << 1) | (c ? v_st[c - 1] >> 63 : 0ull)) & v_em[c]) != (sv.esc(c) & v_em[c])) return 87;
+                    if (hyp == 0)
+                        for (u64 r = f.oq; r != 0; r &= r - 1) {
+                            v_soff.push_back(v_ucnt[u] + v_pre[c] + (u32)popc64(v_em[c] & ((1ull << ctz64(r)) - 1ull)));
+                            nstr++;
+                        }
+                }
+                const u32 ucnt = hyp ? cAB - cA : cA, ustr = hyp ? oAB - oA : oA;
+                if (!slow && ucnt != v_ucount[u]) return 87;
+                if (ustr != nstr) return 87;
+            }
+        }
+        v_soff.push_back((u32)masks_total);
+    }
     // k_s2_reduce: kinds, string lengths (selective copy), elements
     std::vector<u8> kind(n);
     std::vector<u32> dlen(n, 0), copied(n, 0);
@@ -502,6 +539,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     if (!context_allowed(tail_mask, CTX_ROOT)) bad = 1;  // k_scans: tokens behind the last bracket lie at depth 0
     u64 *tape = (u64 *)calloc(tlen + 2, sizeof(u64));
     u8 *strs = (u8 *)malloc(sbytes + 64);
+    size_t str_ord = 0;
     for (size_t i = 0; i < n; i++) {
         const u8 k = kind[i];
         if (k == K_TRUE || k == K_FALSE || k == K_NULL) {
@@ -512,6 +550,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             const u64 so = emitted_before(v_ucnt.data(), v_rec.data(), a0);
             const u64 se = emitted_before(v_ucnt.data(), v_rec.data(), a1);
             if (so != emitted_before_abs(v_rec.data(), a0) || se != emitted_before_abs(v_rec.data(), a1)) return 95;
+            if (!bad) {  // k_s2_emit_planes: the string's number in the message -> soff[]
+                if (str_ord + 1 >= v_soff.size() || v_soff[str_ord] != so || v_soff[str_ord + 1] - v_soff[str_ord] != se - so) return 86;
+            }
+            str_ord++;
             tape[toff[i]] = string_word(true, strings_base + so, 0);
             tape[toff[i] + 1] = se - so;
         } else if (k == K_STRING && !strbad[i]) {

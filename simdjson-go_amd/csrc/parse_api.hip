@@ -35,18 +35,6 @@ static size_t small_document_bytes() {
     return v;
 }
 
-// SJHIP_S2_OVERLAP: 0 = one stream, k_str_emit leaves the chunk offsets (ChunkRec::abs); 1 = one stream, no abs writes;
-// 2 = the string bytes on the side stream beside the tape kernels, 3 = the side stream starts behind k_s2_emit.
-// Default 1: the parse is bound by HBM traffic as a whole, running kernels side by side moved twitter x426 by -2 %
-// and parking x1000 by +3 %
-static int s2_overlap_mode() {
-    static const int v = [] {
-        const char *e = getenv("SJHIP_S2_OVERLAP");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
-
 static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base, uint64_t msg_base) {
     S2Args a = {};
     a.d_msg = ctx->p_msg;
@@ -56,14 +44,6 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.n = ctx->p_nlay;
     a.n_dev = ctx->p_deferred ? (const unsigned long long *)((const char *)ctx->d_ws.p + offsetof(Stage1State, total)) : nullptr;
     a.flags = ctx->p_flags;
-    const int ov = s2_overlap_mode();
-    if (ov >= 1) a.flags |= sj::S2_FLAG_NO_ABS;
-    if (ov >= 3) a.flags |= sj::S2_FLAG_FORK_LATE;
-    if (ov >= 2 && ctx->side_stream) {
-        a.side = ctx->side_stream;
-        a.ev_fork = ctx->ev_fork;
-        a.ev_join = ctx->ev_join;
-    }
     a.ws_zero = ctx->d_s2z.p;
     a.ws = ctx->d_s2.p;
     a.d_tape = (uint64_t *)ctx->d_tape.p;
@@ -149,7 +129,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes() && !ctx->p_no_defer;
         if (ctx->p_deferred) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
-                                ctx->d_s2z.p, stage2_zero_bytes());
+                                ctx->d_s2z.p, stage2_zero_bytes(), !(flags & SJHIP_FLAG_COPY_STRINGS));
             // The stage-2 arrays are laid out for one token per four bytes (the densest fixture, marine_ik, has 0.22):
             // ~14 B of arena per message byte instead of 57.  The kernels clamp the device-side count to this layout
             // (stage2.hip token_count), so a denser document stays in bounds and is parsed again the synchronous way
@@ -160,7 +140,8 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             ctx->p_have_last = have_last;
         } else {
             rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                                   have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
+                                   have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes(),
+                                   !(flags & SJHIP_FLAG_COPY_STRINGS));
         }
         if (rc) return rc;
     }

@@ -18,8 +18,6 @@ struct sjhip_ctx {
     hipStream_t stream = nullptr;      // stream all work is queued on
     hipStream_t own_stream = nullptr;  // created with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t side_stream = nullptr; // the string bytes of a parse run here, beside the tape kernels (parse_api.hip)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *h_scratch = nullptr;      // 4 KiB pinned: state read-backs
     // small documents parsed from a host buffer (sjhip_parse): the last kernel of the chain also writes the stage-2 state,
     // the tape and Strings.B into this pinned block (over PCIe, no copy commands), and sjhip_fetch is two memcpy
@@ -88,9 +86,9 @@ int fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 void release_nd_big(sjhip_ctx *ctx);
 size_t nd_big_device_bytes(const sjhip_ctx *ctx);  // arenas of the shard contexts of a sharded ND parse
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                   uint8_t *d_kind, void *zero2, size_t zero2_bytes);
+                   uint8_t *d_kind, void *zero2, size_t zero2_bytes, bool aux_records = false);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                       uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr,
-                      void *zero2 = nullptr, size_t zero2_bytes = 0);
+                      void *zero2 = nullptr, size_t zero2_bytes = 0, bool aux_records = false);
 }  // namespace sj

@@ -37,7 +37,8 @@ struct S2State {
     unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
     uint32_t num_count;      // number tokens queued for k_numbers
     uint32_t str_count;      // selective copy: strings queued for k_emit_strings (the ones unescaping changes)
-    uint32_t pad[2];
+    uint32_t n_strings;      // every string copied: opening quotes of the message (the unit scan's second total)
+    uint32_t pad[1];
 };
 static_assert(sizeof(S2State) == 64, "S2State must stay one 64-byte line");
 // a run of more than SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string
@@ -66,14 +67,7 @@ struct S2Args {
     uint8_t *d_keyflag;     // null, or tape_cap / 2 + 8 bytes: [tape index of a string entry >> 1] = 1 iff it is an object key
                             // (SJHIP_FLAG_KEY_FLAGS; indices inside this parse's tape, without tape_base)
     hipStream_t stream;
-    // null, or a second stream + two events: the string bytes (k_str_emit) run beside the tape kernels (stage2_launch_emit)
-    hipStream_t side;
-    hipEvent_t ev_fork, ev_join;
 };
-// S2Args::flags bit: k_s2_emit takes a chunk's Strings.B offset from unit_cnt + ChunkRec::pre instead of ChunkRec::abs
-// (k_str_emit then does not have to run in front of it, and does not write abs)
-constexpr uint32_t S2_FLAG_NO_ABS = 1u << 8;
-constexpr uint32_t S2_FLAG_FORK_LATE = 1u << 9;  // the side stream starts behind k_s2_emit (beside numbers and brackets)
 size_t stage2_zero_bytes();
 size_t stage2_workspace_bytes(size_t n_tokens);
 hipError_t stage2_launch_measure(const S2Args &a);
@@ -102,6 +96,7 @@ struct StrAux {
     uint64_t *qm, *q, *st;
     void *rec;  // ChunkRec[chunks]
     uint32_t *unit_cnt;
+    uint32_t *unit_str;   // per unit: strings that begin in it, then (k_scans) their exclusive prefix (every string copied)
     uint8_t *unit_h;
     uint64_t *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (a \u or an invalid escape)
     uint8_t *unit_copy;   // per unit, WithCopyStrings(false): 1 iff bytes of a string that unescaping changes lie in it (stage2.hip)
@@ -121,6 +116,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.st = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
     a.rec = carve(a.chunks * 16);
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
+    a.unit_str = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
     a.unit_slow = reinterpret_cast<uint64_t *>(carve(a.units * 8));
     a.unit_copy = reinterpret_cast<uint8_t *>(carve(a.units));
@@ -131,7 +127,8 @@ inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr);
+                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr,
+                                  bool aux_records = false);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
@@ -139,6 +136,7 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // the packed result there (S1_HOST_*) in one store: the host needs a stream synchronisation but no copy
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0);
+                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0,
+                         bool aux_records = false);  // aux_records: the flatten leaves emit-mask records (WithCopyStrings(false))
 
 }  // namespace sj

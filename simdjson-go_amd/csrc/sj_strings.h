@@ -31,7 +31,7 @@ struct StrView {
     Arr<const u8> base;  // 64-byte aligned base of the message (Arr: sj_bounds.h, a plain pointer in the product build)
     u64 lead, end;   // the message occupies [lead, end) of it
     Arr<const u64> qm, q, st;
-    Arr<const u8> unit_h;
+    Arr<const u8> unit_h;  // per unit: bit 0 = state at its start (1: inside a string), bit 1 = it holds an escape starter
     Arr<const u64> unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
     // the 16 bytes at a .. a+15 as two little-endian words (two unaligned 8-byte loads away from the message ends)
@@ -50,7 +50,7 @@ struct StrView {
     }
     SJ_HD u64 sm(u64 c) const {
         const u64 m = qm[c];
-        return (unit_h[c >> 6] ? ~m : m) & ~q[c];
+        return ((unit_h[c >> 6] & 1u) ? ~m : m) & ~q[c];  // (bit 1 of unit_h: the unit holds an escape starter)
     }
     // escaped characters of chunk c (characters that follow a starter)
     SJ_HD u64 esc(u64 c) const { return (st[c] << 1) | (c ? st[c - 1] >> 63 : 0); }
@@ -249,6 +249,23 @@ SJ_HD bool str_chunk_masks_fast(const StrView &m, u64 c, u64 *em_out, u32 *flags
     const bool ok = str_chunk_masks(m, c, em_out, &um, &escapes, overflow_out);
     *flags_out = escapes ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
     return ok;
+}
+// The same for one chunk from its three masks alone (every string copied, second half of round 5: k_str_emit derives this
+// per chunk instead of reading a record): qm / q / st of the chunk, st of the chunk in front, h = state at the start of
+// the unit.  esc = the escaped characters inside strings (they are all emitted: an escaped character is neither an
+// unescaped quote nor a starter); oq = the OPENING quotes -- qm includes the opening and excludes the closing quote of
+// every string.  String number k of the message is the k-th opening quote and the k-th string token.
+struct ChunkFast {
+    u64 em, esc, oq;
+};
+SJ_HD ChunkFast chunk_fast(u64 qm, u64 q, u64 st, u64 st_prev, u32 h) {
+    const u64 in = h ? ~qm : qm;
+    const u64 sm = in & ~q;
+    ChunkFast r;
+    r.em = sm & ~st;
+    r.esc = ((st << 1) | (st_prev >> 63)) & sm;
+    r.oq = q & in;
+    return r;
 }
 // Pass 2 for a chunk whose escapes are all simple (CHUNK_SLOW without CHUNK_GENERAL): the escaped characters inside
 // strings -- they are all emitted -- are translated in place.  put(p, v) as below; at(p) = the chunk's byte p.

@@ -47,8 +47,14 @@ struct S1Aux {
     // \u escape: the 16-byte record {emit mask, emitted bytes of the unit in front of the chunk | CHUNK_SLOW} and the unit's
     // byte count.  k_measure then only visits the units that unit_slow flags (none on twitter.json / parking-citations: the
     // masks are never read from HBM again, and 101 + 67 MB of reads and writes of configs[1] are gone with the pass).
+    // (second half of round 5: only WithCopyStrings(false) still takes the records from here -- `rec` is null otherwise.
+    // When every string is copied the masks are not read back at all: phase A counts the emitted bytes and the opening
+    // quotes of every unit under BOTH hypotheses (four popcounts and two wave sums), the flatten picks the pair that
+    // applies and leaves unit_cnt / unit_str, and k_str_emit derives the emit mask of a chunk from the three masks it
+    // streams anyway, stage2.hip.  Per chunk that is 24 B written here instead of 24 written + 24 read + 16 written.)
     Arr<ChunkRec> rec;
     Arr<u32> unit_cnt;
+    Arr<u32> unit_str;   // [units] strings that begin in the unit (opening quotes); null in the record form
     Arr<u8> unit_copy;   // cleared here (WithCopyStrings(false): k_str_measure marks the units to compact)
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
@@ -333,7 +339,8 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
-                                        const S1Aux &aux, const u8 *__restrict__ edge, u64 (&kp)[CH][4], bool TOP = false) {
+                                        const S1Aux &aux, const u8 *__restrict__ edge, u64 (&kp)[CH][4], uint2 *s_ucnt,
+                                        bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
 #if defined(SJ_S1_ROLL)
@@ -351,6 +358,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             m[(k * 2 + 1) * 64 + lane] = 0;
             pre[k * 64 + lane] = 0;
             if (lane == 0) s_unit[k * WAVES + wave] = 0;
+            if (AUX && lane == 0) s_ucnt[k * WAVES + wave] = make_uint2(0u, 0u);
             kp[k][0] = kp[k][1] = kp[k][2] = kp[k][3] = 0;
             if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
             continue;
@@ -443,6 +451,19 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             const u64 slow = __ballot(((u32)nonsimple | (u32)(nonsimple >> 32)) != 0);
             if (lane == 0) aux.unit_slow[unit] = slow;
         }
+        if (AUX) {
+            // every string copied: emitted bytes (sj_strings.h: in-string bytes that are neither quotes nor escape starters --
+            // the fast formula; units with a \u escape are counted again by k_measure) and opening quotes of the unit under
+            // hypothesis 0, and under either hypothesis together (the two sets are disjoint: the other one is the difference)
+            uint2 tot = make_uint2(0u, 0u);
+            if (aux.unit_str && unit_off < end) {  // (uniform)
+                const u64 nqst = ~quote_bits & ~starters;
+                const u32 cnt = wave_incl_scan((u32)popc64(qm & nqst) | ((u32)popc64(nqst) << 16));
+                const u32 opn = wave_incl_scan((u32)popc64(qm & quote_bits) | ((u32)popc64(quote_bits) << 16));
+                tot = make_uint2(lane63(cnt), lane63(opn));
+            }
+            if (lane == 0) s_ucnt[k * WAVES + wave] = tot;
+        }
         // unescaped control characters inside strings (find_quote_mask_and_bits_amd64.s:67-80), per hypothesis
         const u64 in_a = c.ctrl & qm, in_b = c.ctrl & ~qm;
         const u32 bad = (__ballot(((u32)in_a | (u32)(in_a >> 32)) != 0) != 0 ? 1u : 0u) |
@@ -453,9 +474,11 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // carry into the chunk, for the emit-mask records the whole parse leaves in flatten_tile)
         pre[k * 64 + lane] = AUX ? incl | (carry_bit << 15) : incl;
         const u32 tot = lane63(incl);
+        // (whole parse, bit 28: the unit holds an escape starter -- k_str_emit does not read the st masks of the others)
+        const u32 has_st = AUX && __ballot(((u32)starters | (u32)(starters >> 32)) != 0) != 0 ? 1u : 0u;
         if (lane == 0)
             s_unit[k * WAVES + wave] =
-                (((u32)popc64(par_ballot) & 1u) << 31) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
+                (((u32)popc64(par_ballot) & 1u) << 31) | (has_st << 28) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
     }
 }
 
@@ -486,7 +509,8 @@ __device__ __forceinline__ void tile_aggregate(const u32 *s_unit, int lane, u32 
 template <int BLOCK, int CH, bool KIND>
 __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl, const u32 *pre, const u32 *s_unit, u32 pre_mask, u32 G, u64 BASE, u32 t,
                                              u64 lead, int lane, int wave, SJ_ARR_PARAM(u32) out_pos, u64 pos_cap,
-                                             u64 &tile_end, Arr<u8> unit_h, u64 len_, Arr<u8> kind_out, const S1Aux &aux) {
+                                             u64 &tile_end, Arr<u8> unit_h, u64 len_, Arr<u8> kind_out, const S1Aux &aux,
+                                             const uint2 *s_ucnt) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     // the window that held the masks (CH * 2 * 64 u64) stages the positions of a unit: 32-bit positions, or (KIND)
@@ -530,7 +554,15 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         const u32 both = pre[k * 64 + lane];
         upto[k] = (h ? both >> 16 : both) & 0x1fffu;
         const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
-        if (unit_h && lane == 0 && un * 4096 < lead + len_) unit_h[un] = (u8)h;  // (a void unit lies behind everything)
+        if (unit_h && lane == 0 && un * 4096 < lead + len_) {  // (a void unit lies behind everything)
+            // bit 0: the state at the start of the unit; bit 1: the unit holds an escape starter
+            unit_h[un] = (u8)(h | (((s_unit[k * WAVES + wave] >> 28) & 1u) << 1));
+            if (KIND && aux.unit_str) {  // every string copied: the unit's counts under the state that is now known
+                const uint2 c = s_ucnt[k * WAVES + wave];
+                aux.unit_cnt[un] = h ? (c.x >> 16) - (c.x & 0xffffu) : c.x & 0xffffu;
+                aux.unit_str[un] = h ? (c.y >> 16) - (c.y & 0xffffu) : c.y & 0xffffu;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < CH; k++) {
@@ -670,6 +702,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // whole parse: the kind planes of the tile that is flattened next (4 x u64 per chunk); a wave keeps the planes of the
     // tile it has just classified in registers until it has flattened the tile in front, then parks them here
     __shared__ __attribute__((aligned(16))) u64 s_kpl[AUX ? WAVES : 1][AUX ? CH * 4 * 64 : 2];
+    __shared__ uint2 s_ucnt[3][AUX ? UNITS : 1];  // whole parse: string bytes / opening quotes per unit, both hypotheses (ring of s_unit)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -726,7 +759,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
-                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, wave == 0 && !first);
+                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, s_ucnt[AUX ? ua : 0], wave == 0 && !first);
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
         }
         u32 *res = s_res2[j & 1u];
@@ -783,7 +816,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             u64 tile_end = 0;
             err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_kpl[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
                                            S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, AUX ? aux.unit_h : Arr<u8>(nullptr), len,
-                                           AUX ? aux.kind : Arr<u8>(nullptr), aux);
+                                           AUX ? aux.kind : Arr<u8>(nullptr), aux, s_ucnt[AUX ? uf : 0]);
             if (t_prev == num_tiles - 1 && tid == 0)
                 __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
@@ -876,7 +909,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     }
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge, kp);
+                                    aux, edge, kp, nullptr);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();
     {
@@ -972,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
-                                            s_unit[ua], aux, edge, kp, wave == 0);
+                                            s_unit[ua], aux, edge, kp, nullptr, wave == 0);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             u32 arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1022,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, false>(tm, s_mask[mf][wave], nullptr, s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
-                                              wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr), aux);
+                                              wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr), aux, nullptr);
         if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
@@ -1152,7 +1185,7 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                                   hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
-                                  unsigned long long *h_state) {
+                                  unsigned long long *h_state, bool aux_records) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -1179,9 +1212,13 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.st = SJ_ARR(a.st, a.chunks, A_S1_ST);
         aux.unit_h = SJ_ARR(a.unit_h, a.units, A_S1_UNIT_H);
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
-        aux.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(a.rec), a.chunks, A_S1_REC);
         aux.unit_cnt = SJ_ARR(a.unit_cnt, a.units, A_S1_UNIT_CNT);
-        aux.unit_copy = SJ_ARR(a.unit_copy, a.units, A_S1_UNIT_COPY);
+        if (aux_records) {  // WithCopyStrings(false): the flatten leaves the emit-mask records
+            aux.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(a.rec), a.chunks, A_S1_REC);
+            aux.unit_copy = SJ_ARR(a.unit_copy, a.units, A_S1_UNIT_COPY);
+        } else {            // every string copied: unit counts only (k_str_emit derives the rest from the masks)
+            aux.unit_str = SJ_ARR(a.unit_str, a.units, A_S1_UNIT_STR);
+        }
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
@@ -1230,10 +1267,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
-                         size_t zero2_bytes) {
+                         size_t zero2_bytes, bool aux_records) {
     hipError_t e = stage1_prepare(d_msg, len, ws, stream, zero2, zero2_bytes);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state, aux_records);
 }
 
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses of the stage-1 kernels since the

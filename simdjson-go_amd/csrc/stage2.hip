@@ -37,14 +37,9 @@
 namespace sj {
 
 static constexpr int S2_TILE = 4096;  // tokens per tile (the packed scan form PAgg is sized for it)
-static constexpr int S2_BLOCK = 512;  // k_s2_emit: 512 threads x 8 tokens
-static constexpr int S2_ITEMS = S2_TILE / S2_BLOCK;
-static constexpr int S2_WAVES = S2_BLOCK / 64;
-static_assert(S2_ITEMS == 8, "k_s2_emit reads the 8 kinds of a thread as one u64");
+static constexpr int RD_BLOCK = 256;  // k_measure
 static constexpr u32 DLEN_INVALID = 0xffffffffu;
 static constexpr u32 DLEN_COPY = 0x80000000u;
-
-__constant__ ElementLut c_elut = make_element_lut();
 
 // The two device-wide scans that run over small arrays (unit byte counts, tile aggregates) are split over
 // SCAN_SEGS blocks, because one CU moves only ~60 GB/s: a block reduces its contiguous segment, publishes the
@@ -73,7 +68,7 @@ struct S2Dev {
     u32 n;         // tokens -- or, with n_dev, an upper bound the arrays are sized for
     const unsigned long long *n_dev;  // null, or the token count on the device (Stage1State::total): the host has not
                                       // waited for stage 1 (small documents: one synchronisation per parse)
-    u32 ndjson, copy_strings, no_abs;
+    u32 ndjson, copy_strings;
     Arr<const u8> kind;  // [n] token kinds (stage 1 writes them next to the positions)
     Arr<u32> dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     Arr<u32> str_off;  // [n] selective copy only: Strings.B offset of a copied string
@@ -92,7 +87,7 @@ struct S2Dev {
     u64 lev_size[MinTree::MAXLEV];
     int nlev;
     S2State *st;
-    SegSlot *seg_units, *seg_tiles;  // [SCAN_SEGS] segment aggregates of the two multi-block scans (zeroed with st)
+    SegSlot *seg_units, *seg_tiles, *seg_ustr;  // [SCAN_SEGS] segment aggregates of the multi-block scans (zeroed with st)
     int unit_segs, tile_segs;        // blocks of the unit scan / of the tile scan: SCAN_SEGS, or 1 where one block is through in
                                      // a single short round (<= 16 384 units, <= 1024 tiles): nothing to publish or wait for
     Arr<u64> tape;
@@ -107,11 +102,13 @@ struct S2Dev {
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
     Arr<ChunkRec> rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
     Arr<u32> unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
+    Arr<u32> unit_str;        // [units]  every string copied: strings that begin in the unit, then their exclusive prefix
+    Arr<u32> soff;            // [soff_cap] every string copied: Strings.B offset of the k-th string of the message, and behind
+    u32 soff_cap;             //          the last one the length of Strings.B (k_str_emit; the storage is dlen's and str_off's)
     Arr<u8> unit_copy;        // [units]  selective copy only (else null): 1 iff the unit holds bytes of a string that unescaping
                               // changes -- cleared with the unit's count, set by k_str_measure; k_str_emit compacts only those units
     u64 units;
     u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
-    u32 variant;  // 1 (default): the token pass on bit planes (sj_tok16.h); 0: the per-token kernels of rounds 1-4 (SJHIP_S2_VARIANT)
 };
 #if defined(SJ_EXP)
 #define SJ_EXPBIT(p, b) ((((p).exp >> (b)) & 1u) != 0)
@@ -184,7 +181,7 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
         r.stp = c ? p.sv.st[c - 1] : 0ull;
         r.slow_w = p.sv.unit_slow[u];
         r.slow_p = u ? p.sv.unit_slow[u - 1] : 0ull;
-        r.h = p.sv.unit_h[u];
+        r.h = p.sv.unit_h[u] & 1u;
         return r;
     };
     // Stage 1's flatten has left the record of every chunk and the count of every unit (stage1.hip flatten_tile, round 5);
@@ -347,11 +344,14 @@ __device__ __forceinline__ void unit_round_load(Arr<const u32> data, u64 i, u64 
         for (int q = 0; q < 16; q++) v[q] = i + q < hi ? data[i + q] : 0u;
     }
 }
+// (STR: the units' string counts instead -- every string copied: k_str_emit numbers the strings of the message with them)
+template <bool STR>
 __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
     __shared__ u32 s_wave[2][16];
     __shared__ unsigned long long s_sum[16], s_prefix;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Arr<u32> data = p.unit_cnt;
+    const Arr<u32> data = STR ? p.unit_str : p.unit_cnt;
+    SegSlot *const slots = STR ? p.seg_ustr : p.seg_units;
     u64 lo, hi;
     seg_range(p.units, 1024, seg, p.unit_segs, lo, hi);
     // pass 1: the segment's byte count
@@ -373,11 +373,14 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
         own.a = agg_identity();
         own.w = 0;
         own.s = tot;
-        if (lane == 0) seg_publish(&p.seg_units[seg], own);
-        const SegSum before = seg_lookback(p.seg_units, seg, lane, p.st);
+        if (lane == 0) seg_publish(&slots[seg], own);
+        const SegSum before = seg_lookback(slots, seg, lane, p.st);
         if (lane == 0) {
             s_prefix = before.s;
-            if (seg == p.unit_segs - 1) p.st->strings_len_masks = before.s + tot;
+            if (seg == p.unit_segs - 1) {
+                if (STR) p.st->n_strings = (u32)(before.s + tot);
+                else p.st->strings_len_masks = before.s + tot;
+            }
         }
     }
     __syncthreads();
@@ -450,14 +453,25 @@ constexpr SelLut make_sel_lut() {
 __constant__ SelLut c_sel = make_sel_lut();
 __constant__ EscapeLut c_esc = make_escape_lut();
 
-// Pass 2 of the string path: one 4 KiB unit per wave, one 64-byte chunk per lane.  A chunk is compacted four
-// bytes at a time: v_perm_b32 squeezes the emitted bytes of a dword together and one unaligned LDS store
-// appends them; the up to four stale bytes such a store leaves behind the lane's data are repaired after a wave
-// barrier, when every lane rewrites the first four bytes of its own region (kept in a register).  Chunks with escapes (flagged by
-// k_str_masks) first patch the translated bytes into their LDS copy of the chunk (sj_strings.h).
+// Pass 2 of the string path: one 4 KiB unit per wave, one 64-byte chunk per lane.  A chunk is compacted eight
+// bytes at a time: two v_perm_b32 squeeze the emitted bytes together and aligned 8-byte LDS atomics merge them into the
+// wave's window (below).  Chunks with escapes first patch the translated bytes into their LDS copy of the chunk (sj_strings.h).
 // Waves are persistent and software-pipelined: a wave walks over units wave_id, wave_id + waves, ...; while it compacts
-// unit i its loads of the 64-byte chunks of unit i+1 and of the records of unit i+2 are in flight (one unit per block
-// left two dependent memory round trips -- record, then chunk -- exposed in front of every 4 KiB).
+// unit i its loads of the 64-byte chunks of unit i+1 and of the masks (records) of unit i+2 are in flight (one unit per
+// block left two dependent memory round trips -- record, then chunk -- exposed in front of every 4 KiB).
+//
+// DERIVE (every string copied, second half of round 5): there are no records for ordinary units.  The wave streams the
+// three masks stage 1 left (24 B per chunk, read here for the first and only time) and derives what the record held --
+// emit mask, escaped characters, the chunk's offset inside the unit (one packed wave scan) -- and, new, the OPENING QUOTES:
+// string number k of the message (k-th opening quote = k-th string token) starts at Strings.B offset
+// soff[k] = E(position of its quote), and since Strings.B is the concatenation of all strings its unescaped length is
+// soff[k + 1] - soff[k].  The wave writes soff[] for the quotes of its unit (unit_str: exclusive prefix of the units'
+// string counts, k_scans); k_s2_emit_planes reads it in order and does not touch masks or records any more (it gathered
+// two 16-byte records per string).  Only units with a \u (or invalid) escape -- whose emit masks k_measure computes
+// escape by escape -- come with records (unit_slow, the predicate of str_masks_body).
+// !DERIVE (WithCopyStrings(false)): records for every unit (stage 1's flatten / k_measure), only units marked by
+// k_str_measure are compacted, into the scratch buffer k_emit_strings copies from.
+template <bool DERIVE>
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
@@ -468,24 +482,106 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     __shared__ u8 s_esc[256];
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
     s_esc[threadIdx.x] = c_esc.v[threadIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the unit's scalars stay in SGPRs)
     const u64 nwaves = (u64)gridDim.x * 4;
     u64 unit = (u64)blockIdx.x * 4 + wave;
-    struct Rec {
-        ChunkRec r;
-        u32 g;  // Strings.B offset of the unit
+    struct Raw {   // what is requested two units ahead
+        u64 qm, q, st;       // DERIVE: the masks of the lane's chunk
+        u32 stp_hi;          // ... and the upper half of st of the chunk in front (bit 31: its last byte starts an escape)
+        ChunkRec r;          // record units
+        u32 g, sb;           // exclusive prefixes of the unit: Strings.B offset, string ordinal
+        u32 h;
+        bool rec, live, last;
     };
-    // (selective copy: a unit without a byte of a string that unescaping changes is not compacted -- nobody reads its
-    // stretch of the scratch buffer; its record reads as "nothing to emit")
-    auto load_rec = [&](u64 u) {
-        Rec x;
+    struct Unit {  // what the wave works with
+        u64 em, esc;      // emit mask; escaped characters that are emitted (DERIVE)
+        u32 pre_raw;      // ChunkRec::pre: emitted bytes of the unit in front of the chunk | CHUNK_SLOW | CHUNK_GENERAL
+        u32 g;
+    };
+    auto load_raw = [&](u64 u) {
+        Raw x;
+        x.qm = x.q = x.st = 0;
+        x.stp_hi = 0;
         x.r = ChunkRec{0, 0, 0};
-        x.g = 0;
-        if (u < p.units && !(p.unit_copy && p.unit_copy[u] == 0)) {
-            x.r = p.rec[u * 64 + lane];
+        x.g = x.sb = x.h = 0;
+        x.rec = false;
+        x.live = u < p.units;
+        x.last = u + 1 == p.units;
+        if (!x.live) return x;
+        const u64 c = u * 64 + lane;
+        if (DERIVE) {
+            const u64 sw = p.sv.unit_slow[u], sp = u ? p.sv.unit_slow[u - 1] : 0ull;
+            x.rec = sw != 0 || (sp >> 63) != 0;  // (wave-uniform; the units str_masks_body has done again)
+            const u32 uh = p.sv.unit_h[u], uhp = u ? (u32)p.sv.unit_h[u - 1] : 0u;
+            x.qm = p.sv.qm[c];
+            x.q = p.sv.q[c];
+            // (the st masks of a unit without an escape starter are zero and stay unread: parking-citations has none at all)
+            if (uh & 2u) x.st = p.sv.st[c];
+            if (c && ((lane ? uh : uhp) & 2u)) x.stp_hi = reinterpret_cast<const u32 *>(arr_at(p.sv.st, c - 1, 1))[1];
+            x.h = uh & 1u;
+            x.sb = p.unit_str[u];
+            if (x.rec) x.r = p.rec[c];
+            x.g = p.unit_cnt[u];
+        } else if (!(p.unit_copy && p.unit_copy[u] == 0)) {
+            // (selective copy: a unit without a byte of a string that unescaping changes is not compacted -- nobody reads its
+            // stretch of the scratch buffer; its record reads as "nothing to emit")
+            x.rec = true;
+            x.r = p.rec[c];
             x.g = p.unit_cnt[u];
         }
         return x;
+    };
+    // DERIVE: the offsets of the unit's strings are staged in the wave's escape list (free between two units' patches) and
+    // leave with coalesced stores; a lane writing the offsets of its chunk's strings straight to memory -- up to eight
+    // scattered 4-byte stores per unit and lane -- made this kernel 30-50 % slower (154 instead of 116 us on configs[1])
+    u32 *const s_so = reinterpret_cast<u32 *>(&s_gu[wave].list[0]);
+    constexpr u32 SO_CAP = 1024;  // (GenUnit::list holds 2052 16-bit entries)
+    auto convert = [&](const Raw &x) {
+        Unit v;
+        v.em = x.r.em;
+        v.pre_raw = x.r.pre;
+        v.esc = 0;
+        v.g = x.g;
+        if (DERIVE) {
+            const ChunkFast f = chunk_fast(x.qm, x.q, x.st, (u64)x.stp_hi << 32, x.h);
+            u32 n, flags;
+            if (x.rec) {  // (uniform) emit mask and flags from k_measure's general routine
+                v.esc = ((x.st << 1) | (u64)(x.stp_hi >> 31)) & v.em;
+                n = (u32)popc64(v.em);
+                flags = v.pre_raw & ~CHUNK_PRE_MASK;
+            } else {
+                v.em = f.em;
+                v.esc = f.esc;
+                n = (u32)popc64(f.em);
+                flags = f.esc != 0 ? CHUNK_SLOW : 0u;
+            }
+            const u32 ns = (u32)popc64(f.oq);
+            const u32 incl = wave_incl_sum(n | (ns << 16));
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            const u32 pre = (incl & 0xffffu) - n, spre = (incl >> 16) - ns, stotal = tot >> 16;
+            v.pre_raw = pre | flags;
+            // the strings that begin in this chunk: their number in the message and their Strings.B offset
+            if (stotal != 0 || x.last) {  // (uniform)
+                const bool staged = stotal <= SO_CAP;  // (uniform)
+                u32 i = spre;
+                for (u64 r = f.oq; r != 0; r &= r - 1, i++) {
+                    const u32 val = x.g + pre + (u32)popc64(v.em & ((1ull << ctz64(r)) - 1ull));
+                    if (staged) s_so[i] = val;
+                    else if (x.sb + i < p.soff_cap) p.soff[x.sb + i] = val;
+                }
+                if (staged) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    for (u32 j = (u32)lane; j < stotal; j += 64)
+                        if (x.sb + j < p.soff_cap) p.soff[x.sb + j] = s_so[j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();  // (the next user of the list waits for these reads)
+                }
+                // (behind the last string: the end of Strings.B, so that every length is a difference)
+                if (x.last && lane == 63 && x.sb + stotal < p.soff_cap) p.soff[x.sb + stotal] = x.g + (tot & 0xffffu);
+            }
+        }
+        return v;
     };
     auto load_chunk = [&](u64 u, u64 em, u32 (&w)[16]) {
         // The chunk must hold message bytes: then its 64-byte line is readable.  An emit mask alone does not say so: a
@@ -501,30 +597,27 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
         }
     };
-    Rec cur = load_rec(unit), nxt = load_rec(unit + nwaves);
+    Unit cur = convert(load_raw(unit)), nxt = convert(load_raw(unit + nwaves));
     __syncthreads();
     if (unit >= p.units) return;
     u8 *in8 = &s_io[wave][0];
     u32 *in32 = reinterpret_cast<u32 *>(in8);
     auto byte_ix = [&](u32 q) { return ((q >> 2) * 64 + lane) * 4 + (q & 3); };
     u32 w[16], w_n[16];
-    load_chunk(unit, cur.r.em, w);
+    load_chunk(unit, cur.em, w);
     for (;;) {
         const u64 c = unit * 64 + lane;
         const u64 next = unit + nwaves;
         const bool more = next < p.units;  // wave-uniform
-        const Rec nn = load_rec(next + nwaves);   // two units ahead
-        load_chunk(next, nxt.r.em, w_n);          // one unit ahead (its record was requested an iteration ago)
-        const u64 em = cur.r.em;
-        const u32 pre_raw = cur.r.pre;
+        const Raw nn = load_raw(next + nwaves);   // two units ahead
+        load_chunk(next, nxt.em, w_n);            // one unit ahead (its masks were requested an iteration ago)
+        const u64 em = cur.em;
+        const u32 pre_raw = cur.pre_raw;
         const u32 pre = pre_raw & CHUNK_PRE_MASK;
         const bool patched = (pre_raw & CHUNK_SLOW) != 0, general = (pre_raw & CHUNK_GENERAL) != 0;
         const u32 n = (u32)popc64(em);
         const u32 total = (u32)__shfl((int)(pre + n), 63, 64);
         const u64 g = (u64)cur.g;  // exclusive prefix: Strings.B offset of the unit
-        // the absolute Strings.B offset of the chunk, for k_s2_emit (which runs behind this kernel): a string then costs
-        // two record loads instead of two records + two unit prefixes
-        if (!p.no_abs && !p.unit_copy) p.rec[c].abs = (u32)g + pre;  // (selective copy takes its offsets from unit_cnt + pre)
         if (total != 0) {  // wave-uniform
             const bool mine = em != 0 && patched;
             if (mine) {
@@ -538,8 +631,11 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
                 // fall into, this one or the next (sj_strings.h str_chunk_patch is the per-chunk statement).
                 u64 le = 0, foreign = 0;
                 if (mine && general) {
-                    const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-                    le = ((stc << 1) | stp) & em;
+                    if (DERIVE) le = cur.esc;
+                    else {
+                        const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+                        le = ((stc << 1) | stp) & em;
+                    }
                 }
                 if (lane == 0 && general && c > 0)  // escapes of the chunk in front whose bytes reach into chunk 0
                     foreign = ((p.sv.esc(c - 1) & p.rec[c - 1].em) >> 60) & 0xfull;
@@ -558,8 +654,13 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
             if (mine) {
                 if (!general) {  // simple escapes only: translated in place, nothing is read from the message
-                    const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-                    for (u64 r = ((stc << 1) | stp) & em; r != 0; r &= r - 1) {
+                    u64 r;
+                    if (DERIVE) r = cur.esc;
+                    else {
+                        const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
+                        r = ((stc << 1) | stp) & em;
+                    }
+                    for (; r != 0; r &= r - 1) {
                         const u32 ix = byte_ix((u32)ctz64(r));
                         in8[ix] = s_esc[in8[ix]];
                     }
@@ -615,7 +716,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         if (!more) break;
         unit = next;
         cur = nxt;
-        nxt = nn;
+        nxt = convert(nn);
 #pragma unroll
         for (int q = 0; q < 16; q++) w[q] = w_n[q];
     }
@@ -666,101 +767,6 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
     PAgg before = pagg_identity();
     if (wave > 0) before = pagg_readlane(t, (wave - 1) & 15);
     return pagg_comb<S>(before, pagg_dpp<S, 0x138, 0xf>(incl));  // wave_shr:1: the lane in front, identity in lane 0
-}
-
-// LDS image of a tile's kinds: s_kind[4 + j] = kind of token t0 + j (K_BAD beyond the end), [2] [3] the two
-// tokens in front of the tile, [4 + S2_TILE] the one behind it
-static constexpr int KIND_LDS = S2_TILE + 8;
-
-// ---- pass 1: tile aggregates ------------------------------------------------------------------------------------
-// 256 threads x 16 tokens: a thread reads its 16 kinds with one 16-byte load; the neighbours' kinds come from LDS.
-static constexpr int RD_BLOCK = 256, RD_ITEMS = S2_TILE / RD_BLOCK;
-static_assert(RD_ITEMS == 16, "one uint4 of kinds per thread");
-__device__ __forceinline__ void s2_reduce_body(const S2Dev &p, u32 block) {
-    __shared__ u32 s_elut[LUT_SIZE];
-    __shared__ __attribute__((aligned(16))) u32 s_k[RD_BLOCK * 4 + 8];  // dword 4 + 4 * tid: the thread's kinds
-    __shared__ PAgg s_w[RD_BLOCK / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 n = token_count(p);
-    if ((u64)block * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
-    s_elut[tid] = c_elut.v[tid];
-    s_elut[tid + 256] = c_elut.v[tid + 256];
-    const u32 t0 = block * S2_TILE, base = t0 + (u32)tid * RD_ITEMS;
-    constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
-    uint4 kv = make_uint4(NL4, NL4, NL4, NL4);
-    if (base + RD_ITEMS <= n) {
-        kv = *reinterpret_cast<const uint4 *>(arr_at(p.kind, base, 16));
-    } else if (base < n) {
-        u32 d[4] = {NL4, NL4, NL4, NL4};
-        for (u32 j = 0; base + j < n; j++) d[j >> 2] = (d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((u32)p.kind[base + j] << (8 * (j & 3)));
-        kv = make_uint4(d[0], d[1], d[2], d[3]);
-    }
-    *reinterpret_cast<uint4 *>(&s_k[4 + 4 * tid]) = kv;
-    if (tid == 0)  // the two tokens in front of the tile (K_NONE in front of the message)
-        s_k[3] = t0 == 0 ? 0x01010101u * K_NONE : ((u32)p.kind[t0 - 2] << 16) | ((u32)p.kind[t0 - 1] << 24);
-    if (tid == 1) s_k[4 + 4 * RD_BLOCK] = (u64)t0 + S2_TILE < n ? (u32)p.kind[t0 + S2_TILE] : (u32)K_NL;
-    // selective copy (WithCopyStrings(false)): a string goes to Strings.B only if unescaping changes it, so every
-    // string is measured here (parseStringSimdValidateOnly); with copy_strings the emit masks give the lengths
-    u32 copied[RD_ITEMS];
-#pragma unroll
-    for (int k = 0; k < RD_ITEMS; k++) copied[k] = 0;
-    const u32 kd4[4] = {kv.x, kv.y, kv.z, kv.w};
-    if (p.sv.qm && !p.copy_strings) {
-        // selective copy on the emit masks: k_str_measure has left the length of every string (one 64-byte load of the
-        // thread's sixteen entries; entries of other tokens are not read)
-        u32 dv[RD_ITEMS];
-        if (base + RD_ITEMS <= n) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
-                dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < RD_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < RD_ITEMS; k++) {
-            const bool str = base + k < n && ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) == K_STRING;
-            copied[k] = (str && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
-        }
-    } else if (!p.sv.qm) {
-        const MsgView mv{p.msg, p.len};
-#pragma unroll
-        for (int k = 0; k < RD_ITEMS; k++) {
-            if (base + k >= n || ((kd4[k >> 2] >> (8 * (k & 3))) & 0xffu) != K_STRING) continue;
-            u32 sl, dl, out;
-            if (!string_walk(mv, p.pos[base + k], nullptr, &sl, &dl)) {
-                out = DLEN_INVALID;
-                atomicOr(&p.st->err, 1u);
-            } else {
-                const bool cp = p.copy_strings || sl != dl;
-                out = dl | (cp ? DLEN_COPY : 0u);
-                copied[k] = cp ? dl : 0u;
-            }
-            p.dlen[base + k] = out;
-        }
-    }
-    __syncthreads();
-    // byte stream: two kinds of the thread in front, the 16 own ones, one of the thread behind
-    const u32 D[6] = {s_k[3 + 4 * tid], kv.x, kv.y, kv.z, kv.w, s_k[8 + 4 * tid]};
-    PAgg acc = pagg_identity();
-#pragma unroll
-    for (int k = 0; k < RD_ITEMS; k++) {
-        const int off = 2 + k;  // byte offset of ppk in the stream
-        const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-        const PAgg te = token_pelement(s_elut, win, copied[k]);  // (no branch around the look-up, see k_s2_emit)
-        const u32 live = base + k < n ? ~0u : 0u;
-        acc = pagg_comb<true>(acc, PAgg{te.x & live, te.y & live, (te.z & live) | (AM_ALL & ~live), te.s & live});
-    }
-    const PAgg incl = pagg_wave_inclusive<true>(acc);
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        PAgg tot = s_w[0];
-        for (int w = 1; w < RD_BLOCK / 64; w++) tot = pagg_comb<true>(tot, s_w[w]);
-        p.agg[block].a = pagg_unpack(tot);
-    }
 }
 
 // ---- selective copy on the emit masks: the length of every string, one string per lane ------------------------------
@@ -945,282 +951,13 @@ __device__ __forceinline__ void scan_tiles_body(const S2Dev &p, int seg) {
 // the tile aggregates (as two launches each cost its ~10 us of fixed latency).
 __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
     if (p.sv.qm) {
-        if ((int)blockIdx.x < p.unit_segs) str_scan_body(p, (int)blockIdx.x);
-        else scan_tiles_body(p, (int)blockIdx.x - p.unit_segs);
+        const int b = (int)blockIdx.x, us = p.unit_segs, ss = p.unit_str ? p.unit_segs : 0;
+        if (b < us) str_scan_body<false>(p, b);
+        else if (b < us + ss) str_scan_body<true>(p, b - us);
+        else scan_tiles_body(p, b - us - ss);
     } else {
         scan_tiles_body(p, (int)blockIdx.x);
     }
-}
-
-// ---- pass 3: offsets + every tape word that needs no bracket partner ----------------------------------------------
-// Everything a token needs from memory (the 8 bytes of an atom, the emit-mask words of a string) is requested
-// for four tokens of a thread at a time before the first use: two memory round trips per tile, not one per token.
-// Number tokens are only queued here (k_numbers parses them with the lanes packed densely).
-// MASKS: every string is copied and the emit masks give offsets and lengths (sj_strings.h); otherwise the
-// lengths measured by k_s2_reduce are read back and the scan carries the Strings.B offsets.
-// (selective copy carries the Strings.B byte count through the scan and the measured lengths in registers: it is given
-// 80 registers -- six waves per SIMD, three blocks per CU -- instead of spilling at 64)
-template <bool MASKS>
-__global__ __launch_bounds__(S2_BLOCK, MASKS ? 8 : 6) void k_s2_emit(S2Dev p) {
-    __shared__ u32 s_elut[LUT_SIZE];
-    __shared__ __attribute__((aligned(16))) u8 s_kind[KIND_LDS];
-    __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
-    __shared__ PAgg s_w[S2_WAVES];
-    // the tile's strings (from the front) and its atoms and numbers (from the back) in one array -- a tile has 4096
-    // tokens, so the two never meet: token index | tape offset inside the tile << 12 | kind << 26
-    __shared__ u32 s_q[S2_TILE];
-    __shared__ u32 s_cnt, s_scnt, s_dcnt, s_base, s_fill, s_ccnt, s_cbase, s_cfill;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 n = token_count(p);
-    if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
-    const u32 t0 = blockIdx.x * S2_TILE, base = t0 + (u32)tid * S2_ITEMS;
-    const u64 tape_len = p.st->tape_len;
-    if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    s_elut[tid] = c_elut.v[tid];
-    if (tid == 0) s_cnt = s_scnt = s_dcnt = s_fill = s_ccnt = s_cfill = 0;
-    const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
-    const u32 endpos = (u32)p.len;
-    constexpr u32 NL4 = 0x01010101u * K_NL;  // behind the last token: K_NL (token_pelement)
-    u32 pp[S2_ITEMS];
-    u32 kv[2] = {NL4, NL4};
-    if (base + S2_ITEMS <= n) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base, 4)), b = *reinterpret_cast<const uint4 *>(arr_at(p.pos, base + 4, 4));
-        pp[0] = a.x; pp[1] = a.y; pp[2] = a.z; pp[3] = a.w;
-        pp[4] = b.x; pp[5] = b.y; pp[6] = b.z; pp[7] = b.w;
-        const uint2 k2 = *reinterpret_cast<const uint2 *>(arr_at(p.kind, base, 8));
-        kv[0] = k2.x;
-        kv[1] = k2.y;
-    } else {
-#pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++) {
-            pp[k] = endpos;
-            if (base + k < n) {
-                pp[k] = p.pos[base + k];
-                kv[k >> 2] = (kv[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((u32)p.kind[base + k] << (8 * (k & 3)));
-            }
-        }
-    }
-    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS]) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-    *reinterpret_cast<uint4 *>(&s_pos[tid * S2_ITEMS + 4]) = make_uint4(pp[4], pp[5], pp[6], pp[7]);
-    *reinterpret_cast<uint2 *>(&s_kind[4 + tid * S2_ITEMS]) = make_uint2(kv[0], kv[1]);  // 4-byte aligned
-    if (tid < 2) s_kind[2 + tid] = t0 + (u32)tid >= 2u ? p.kind[t0 + (u32)tid - 2u] : (u8)K_NONE;
-    if (tid == 2) {
-        const bool more = (u64)t0 + S2_TILE < n;
-        s_kind[4 + S2_TILE] = more ? p.kind[t0 + S2_TILE] : (u8)K_NL;
-        s_pos[S2_TILE] = more ? p.pos[t0 + S2_TILE] : endpos;
-    }
-    const MsgView mv{p.msg, p.len};
-    // tokens behind the end of the message have kind K_NL and the identity element: they fall through everything
-    u8 kd[S2_ITEMS];
-    bool is_str[S2_ITEMS], is_atom[S2_ITEMS];
-    u32 dl[S2_ITEMS], copied[S2_ITEMS];  // selective copy: measured lengths
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        kd[k] = (u8)((kv[k >> 2] >> (8 * (k & 3))) & 0xffu);
-        is_str[k] = kd[k] == K_STRING;
-        is_atom[k] = (u32)(kd[k] - K_TRUE) < 3u;
-        dl[k] = copied[k] = 0;
-    }
-    if (!MASKS) {  // the measured lengths: the thread's eight entries as two 16-byte loads (only string entries are defined)
-        if (base + S2_ITEMS <= n) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base, 4)), b = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4, 4));
-            dl[0] = a.x; dl[1] = a.y; dl[2] = a.z; dl[3] = a.w;
-            dl[4] = b.x; dl[5] = b.y; dl[6] = b.z; dl[7] = b.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < S2_ITEMS; k++)
-                if (base + k < n) dl[k] = p.dlen[base + k];
-        }
-#pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++)
-            copied[k] = (is_str[k] && dl[k] != DLEN_INVALID && (dl[k] & DLEN_COPY)) ? (dl[k] & ~DLEN_COPY) : 0u;
-    }
-    __syncthreads();
-    // ---- elements and the scan inside the tile
-    PAgg e[S2_ITEMS];
-    {
-        const u32 *k32 = reinterpret_cast<const u32 *>(s_kind);
-        // byte stream: two kinds of the thread in front, the 8 own ones, one of the thread behind
-        const u32 D[4] = {k32[2 * tid], kv[0], kv[1], k32[2 * tid + 3]};
-#pragma unroll
-        for (int k = 0; k < S2_ITEMS; k++) {
-            const int off = 2 + k;  // byte offset of ppk in the stream
-            const u32 win = (off & 3) ? __builtin_amdgcn_alignbyte(D[(off >> 2) + 1], D[off >> 2], off & 3) : D[off >> 2];
-            // (no branch around the table look-up: eight dependent LDS round trips otherwise; tokens behind the end
-            // carry sentinel kinds, their element is masked to the identity)
-            const PAgg te = token_pelement(s_elut, win, copied[k]);
-            const u32 live = base + k < n ? ~0u : 0u;
-            e[k] = PAgg{te.x & live, te.y & live, (te.z & live) | (AM_ALL & ~live), te.s & live};
-        }
-    }
-    PAgg mine = e[0];
-#pragma unroll
-    for (int k = 1; k < S2_ITEMS; k++) mine = pagg_comb<!MASKS>(mine, e[k]);
-    PAgg total;
-    PAgg lp = pagg_block_exclusive<!MASKS, S2_WAVES>(mine, s_w, lane, wave, total);  // prefix inside the tile
-    bool bad = false;
-    // Queues.  A thread's eight tokens are of any kind, so a loop over them runs the code of EVERY kind eight times with
-    // most lanes masked off, and the kernel is bound by VALU issue (70 % busy; a wave64 instruction holds a SIMD for
-    // four cycles).  Only what is cheap per token stays in that loop; strings (every string copied: two record gathers,
-    // two 64-bit popcounts), atoms and numbers are entered into queues in LDS (token index | tape offset inside the tile
-    // << 12) and worked on afterwards with the lanes packed densely: a kind costs ceil(count / 512) passes instead of 8.
-    u32 nnum = 0, nstr = 0, natom = 0;
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        nnum += kd[k] == K_NUM ? 1u : 0u;
-        nstr += is_str[k] ? 1u : 0u;
-        natom += is_atom[k] ? 1u : 0u;
-    }
-    // queue slots: the counts of a wave are summed with a DPP scan and one lane draws the wave's ranges (an LDS atomic
-    // that all 64 lanes aim at the same counter is executed a lane at a time)
-    u32 sslot = 0, dslot = 0;
-    {
-        const u32 pk = nstr | ((natom + nnum) << 10) | (nnum << 20);  // <= 512 each per wave
-        u32 incl = pk;
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);  // row_shr:1
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);  // row_shr:2
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);  // row_shr:4
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);  // row_shr:8
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-        incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-        const u32 wtot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        u32 sb = 0, db = 0;
-        if (lane == 63) {
-            if (wtot & 0x3ffu) sb = atomicAdd(&s_scnt, wtot & 0x3ffu);
-            if ((wtot >> 10) & 0x3ffu) db = atomicAdd(&s_dcnt, (wtot >> 10) & 0x3ffu);
-            if (wtot >> 20) atomicAdd(&s_cnt, wtot >> 20);
-        }
-        sb = (u32)__builtin_amdgcn_readlane((int)sb, 63);
-        db = (u32)__builtin_amdgcn_readlane((int)db, 63);
-        const u32 ex = incl - pk;
-        sslot = sb + (ex & 0x3ffu);
-        dslot = db + ((ex >> 10) & 0x3ffu);
-        if (!MASKS) {  // selective copy: the tile's strings that k_emit_strings will copy (one global atomic per tile below)
-            u32 nc = 0;
-#pragma unroll
-            for (int k = 0; k < S2_ITEMS; k++) nc += copied[k] != 0u ? 1u : 0u;
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x111, 0xf, 0xf, false);
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x112, 0xf, 0xf, false);
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x114, 0xf, 0xf, false);
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x118, 0xf, 0xf, false);
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x142, 0xa, 0xf, false);
-            nc += (u32)__builtin_amdgcn_update_dpp(0, (int)nc, 0x143, 0xc, 0xf, false);
-            if (lane == 63 && nc) atomicAdd(&s_ccnt, nc);
-        }
-    }
-    const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
-#pragma unroll
-    for (int k = 0; k < S2_ITEMS; k++) {
-        const u32 lo = lp.x & 0x3fffu;  // tape words of the tile in front of this token
-        const u32 o = T0 + lo;
-        const u32 qe = (u32)(tid * S2_ITEMS + k) | (lo << 12);
-        bad |= am_value(e[k].z) == 0;  // legal in no context at all
-        if (is_str[k]) {  // worked on densely below; selective copy: the scan has the Strings.B offset, keep it for then
-            s_q[sslot++] = qe;
-            // (in the slot of the token's own position, which the dense pass reads back from memory: no LDS of its own)
-            if (!MASKS) s_pos[tid * S2_ITEMS + k] = lp.s;
-        }
-        if (is_atom[k] || (kd[k] == K_NUM && !SJ_EXPBIT(p, 9))) s_q[S2_TILE - 1 - dslot++] = qe | ((u32)kd[k] << 26);
-        if ((u32)(kd[k] - K_OPEN_OBJ) < 4u && !SJ_EXPBIT(p, 3)) {
-            const u32 lbc = lp.x >> 14;
-            const u32 c = tp.bc + lbc;  // brackets in front of this one
-            const i32 d_before = tp.d + (i32)(2u * (lp.y & 0x1fffu)) - (i32)lbc;
-            p.br_depth[c] = d_before + (is_open(kd[k]) ? 1 : -1);
-            p.br_off[c] = o;
-            p.br_info[c] = (u8)(kd[k] | (am_value(am_combine(am_combine(tp.am, lp.z), e[k].z)) << 4));
-        }
-        if (e[k].y >> 13) p.nl_off[tp.nb + (lp.y >> 13)] = o;
-        lp = pagg_comb<!MASKS>(lp, e[k]);
-    }
-    __syncthreads();  // the queues are complete
-    // ---- strings: Strings.B offset and unescaped length from the emit masks (sj_strings.h), both tape words in one
-    // 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
-    if (MASKS && !SJ_EXPBIT(p, 0)) {
-        const u32 ns = s_scnt;
-        for (u32 j = (u32)tid; j < ns; j += S2_BLOCK) {
-            const u32 v = s_q[j], idx = v & 0xfffu;
-            const u64 a0 = (u64)s_pos[idx] + p.sv.lead + 1, a1 = (u64)s_pos[idx + 1] + p.sv.lead;
-            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];  // one 16-byte load each
-            const u32 b0 = (u32)a0 & 63u, b1 = (u32)a1 & 63u;
-            // absolute Strings.B offset of the chunk (left by k_str_emit, or unit prefix + bytes of the unit in front) + inside
-            const u64 c0 = p.no_abs ? (u64)p.unit_cnt[a0 >> 12] + (r0.pre & CHUNK_PRE_MASK) : (u64)r0.abs;
-            const u64 c1 = p.no_abs ? (u64)p.unit_cnt[a1 >> 12] + (r1.pre & CHUNK_PRE_MASK) : (u64)r1.abs;
-            const u64 so = c0 + (u64)popc64(r0.em & ~(~0ull << b0));
-            const u64 se = c1 + (u64)popc64(r1.em & ~(~0ull << b1));
-            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
-            if (!SJ_EXPBIT(p, 2))
-                *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-            if (p.keyflag) p.keyflag[(T0 + (v >> 12)) >> 1] = s_kind[4 + idx + 1] == K_COLON ? 1 : 0;
-        }
-    }
-    // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
-    // a string that unescaping changed points into Strings.B and is queued for k_emit_strings with everything that kernel
-    // needs, the others point into the message (parseString, stage2_build_tape_amd64.go:90-109)
-    if (!MASKS) {
-        const u32 ns = s_scnt;
-        if (tid == 0 && s_ccnt != 0 && p.sv.qm) s_cbase = atomicAdd(&p.st->str_count, s_ccnt);
-        __syncthreads();
-        for (u32 j0 = 0; j0 < ns; j0 += S2_BLOCK) {  // (block-uniform trip count: the ballots below want whole waves)
-            const u32 j = j0 + (u32)tid;
-            bool queue = false;
-            u32 at = 0, so = 0, len = 0;
-            if (j < ns) {
-                const u32 v = s_q[j], idx = v & 0xfffu;
-                const u32 dlw = p.dlen[t0 + idx];
-                at = p.pos[t0 + idx];
-                so = tp.s + s_pos[idx];
-                if (dlw != DLEN_INVALID) {
-                    const bool cp = (dlw & DLEN_COPY) != 0;
-                    len = dlw & ~DLEN_COPY;
-                    const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = len;
-                    *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + (v >> 12), 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-                    if (p.keyflag) p.keyflag[(T0 + (v >> 12)) >> 1] = s_kind[4 + idx + 1] == K_COLON ? 1 : 0;
-                    if (!p.sv.qm) p.str_off[t0 + idx] = so;  // (per-string walks: k_emit_strings looks the offset up per token)
-                    queue = cp && len != 0 && p.sv.qm;
-                }
-            }
-            // queue slots inside the tile's range: one LDS atomic per wave and pass, the lanes take consecutive entries
-            // (a global atomic per wave instead -- 46 000 on one word for configs[1] -- took the kernel from 0.2 to 1.07 ms)
-            const u64 qm = __ballot(queue);
-            if (qm != 0) {
-                u32 qbase = 0;
-                if (lane == 0) qbase = atomicAdd(&s_cfill, (u32)__popcll(qm));
-                qbase = s_cbase + (u32)__builtin_amdgcn_readfirstlane((int)qbase);
-                const u32 slot = qbase + (u32)__popcll(qm & ((1ull << lane) - 1ull));
-                if (queue && slot < p.strq_cap) p.strq[slot] = make_uint4(at, so, len, 0u);
-            }
-        }
-    }
-    // ---- atoms: validated from the 8 message bytes at the token; numbers move to the global queue (k_numbers parses
-    // them with the lanes packed densely; the order of the queue does not matter)
-    {
-        const u32 nd = s_dcnt, cnt = s_cnt;
-        if (cnt != 0 && tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
-        if (cnt != 0) __syncthreads();  // (block-uniform)
-        const u32 qb = s_base;
-        for (u32 j = (u32)tid; j < nd; j += S2_BLOCK) {
-            const u32 v = s_q[S2_TILE - 1 - j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x3fffu);
-            const u8 ak = (u8)(v >> 26);
-            if (ak == K_NUM) {
-                // A plain integer of up to 18 digits is parsed here, from three 8-byte loads, and its two words leave with
-                // the tile's own stretch of the tape (sj_number.h parse_int_fast); everything else is queued for
-                // k_numbers (the slots of the numbers taken here stay unused: k_numbers skips them).  twitter.json holds
-                // 2 840 numbers, all but a handful such integers: a queue entry written and read, a 64-byte sector of the
-                // message fetched a second time and a 16-byte tape store on its own sector less for each of them.
-                u64 iv = 0;
-                const bool fast = !SJ_EXPBIT(p, 9) && parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
-                if (fast) {
-                    const u64 tw = (u64)'l' << 56;
-                    if (!SJ_EXPBIT(p, 2)) *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
-                }
-                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(fast ? 0xffffffffu : at, o);
-            } else {
-                bad |= !atom_valid_word(SJ_EXPBIT(p, 1) ? 0ull : load8_guarded(mv, at), p.len - at, ak);
-                if (!SJ_EXPBIT(p, 2)) p.tape[o] = atom_word(ak);
-            }
-        }
-    }
-    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(&p.st->err, 1u);
 }
 
 __device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); }  // m != 0
@@ -1326,6 +1063,9 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
             p.dlen[base + k] = out;
         }
     }
+    // (every string copied from the masks: the scan's byte field carries the NUMBER of strings instead -- the tile's first
+    // string is string number Agg::s of the message, whose Strings.B offset k_str_emit leaves in soff[])
+    if (p.sv.qm && p.copy_strings) sbytes = popc32(m.str);
     PAgg acc = lane16_pagg(m);
     acc.s = sbytes;
     const PAgg incl = pagg_wave_inclusive<true>(acc);
@@ -1341,8 +1081,7 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
 __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
     if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
-    else if (p.variant) s2_reduce_planes(p, blockIdx.x - mblocks);
-    else s2_reduce_body(p, blockIdx.x - mblocks);
+    else s2_reduce_planes(p, blockIdx.x - mblocks);
 }
 
 // ---- pass 3 on planes -----------------------------------------------------------------------------------------------
@@ -1352,8 +1091,10 @@ template <bool MASKS, int ITEMS>
 __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit_planes(S2Dev p) {
     constexpr int BLK = S2_TILE / ITEMS, WAVES = BLK / 64;
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
-    // strings [0, S) | the tile's brackets [S, S + B) | atoms and numbers [S + B, S + B + D): a tile has 4096 tokens
-    __shared__ u32 s_q[S2_TILE];
+    // strings [0, S) | the tile's brackets [SB, SB + B) | atoms and numbers [SB + B, SB + B + D): a tile has 4096 tokens.
+    // MASKS (every string copied): no string queue -- [0, S] holds the Strings.B offsets of the tile's S strings and of the
+    // string behind them (soff[], left by k_str_emit in message order = token order), SB = S + 1; otherwise SB = S
+    __shared__ u32 s_q[S2_TILE + 8];
     __shared__ u32 s_edge[BLK + 2];
     __shared__ PAgg s_w[WAVES];
     __shared__ u32 s_wc[WAVES];
@@ -1442,25 +1183,28 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         if (lane == 63 && nn) atomicAdd(&s_nnum, nn);
     }
     const u32 S = ctot & 0x1fffu, D = ctot >> 13, B = total.x >> 14;
+    const u32 SB = MASKS ? S + 1u : S;
+    if (MASKS) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
+        for (u32 j = (u32)tid; j <= S; j += BLK) s_q[j] = tp.s + j < p.soff_cap ? p.soff[tp.s + j] : 0u;
+    }
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
     const u32 lane_w = ex.x & 0x3fffu, lane_bc = ex.x >> 14, lane_open = ex.y & 0x1fffu, lane_nb = ex.y >> 13;
     bool bad = lane16_illegal(m);  // a token that is legal in no context at all
-    {
+    if (!MASKS) {
         u32 slot = cex & 0x1fffu, run = ex.s;
         for (u32 r = m.str; r != 0; r &= r - 1) {  // strings: worked on densely below
             const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             s_q[slot++] = idx | ((lane_w + lane16_words_before(m, j)) << 12) | (((m.keystr >> j) & 1u) << 25);
-            if (!MASKS) {  // the Strings.B offset of the string inside the tile, in the slot of the token's own position
-                s_pos[idx] = run;  // (the dense pass reads the position back from memory: no LDS of its own)
-                u32 c = 0;
+            // the Strings.B offset of the string inside the tile, in the slot of the token's own position
+            s_pos[idx] = run;  // (the dense pass reads the position back from memory: no LDS of its own)
+            u32 c = 0;
 #pragma unroll
-                for (int k = 0; k < ITEMS; k++) c = (u32)k == j ? dv[k] : c;
-                run += c;
-            }
+            for (int k = 0; k < ITEMS; k++) c = (u32)k == j ? dv[k] : c;
+            run += c;
         }
     }
     {
-        u32 slot = S + B + (cex >> 13);
+        u32 slot = SB + B + (cex >> 13);
         for (u32 r = m.num | m.atom; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             const u32 kd = ((m.num >> j) & 1u) ? (u32)K_NUM : (u32)lane16_atom_kind(m, j);
@@ -1468,7 +1212,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     {
-        u32 slot = S + lane_bc;
+        u32 slot = SB + lane_bc;
         const u32 am_in = am_combine(tp.am, ex.z);
         for (u32 r = m.br; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), upto = (2u << j) - 1u;
@@ -1481,43 +1225,17 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         p.nl_off[tp.nb + lane_nb + popc32(m.nlr & ((1u << j) - 1u))] = T0 + lane_w + lane16_words_before(m, j);
     }
     __syncthreads();  // the queues and the bracket list are complete
-    // ---- strings: Strings.B offset and unescaped length from the emit masks (sj_strings.h), both tape words in one
-    // 16-byte store (the tape is only 8-byte aligned: fine on gfx950)
+    // ---- strings, every string copied: string number (tp.s + index inside the tile) of the message -> its Strings.B offset,
+    // and the next string's offset ends it (Strings.B is the concatenation of all strings); both tape words in one 16-byte
+    // store (the tape is only 8-byte aligned: fine on gfx950).  No gathers: a lane's strings are consecutive entries.
     if (MASKS) {
-        // two strings per thread and round, every gather of both requested before the first use (a tile's strings are a few
-        // rounds of the block: the pass is a chain of dependent round trips, not instructions)
-        struct SLoad {
-            ChunkRec r0, r1;
-            u64 c0, c1, a0, a1;
-        };
-        auto sload = [&](u32 idx) {
-            SLoad x;
-            x.a0 = (u64)s_pos[idx] + p.sv.lead + 1;
-            x.a1 = (u64)s_pos[idx + 1] + p.sv.lead;
-            x.r0 = p.rec[x.a0 >> 6];  // one 16-byte load each
-            x.r1 = p.rec[x.a1 >> 6];
-            // absolute Strings.B offset of the chunk (left by k_str_emit, or unit prefix + bytes of the unit in front) + inside
-            x.c0 = p.no_abs ? (u64)p.unit_cnt[x.a0 >> 12] : 0ull;
-            x.c1 = p.no_abs ? (u64)p.unit_cnt[x.a1 >> 12] : 0ull;
-            return x;
-        };
-        auto sstore = [&](u32 v, const SLoad &x) {
-            const u32 lo = (v >> 12) & 0x1fffu;
-            const u32 b0 = (u32)x.a0 & 63u, b1 = (u32)x.a1 & 63u;
-            const u64 c0 = p.no_abs ? x.c0 + (x.r0.pre & CHUNK_PRE_MASK) : (u64)x.r0.abs;
-            const u64 c1 = p.no_abs ? x.c1 + (x.r1.pre & CHUNK_PRE_MASK) : (u64)x.r1.abs;
-            const u64 so = c0 + (u64)popc64(x.r0.em & ~(~0ull << b0));
-            const u64 se = c1 + (u64)popc64(x.r1.em & ~(~0ull << b1));
-            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = se - so;
+        u32 ks = cex & 0x1fffu;
+        for (u32 r = m.str; r != 0; r &= r - 1, ks++) {
+            const u32 j = (u32)__builtin_ctz(r), lo = lane_w + lane16_words_before(m, j);
+            const u32 so = s_q[ks], se = s_q[ks + 1];
+            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
             *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-            if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
-        };
-        for (u32 j = (u32)tid; j < S; j += 2 * BLK) {
-            const bool two = j + BLK < S;
-            const u32 va = s_q[j], vb = two ? s_q[j + BLK] : va;
-            const SLoad xa = sload(va & 0xfffu), xb = sload(vb & 0xfffu);
-            sstore(va, xa);
-            if (two) sstore(vb, xb);
+            if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((m.keystr >> j) & 1u);
         }
     }
     // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
@@ -1564,7 +1282,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         if (cnt != 0) __syncthreads();  // (block-uniform)
         const u32 qb = s_base;
         for (u32 j = (u32)tid; j < D; j += BLK) {
-            const u32 v = s_q[S + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+            const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
             const u8 ak = (u8)(8u + ((v >> 26) & 3u));
             if (ak == K_NUM) {
                 u64 iv = 0;
@@ -1588,7 +1306,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         const u32 G = (B + 63u) / 64u;
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // the minimum depth of every group of 64
             const u32 c = g * 64u + (u32)lane;
-            i32 v = c < B ? tbr_depth(s_q[S + c]) : 0x7fffffff;
+            i32 v = c < B ? tbr_depth(s_q[SB + c]) : 0x7fffffff;
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) {
                 const i32 o = __shfl_xor(v, sft, 64);
@@ -1601,7 +1319,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // wave-uniform
             const u32 c = g * 64u + (u32)lane;
             const bool valid = c < B;
-            const u32 e = valid ? s_q[S + c] : 0u;
+            const u32 e = valid ? s_q[SB + c] : 0u;
             const i32 drel = valid ? tbr_depth(e) : 0x7fffffff;
             const u8 kd = tbr_kind(e);
             const u32 gap = tbr_gap(e), oc = T0 + tbr_off(e);
@@ -1635,7 +1353,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 while (cand != 0 && pm != 0) {
                     const u32 gp = (u32)top_bit(cand);
                     cand &= ~(1ull << gp);
-                    const i32 dprev = tbr_depth(s_q[S + gp * 64u + (u32)lane]);  // (a group in front is full)
+                    const i32 dprev = tbr_depth(s_q[SB + gp * 64u + (u32)lane]);  // (a group in front is full)
                     for (u64 pp = pm; pp != 0;) {
                         const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pp));
                         const u64 at = __ballot(dprev <= v);
@@ -1655,7 +1373,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 bad |= !context_allowed(gap, CTX_ROOT);
                 done = true;
             } else if (res >= 0) {
-                const u32 ej = s_q[S + (u32)res + 1u];  // partner (close) / parent (open)
+                const u32 ej = s_q[SB + (u32)res + 1u];  // partner (close) / parent (open)
                 const u8 jk = tbr_kind(ej);
                 bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
                 done = true;
@@ -2039,7 +1757,7 @@ static u32 persistent_blocks(K kernel, u64 want) {
 }
 
 // the zeroed region: S2State and the segment slots of the two scans (zeroed by stage 1's preparation kernel)
-size_t stage2_zero_bytes() { return (sizeof(S2State) + 2 * SCAN_SEGS * sizeof(SegSlot) + 255) / 256 * 256; }
+size_t stage2_zero_bytes() { return (sizeof(S2State) + 3 * SCAN_SEGS * sizeof(SegSlot) + 255) / 256 * 256; }
 
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = 256;
@@ -2069,6 +1787,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.st = reinterpret_cast<S2State *>(a.ws_zero);
     p.seg_units = reinterpret_cast<SegSlot *>(reinterpret_cast<char *>(a.ws_zero) + sizeof(S2State));
     p.seg_tiles = p.seg_units + SCAN_SEGS;
+    p.seg_ustr = p.seg_tiles + SCAN_SEGS;
     p.msg = SJ_ARR(reinterpret_cast<const u8 *>(a.d_msg), a.len, A_MSG);
     p.len = a.len;
     p.pos = SJ_ARR(a.d_pos, n, A_POS);
@@ -2076,7 +1795,6 @@ static S2Dev stage2_view(const S2Args &a) {
     p.n_dev = a.n_dev;
     p.ndjson = a.flags & 1u;
     p.copy_strings = (a.flags >> 1) & 1u;
-    p.no_abs = (a.flags & S2_FLAG_NO_ABS) ? 1u : 0u;
     p.kind = SJ_ARR(a.d_kind, n, A_KIND);
     p.br_info = SJ_ARR(reinterpret_cast<u8 *>(carve(n + 16)), n + 16, A_BR_INFO);
     p.dlen = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_DLEN);
@@ -2129,13 +1847,12 @@ static S2Dev stage2_view(const S2Args &a) {
     p.sv.unit_slow = nullptr;
     p.rec = nullptr;
     p.unit_cnt = nullptr;
+    p.unit_str = nullptr;
+    p.soff = nullptr;
+    p.soff_cap = 0;
     p.unit_copy = nullptr;
     p.units = 0;
     p.exp = 0;
-    {
-        static const int v = getenv("SJHIP_S2_VARIANT") ? atoi(getenv("SJHIP_S2_VARIANT")) : 1;
-        p.variant = v != 0;
-    }
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
 #endif
@@ -2151,6 +1868,12 @@ static S2Dev stage2_view(const S2Args &a) {
         p.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(x.rec), x.chunks, A_REC);
         p.unit_cnt = SJ_ARR(x.unit_cnt, x.units, A_UNIT_CNT);
         if (!p.copy_strings) p.unit_copy = SJ_ARR(x.unit_copy, x.units, A_UNIT_COPY);
+        else {  // every string copied: the strings of the message are numbered, their Strings.B offsets go where the measured
+                // lengths of the other mode lie (dlen and str_off are adjacent: 2 x align_up(4n, 256) >= 4 (n + 2) bytes)
+            p.unit_str = SJ_ARR(x.unit_str, x.units, A_UNIT_STR);
+            p.soff_cap = (u32)(n + 2 < 0xffffffffull ? n + 2 : 0xffffffffull);
+            p.soff = SJ_ARR(arr_raw(p.dlen), p.soff_cap, A_SOFF);
+        }
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
     return p;
@@ -2180,7 +1903,7 @@ hipError_t stage2_launch_measure(const S2Args &a) {
         const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
         hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
     }
-    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? p.unit_segs + p.tile_segs : p.tile_segs), dim3(1024), 0, a.stream, p);
+    hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? p.unit_segs * (p.unit_str ? 2 : 1) + p.tile_segs : p.tile_segs), dim3(1024), 0, a.stream, p);
     return hipGetLastError();
 }
 
@@ -2192,27 +1915,16 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     const size_t n = a.n;
     if (n == 0) return hipSuccess;
     const u32 gb = (u32)((n + 255) / 256);
-    // The string bytes: in front of the tape kernels (k_str_emit then leaves every chunk's absolute Strings.B offset
-    // for k_s2_emit), or, with S2_FLAG_NO_ABS and a side stream, beside them: k_str_emit streams at HBM speed while
-    // k_br_match / k_min_upper / k_numbers wait on dependent loads, so the two chains fill each other's gaps.
+    // The string bytes run in front of the tape kernels: every string copied -- k_str_emit leaves the Strings.B offset of
+    // every string of the message (soff[]) for k_s2_emit_planes; WithCopyStrings(false) -- the compaction of the units that
+    // hold strings to be copied goes to the scratch buffer k_emit_strings takes them from.  (Rounds 3 and 4 could also run
+    // k_str_emit on a second stream beside the tape kernels, SJHIP_S2_OVERLAP: -2 % / +3 % on the two workloads, never the
+    // default; gone with the records the tape kernels read then.)
     const bool masks_copy = p.sv.qm && p.copy_strings;  // every string copied: offsets and lengths straight from the emit masks
-    const bool beside = masks_copy && a.side && (a.flags & S2_FLAG_NO_ABS);
-    const bool late = beside && (a.flags & S2_FLAG_FORK_LATE);  // the side stream starts behind k_s2_emit
-    auto fork_strings = [&]() -> hipError_t {
-        hipError_t e = hipEventRecord(a.ev_fork, a.stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(a.side, a.ev_fork, 0);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.side, p);
-        return hipEventRecord(a.ev_join, a.side);
-    };
-    if (beside && !late) {
-        const hipError_t e = fork_strings();
-        if (e != hipSuccess) return e;
-    } else if (p.sv.qm && !beside) {
-        hipLaunchKernelGGL(k_str_emit, dim3(persistent_blocks(k_str_emit, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
-    }
-    if (p.variant) {
-        static const int items = getenv("SJHIP_S2_ITEMS") ? atoi(getenv("SJHIP_S2_ITEMS")) : 8;
+    if (masks_copy) hipLaunchKernelGGL(k_str_emit<true>, dim3(persistent_blocks(k_str_emit<true>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    else if (p.sv.qm) hipLaunchKernelGGL(k_str_emit<false>, dim3(persistent_blocks(k_str_emit<false>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    {
+        static const int items = getenv("SJHIP_S2_ITEMS") ? atoi(getenv("SJHIP_S2_ITEMS")) : 8;  // tokens per lane (A/B)
         if (items == 16) {
             if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
             else hipLaunchKernelGGL((k_s2_emit_planes<false, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
@@ -2220,13 +1932,6 @@ hipError_t stage2_launch_emit(const S2Args &a) {
             if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
             else hipLaunchKernelGGL((k_s2_emit_planes<false, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
         }
-    } else {
-        if (masks_copy) hipLaunchKernelGGL(k_s2_emit<true>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
-        else hipLaunchKernelGGL(k_s2_emit<false>, dim3(p.tiles), dim3(S2_BLOCK), 0, a.stream, p);
-    }
-    if (late) {
-        const hipError_t e = fork_strings();
-        if (e != hipSuccess) return e;
     }
     {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count).
         // (Measured and dropped in round 4: the numbers beside the bracket matcher instead -- both wait on dependent
@@ -2239,10 +1944,6 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     if (!masks_copy) hipLaunchKernelGGL(k_emit_strings, dim3(p.sv.qm ? (gb < 2048 ? gb : 2048) : gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 2048 ? gb : 2048), dim3(256), 0, a.stream, p);  // (8 waves per SIMD resident)
-    if (beside) {
-        const hipError_t e = hipStreamWaitEvent(a.stream, a.ev_join, 0);
-        if (e != hipSuccess) return e;
-    }
     return hipGetLastError();
 }
 

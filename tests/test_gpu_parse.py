@@ -555,11 +555,10 @@ def test_sharded_parse_nd_equals_oracle(ctx, world, copy_strings):
         assert np.array_equal(np.concatenate(strs), ref.strings)
 
 
-@pytest.mark.parametrize("mode", ["0", "2", "3"])
-def test_stage2_overlap_modes_equal_default(mode):
-    """SJHIP_S2_OVERLAP (parse_api.hip) selects where k_str_emit runs and who computes the chunk offsets: 0 = in front of
-    the tape kernels with absolute offsets in the records, 1 = default, 2 / 3 = on the side stream.  Every mode must
-    produce the oracle's tape; the variable is read once per process, so each mode runs in its own interpreter."""
+def test_emit_sixteen_tokens_per_lane_equals_default():
+    """SJHIP_S2_ITEMS=16 (stage2.hip stage2_launch_emit) runs the emit pass with sixteen tokens per lane (256 threads per
+    4096-token tile) instead of eight -- the A/B shape of round 5.  Both copy modes must produce the oracle's tape; the
+    variable is read once per process, so the variant runs in its own interpreter."""
     import os
     import subprocess
     import sys
@@ -572,17 +571,17 @@ ctx = sjhip.Context(0)
 docs = [(fixtures.load(n), n == 'parking-citations') for n in ('twitter', 'twitterescaped', 'canada', 'parking-citations', 'mesh.pretty')]
 docs.append((workloads.c5_parking_nd(30), True))            # > SJHIP_SMALL_BYTES: two host synchronisations
 docs.append((workloads.c2_twitter_array(9), False))
-for rep in range(2):
+for copy in (True, False):
     for d, nd in docs:
-        ref = O.parse(d, ndjson=nd, copy_strings=True)
-        pj = ctx.parse(d, ndjson=nd, copy_strings=True)
-        assert ref.rc == 0 and np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), (len(d), nd)
+        ref = O.parse(d, ndjson=nd, copy_strings=copy)
+        pj = ctx.parse(d, ndjson=nd, copy_strings=copy)
+        assert ref.rc == 0 and np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), (len(d), nd, copy)
 print('ok')
 """
-    env = dict(os.environ, SJHIP_S2_OVERLAP=mode)
+    env = dict(os.environ, SJHIP_S2_ITEMS="16")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (mode, r.stdout[-500:], r.stderr[-1500:])
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_fetch_after_small_parse_paths(ctx):
