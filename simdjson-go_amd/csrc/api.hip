@@ -82,7 +82,7 @@ sjhip_ctx *sjhip_ctx_create(int device) {
 // every device arena of a context
 #define SJ_CTX_ARENAS(ctx)                                                                                                   \
     {&(ctx)->d_msg, &(ctx)->d_pos, &(ctx)->d_ws, &(ctx)->d_kat, &(ctx)->d_tape, &(ctx)->d_strings, &(ctx)->d_s2, &(ctx)->d_s2z, \
-     &(ctx)->d_aux, &(ctx)->d_scol, &(ctx)->d_stab, &(ctx)->d_q, &(ctx)->d_qtape, &(ctx)->d_qstrings, &(ctx)->d_strtmp,       \
+     &(ctx)->d_aux, &(ctx)->d_scol, &(ctx)->d_stab, &(ctx)->d_q, &(ctx)->d_qtape, &(ctx)->d_qstrings,       \
      &(ctx)->d_keyflag}
 
 size_t sjhip_ctx_device_bytes(const sjhip_ctx *ctx) {
@@ -209,7 +209,7 @@ static void invalidate_result(sjhip_ctx *ctx) {
 // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
 // would hand positions to other streams before they are visible there.)
 int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                       uint8_t *d_kind, void *zero2, size_t zero2_bytes, bool aux_records) {
+                       uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
     if (len >= 0xffffffc0ull) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
@@ -220,7 +220,7 @@ int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson
     if (len > 0) {
         *(volatile unsigned long long *)ctx->h_scratch = 0;
         HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
-                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes, aux_records),
+                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
                "stage1 launch");
     }
     return SJHIP_OK;
@@ -263,8 +263,8 @@ int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_l
 
 int sj::stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                           uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux, uint8_t *d_kind, void *zero2,
-                          size_t zero2_bytes, bool aux_records) {
-    int rc = stage1_enqueue(ctx, d_msg, len, ndjson, d_pos, pos_cap, str_aux, d_kind, zero2, zero2_bytes, aux_records);
+                          size_t zero2_bytes) {
+    int rc = stage1_enqueue(ctx, d_msg, len, ndjson, d_pos, pos_cap, str_aux, d_kind, zero2, zero2_bytes);
     if (rc) return rc;
     if (len > 0) HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
     return stage1_collect(ctx, len, last_byte, have_last, n, ok);

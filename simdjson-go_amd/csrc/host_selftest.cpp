@@ -342,10 +342,6 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
                 dlen[i] = dl;
                 needcopy[i] = force_copy || sl != dl;
                 copied[i] = needcopy[i] ? dl : 0u;
-                if (masks && !bad) {  // WithCopyStrings(false) on the device measures from the emit masks: same answers
-                    const StrMeasure sm = string_measure_masks(sv, v_rec.data(), v_ucount.data(), (u64)pos[i] + 1, i + 1 < n ? pos[i + 1] : len);
-                    if (!sm.ok || sm.dl != dl || sm.copied != (sl != dl)) return 94;
-                }
             }
         }
     }
@@ -488,6 +484,93 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
         sbytes += e.s;
         run = agg_combine(run, e);
     }
+    // WithCopyStrings(false), byte-parallel (sj_strings.h chunk_sel): the bytes of the strings that hold an escape starter,
+    // chunk by chunk; F / G across chunks as the kernels compute them -- a scan inside the unit, the state at the unit's
+    // ends from the quotes and starters of the neighbouring units (sel_unit_in / sel_unit_out below) -- against one
+    // sequential pass over the whole message; then per string: copied or not, Strings.B offset, both lengths, against the
+    // per-string walks above.
+    std::vector<u64> v_sel(used_units * 64, 0);
+    if (masks && !copy && !bad) {
+        const size_t nch = used_units * 64;
+        std::vector<ChunkSel> cs(nch);
+        for (size_t c = 0; c < nch; c++) cs[c] = chunk_sel(v_qm[c], v_q[c], v_st[c], 0u);
+        // ground truth of the two scans
+        std::vector<u32> F(nch + 1, 0), G(nch + 1, 0);  // F[c]: state at the start of chunk c; G[c]: state at the END of chunk c - 1
+        for (size_t c = 0; c < nch; c++) F[c + 1] = sel_apply(cs[c].fwd, F[c]);
+        for (size_t c = nch; c-- > 0;) G[c] = sel_apply(cs[c].bwd, G[c + 1]);
+        // the kernels' way: the state at a unit's start from the units in front (the last quote of the nearest unit that
+        // holds one, the starters behind it), at its end from the units behind (the first quote, the starters in front of it)
+        for (size_t u = 0; u < used_units; u++) {
+            u32 fin = 0, gout = 0;
+            const bool open_in = (cs[u * 64].in & ~cs[u * 64].oq & 1ull) != 0;
+            if (open_in)
+                for (size_t v = u; v-- > 0;) {
+                    bool quote = false;
+                    for (size_t c = v * 64 + 64; c-- > v * 64;) {
+                        if (v_q[c] != 0) {
+                            const int hb = 63 - clz64(v_q[c]);
+                            if (hb < 63 && (v_st[c] >> (hb + 1)) != 0) fin = 1;
+                            quote = true;
+                            break;
+                        }
+                        if (v_st[c] != 0) fin = 1;
+                    }
+                    if (quote) break;
+                }
+            const bool open_out = u + 1 < used_units && (cs[u * 64 + 63].in >> 63) != 0;
+            if (open_out)
+                for (size_t v = u + 1; v < used_units; v++) {
+                    bool quote = false;
+                    for (size_t c = v * 64; c < v * 64 + 64; c++) {
+                        if (v_q[c] != 0) {
+                            const int lb = ctz64(v_q[c]);
+                            if (lb > 0 && (v_st[c] & ((1ull << lb) - 1ull)) != 0) gout = 1;
+                            quote = true;
+                            break;
+                        }
+                        if (v_st[c] != 0) gout = 1;
+                    }
+                    if (quote) break;
+                }
+            if ((open_in ? F[u * 64] : 0u) != fin) return 85;
+            if ((open_out ? G[u * 64 + 64] : 0u) != gout) return 85;
+            // inside the unit: the composed functions of the chunks in front / behind applied to the unit's state
+            u32 fc = 1u;  // identity
+            for (u32 l = 0; l < 64; l++) {
+                if (sel_apply(fc, fin) != (l == 0 && !open_in ? 0u : F[u * 64 + l]) && (cs[u * 64 + l].hr != 0)) return 85;
+                fc = sel_then(fc, cs[u * 64 + l].fwd);
+            }
+            u32 gc = 1u;
+            for (u32 l = 64; l-- > 0;) {
+                if (sel_apply(gc, gout) != G[u * 64 + l + 1] && (cs[u * 64 + l].tr != 0)) return 85;
+                gc = sel_then(gc, cs[u * 64 + l].bwd);
+            }
+        }
+        for (size_t c = 0; c < nch; c++) v_sel[c] = chunk_sel_mask(cs[c], F[c], G[c + 1]);
+        // per string: k-th opening quote, k-th closing quote
+        std::vector<u32> so2, cq2;
+        u64 runb = 0;
+        for (size_t c = 0; c < nch; c++) {
+            const u64 emc = v_em[c] & v_sel[c];
+            for (u64 r = cs[c].oq; r != 0; r &= r - 1) so2.push_back((u32)(runb + popc64(emc & ((1ull << ctz64(r)) - 1ull))));
+            for (u64 r = cs[c].cq; r != 0; r &= r - 1) cq2.push_back((u32)(c * 64 + ctz64(r)));
+            runb += (u64)popc64(emc);
+        }
+        so2.push_back((u32)runb);
+        size_t k = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (kind[i] != K_STRING || strbad[i]) {
+                if (kind[i] == K_STRING) k++;
+                continue;
+            }
+            if (k + 1 >= so2.size() || k >= cq2.size()) return 84;
+            const bool ch = so2[k + 1] != so2[k];
+            if (ch != (needcopy[i] != 0)) return 84;
+            if (ch ? (so2[k] != soff[i] || so2[k + 1] - so2[k] != dlen[i]) : (cq2[k] - pos[i] - 1 != dlen[i])) return 84;
+            k++;
+        }
+        if (runb != sbytes) return 84;
+    }
     // The same pass organised the way a kernel on bit planes would run it (sj_planes.h): a tile of 4096 tokens per wave,
     // 64 tokens per lane; a lane knows the masks of its group, the exclusive prefix over the lanes in front of it (and
     // the tiles in front of the tile) and derives from those alone the tape offset of every token, the compact index,
@@ -606,7 +689,7 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     if (masks && !copy) full.resize(masks_total + 64);
     if (masks && !bad) {  // k_str_emit: patch the escapes of a chunk, then keep the bytes its emit mask names
         u8 *const sink = copy ? strs : full.data();
-        std::vector<u8> ubuf(4096);
+        std::vector<u8> ubuf(4096), selbuf;
         for (size_t c = 0; c < used_units * 64; c++) {
             if ((c & 63) == 0) {
                 // the escape-by-escape form of the general patch (k_str_emit: gen_item_patch) for the whole unit, to be
@@ -639,7 +722,10 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
             }
             u8 *dst = sink + v_ucnt[c >> 6] + v_pre[c];
             for (u64 r = v_em[c]; r != 0; r &= r - 1) *dst++ = chunk[ctz64(r)];
+            if (!copy)  // the byte-parallel selective copy keeps only the bytes of strings that hold an escape
+                for (u64 r = v_em[c] & v_sel[c]; r != 0; r &= r - 1) selbuf.push_back(chunk[ctz64(r)]);
         }
+        if (!copy && (selbuf.size() != sbytes || (sbytes && memcmp(selbuf.data(), strs, sbytes) != 0))) return 83;
         if (!copy)  // k_emit_strings: the strings that changed are taken from the compaction -- the walk's bytes
             for (size_t i = 0; i < n; i++)
                 if (kind[i] == K_STRING && needcopy[i] && !strbad[i] &&

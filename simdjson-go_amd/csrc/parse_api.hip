@@ -49,7 +49,6 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.d_tape = (uint64_t *)ctx->d_tape.p;
     a.tape_cap = 2 * ctx->p_nlay + 2;
     a.d_strings = (uint8_t *)ctx->d_strings.p;
-    a.d_strings_tmp = (ctx->p_flags & SJHIP_FLAG_COPY_STRINGS) ? nullptr : (uint8_t *)ctx->d_strtmp.p;
     a.strings_cap = ctx->p_len + 64;
     a.tape_base = tape_base;
     a.strings_base = strings_base;
@@ -103,17 +102,13 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     size_t n = 0;
     int ok = 0;
     // stage 1 leaves its string masks for the byte-parallel unescape.  Every string copied (the reference's default):
-    // Strings.B is the compaction itself; WithCopyStrings(false): the compaction goes to a scratch buffer and the strings
-    // that unescaping changed are copied out of it (stage2.hip k_emit_strings)
+    // Strings.B is the compaction of all string bytes; WithCopyStrings(false): the compaction of the bytes of the strings
+    // that hold an escape (stage2.hip k_str_emit) -- in both modes written once, in place
     void *aux = nullptr;
     {
         int rc = arena_reserve(ctx, ctx->d_aux, str_aux_bytes(len + 64));
         if (rc) return rc;
         aux = ctx->d_aux.p;
-        if (!(flags & SJHIP_FLAG_COPY_STRINGS)) {
-            rc = arena_reserve(ctx, ctx->d_strtmp, len + 64);
-            if (rc) return rc;
-        }
     }
     {
         // the state and the scan slots of stage 2: zeroed by stage 1's preparation kernel (no memset launch of their own)
@@ -129,7 +124,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes() && !ctx->p_no_defer;
         if (ctx->p_deferred) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
-                                ctx->d_s2z.p, stage2_zero_bytes(), !(flags & SJHIP_FLAG_COPY_STRINGS));
+                                ctx->d_s2z.p, stage2_zero_bytes());
             // The stage-2 arrays are laid out for one token per four bytes (the densest fixture, marine_ik, has 0.22):
             // ~14 B of arena per message byte instead of 57.  The kernels clamp the device-side count to this layout
             // (stage2.hip token_count), so a denser document stays in bounds and is parsed again the synchronous way
@@ -140,8 +135,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             ctx->p_have_last = have_last;
         } else {
             rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
-                                   have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes(),
-                                   !(flags & SJHIP_FLAG_COPY_STRINGS));
+                                   have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
         }
         if (rc) return rc;
     }
@@ -176,7 +170,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
         }
         if (tape_len) *tape_len = (size_t)hs->tape_len;
-        if (strings_len) *strings_len = (ctx->p_aux && (flags & SJHIP_FLAG_COPY_STRINGS)) ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
+        if (strings_len) *strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     }
     return SJHIP_OK;
 }
@@ -258,7 +252,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
     ctx->tape_len = (size_t)hs->tape_len;
-    ctx->strings_len = (ctx->p_aux && (ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
+    ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
     ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
     ctx->kf_valid = ctx->q_valid && (ctx->p_flags & SJHIP_FLAG_KEY_FLAGS) && ctx->d_keyflag.p;

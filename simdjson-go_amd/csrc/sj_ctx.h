@@ -33,7 +33,6 @@ struct sjhip_ctx {
     sj::DevBuf d_msg, d_pos, d_ws, d_kat, d_tape, d_strings, d_s2, d_s2z, d_aux;
     sj::DevBuf d_keyflag;              // SJHIP_FLAG_KEY_FLAGS: key flags of the string entries, for marshal.hip
     int kf_valid = 0;                  // ... and they belong to the resident result
-    sj::DevBuf d_strtmp;               // WithCopyStrings(false): the unescaped bytes of all strings (parse_api.hip)
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     sj::Stage1State s1;                // last stage-1 state (host copy)
@@ -86,9 +85,9 @@ int fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 void release_nd_big(sjhip_ctx *ctx);
 size_t nd_big_device_bytes(const sjhip_ctx *ctx);  // arenas of the shard contexts of a sharded ND parse
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                   uint8_t *d_kind, void *zero2, size_t zero2_bytes, bool aux_records = false);
+                   uint8_t *d_kind, void *zero2, size_t zero2_bytes);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                       uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr,
-                      void *zero2 = nullptr, size_t zero2_bytes = 0, bool aux_records = false);
+                      void *zero2 = nullptr, size_t zero2_bytes = 0);
 }  // namespace sj

@@ -34,9 +34,9 @@ struct S2State {
     unsigned long long strings_len;
     uint32_t n_br;           // number of bracket tokens (size of the compact bracket view)
     uint32_t tail_mask;      // allowed contexts of the gap behind the last bracket (sj_stage2.h)
-    unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (copy mode)
+    unsigned long long strings_len_masks;  // Strings.B length according to the emit masks (both copy modes; without masks: strings_len)
     uint32_t num_count;      // number tokens queued for k_numbers
-    uint32_t str_count;      // selective copy: strings queued for k_emit_strings (the ones unescaping changes)
+    uint32_t str_count;      // (unused since round 5)
     uint32_t n_strings;      // every string copied: opening quotes of the message (the unit scan's second total)
     uint32_t pad[1];
 };
@@ -59,8 +59,6 @@ struct S2Args {
     uint64_t *d_tape;
     size_t tape_cap;
     uint8_t *d_strings;
-    uint8_t *d_strings_tmp;  // WithCopyStrings(false) with string masks: scratch of strings_cap bytes for the unescaped bytes of
-                             // ALL strings (k_str_emit), from which the strings that changed are copied to d_strings
     size_t strings_cap;
     uint64_t tape_base, strings_base, msg_base;
     void *str_aux;          // string masks of stage 1 (str_aux_layout) or null: per-string walks
@@ -99,7 +97,8 @@ struct StrAux {
     uint32_t *unit_str;   // per unit: strings that begin in it, then (k_scans) their exclusive prefix (every string copied)
     uint8_t *unit_h;
     uint64_t *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (a \u or an invalid escape)
-    uint8_t *unit_copy;   // per unit, WithCopyStrings(false): 1 iff bytes of a string that unescaping changes lie in it (stage2.hip)
+    uint32_t *unit_tq;    // per unit, WithCopyStrings(false): aligned offset of the closing quote of the string that is open at the unit's end
+    uint8_t *unit_copy;   // per unit, WithCopyStrings(false): the states at the unit's ends of the byte-parallel selective copy (stage2.hip USEL_*)
 };
 inline StrAux str_aux_layout(void *buf, size_t span) {
     StrAux a;
@@ -120,6 +119,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
     a.unit_slow = reinterpret_cast<uint64_t *>(carve(a.units * 8));
     a.unit_copy = reinterpret_cast<uint8_t *>(carve(a.units));
+    a.unit_tq = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.bytes = (size_t)(w - reinterpret_cast<char *>(buf));
     return a;
 }
@@ -127,8 +127,7 @@ inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr,
-                                  bool aux_records = false);
+                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
@@ -136,7 +135,6 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // the packed result there (S1_HOST_*) in one store: the host needs a stream synchronisation but no copy
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0,
-                         bool aux_records = false);  // aux_records: the flatten leaves emit-mask records (WithCopyStrings(false))
+                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0);
 
 }  // namespace sj

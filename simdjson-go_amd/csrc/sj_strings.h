@@ -366,50 +366,71 @@ SJ_HD u64 emitted_before(Arr<const u32> unit_base, Arr<const ChunkRec> rec, u64 
     return (u64)unit_base[a >> 12] + (r.pre & CHUNK_PRE_MASK) + (u64)popc64(below);
 }
 
-// ---- WithCopyStrings(false) from the same masks (parseString, stage2_build_tape_amd64.go:90-109: a string goes to
-// Strings.B only if unescaping changed its length) ---------------------------------------------------------------------
-// a0 = aligned offset of the first content byte (behind the opening quote), a1 = aligned offset of the next token (the
-// end of the message behind the last token).  The unescaped length is the number of emit-mask bits in [a0, a1) -- the
-// emit mask is empty outside strings -- and the raw length the distance to the closing quote, the last unescaped quote
-// in front of a1 (whitespace may lie between it and the next token).  Every escape shortens a string, so the two
-// differ exactly for the strings that hold one.  unit_counts: emitted bytes per unit (BEFORE the unit scan turns them
-// into prefixes: this runs in the measuring phase).  ok = false: no closing quote in reach (stage 1 has failed).
-struct StrMeasure {
-    u32 dl;
-    bool copied, ok;
+// ---- WithCopyStrings(false), byte-parallel (second half of round 5) ------------------------------------------------------
+// parseString sends a string to Strings.B only if unescaping changed it (parseStringSimdValidateOnly + the src_len != dst_len
+// rule, parse_string_amd64.go:33-42, stage2_build_tape_amd64.go:90-109), i.e. iff it holds an escape starter.  Strings.B is
+// then the concatenation of the unescaped contents of THOSE strings -- still a property of the message: the emit mask
+// restricted to the bytes of strings that hold a starter.  Which bytes those are is a segmented OR over the bytes of a
+// string, evaluated 64 bytes at a time:
+//   in    in-string mask of the chunk with the opening and without the closing quote of every string (qm under h)
+//   mark  escape starters inside strings
+//   a run of ones of `in` is the part of one string that lies in this chunk; a run with a mark is filled from the mark to
+//   both ends by one addition each way (the carry of in + mark runs through the ones above the mark; the bytes below it
+//   through the same addition on the bit-reversed words);
+//   the run that touches byte 0 without starting there (head run: the string was open in front of the chunk) and the
+//   run that touches byte 63 (tail run) also depend on the other chunks of their string: F = "the string open at the start
+//   of the chunk holds a mark in front of the chunk", G = "the string open at the end of the chunk holds one behind it" --
+//   two scans over the chunks (forward / backward) of the one-bit functions sel_fwd / sel_bwd, which compose like the
+//   context functions of the token scan (x -> (x & a) | b).
+// The k-th string of the message (k-th opening quote, k-th string token) is copied iff bytes are selected between its quotes;
+// its Strings.B offset is the number of selected emit-mask bits in front of its opening quote, its unescaped length the
+// selected bits up to the next opening quote, and the raw length of a string that is NOT copied is the distance to its
+// closing quote -- the k-th closing quote of the message (strings do not nest).  k_str_emit leaves soff[k] and the position
+// of the k-th closing quote in message order; k_s2_emit_planes reads both in token order.  No per-string walk, no measuring
+// pass over the tokens, nothing is compacted that is not copied.
+SJ_HD u64 brev64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    u64 r = 0;
+    for (int i = 0; i < 64; i++) r |= ((x >> i) & 1ull) << (63 - i);
+    return r;
+#endif
+}
+// bits of the runs of ones of R at or above a bit of M inside the same run (M a subset of R)
+SJ_HD u64 fill_up(u64 R, u64 M) { return (((R + M) ^ R) & R) | M; }
+struct ChunkSel {
+    u64 in, oq, cq;     // in-string mask (see above), opening quotes, closing quotes
+    u64 hr, tr;         // head run (empty unless the string was open in front of the chunk), tail run (empty unless open behind it)
+    u64 local;          // the bytes of runs that hold a mark inside this chunk
+    u32 fwd, bwd;       // the scan elements: bit 0 = a, bit 1 = b of x -> (x & a) | b
 };
-// (r0 = rec[a0 >> 6], r1 = rec[a1 >> 6], q1 = m.q[a1 >> 6] are handed in: k_str_measure requests them for two strings at a
-// time before it uses any of them)
-SJ_HD StrMeasure string_measure_loaded(const StrView &m, Arr<const u32> unit_counts, u64 a0, u64 a1, const ChunkRec &r0,
-                                       const ChunkRec &r1, u64 q1) {
-    StrMeasure r{0u, false, false};
-    if (a1 <= a0) return r;  // (the quote is the last byte: nothing closes it)
-    const u64 c0 = a0 >> 6, c1 = a1 >> 6;
-    const u32 b0 = (u32)(a0 & 63), b1 = (u32)(a1 & 63);
-    const u64 below0 = b0 ? ~0ull >> (64 - b0) : 0ull, below1 = b1 ? ~0ull >> (64 - b1) : 0ull;
-    u64 n = (u64)(r1.pre & CHUNK_PRE_MASK) + (u64)popc64(r1.em & below1) - ((u64)(r0.pre & CHUNK_PRE_MASK) + (u64)popc64(r0.em & below0));
-    for (u64 u = a0 >> 12; u < (a1 >> 12); u++) n += unit_counts[u];  // (a string that leaves its 4 KiB unit: rare)
-    r.dl = (u32)n;
-    u64 c = c1, mask = below1, qw = q1;
-    for (;;) {
-        u64 qb = qw & mask;
-        if (c == c0) qb &= ~below0;
-        if (qb != 0) {
-            const u64 cq = c * 64 + (u64)(63 - clz64(qb));
-            r.copied = cq - a0 != n;
-            r.ok = true;
-            return r;
-        }
-        if (c == c0) return r;
-        c--;
-        mask = ~0ull;
-        qw = m.q[c];
-    }
+SJ_HD ChunkSel chunk_sel(u64 qm, u64 q, u64 st, u32 h) {
+    ChunkSel r;
+    r.in = h ? ~qm : qm;
+    r.oq = q & r.in;
+    r.cq = q & ~r.in;
+    const u64 R = r.in, M = st & R;
+    const u64 Rr = brev64(R);
+    r.local = fill_up(R, M) | brev64(fill_up(Rr, brev64(M)));
+    const bool head_open = (R & ~r.oq & 1ull) != 0, tail_open = (R >> 63) != 0;
+    r.hr = head_open ? R & ~(R + 1ull) : 0ull;                  // the trailing ones of R
+    r.tr = tail_open ? brev64(Rr & ~(Rr + 1ull)) : 0ull;         // the leading ones of R
+    const bool through = head_open && R == ~0ull;               // one string from the first to the last byte (then oq == 0)
+    const u32 any = M != 0 ? 1u : 0u, hm = (r.hr & M) != 0 ? 1u : 0u, tm = (r.tr & M) != 0 ? 1u : 0u;
+    // forward: state "the string open here holds a mark in front" at the start of the chunk -> at its end
+    r.fwd = tail_open ? (through ? 1u | (any << 1) : tm << 1) : 0u;
+    // backward: state "the string open here holds a mark behind" at the end of the chunk -> at its start
+    r.bwd = head_open ? (through ? 1u | (any << 1) : hm << 1) : 0u;
+    return r;
 }
-SJ_HD StrMeasure string_measure_masks(const StrView &m, Arr<const ChunkRec> rec, Arr<const u32> unit_counts, u64 a0, u64 a1) {
-    if (a1 <= a0) return StrMeasure{0u, false, false};
-    return string_measure_loaded(m, unit_counts, a0, a1, rec[a0 >> 6], rec[a1 >> 6], m.q[a1 >> 6]);
+SJ_HD u32 sel_apply(u32 f, u32 x) { return (x & f & 1u) | (f >> 1); }
+SJ_HD u32 sel_then(u32 first, u32 second) {  // first, then second
+    const u32 a = first & second & 1u, b = ((first >> 1) & second & 1u) | (second >> 1);
+    return a | (b << 1);
 }
+// the bytes of the chunk that belong to strings which are copied; F / G: the states at the start / at the end of the chunk
+SJ_HD u64 chunk_sel_mask(const ChunkSel &c, u32 F, u32 G) { return c.local | (F ? c.hr : 0ull) | (G ? c.tr : 0ull); }
 
 // the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)
 SJ_HD u64 emitted_before_abs(Arr<const ChunkRec> rec, u64 a) {

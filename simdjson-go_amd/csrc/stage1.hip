@@ -42,20 +42,15 @@ struct S1Aux {
     Arr<u8> unit_h;
     Arr<u64> unit_slow;  // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
     Arr<u8> kind;        // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
-    // round 5: the flatten of a tile -- the first place that knows the state at the start of every unit -- also leaves what the
-    // string half of k_measure (stage2.hip str_masks_body) computed from the three masks above for every chunk without a
-    // \u escape: the 16-byte record {emit mask, emitted bytes of the unit in front of the chunk | CHUNK_SLOW} and the unit's
-    // byte count.  k_measure then only visits the units that unit_slow flags (none on twitter.json / parking-citations: the
-    // masks are never read from HBM again, and 101 + 67 MB of reads and writes of configs[1] are gone with the pass).
-    // (second half of round 5: only WithCopyStrings(false) still takes the records from here -- `rec` is null otherwise.
-    // When every string is copied the masks are not read back at all: phase A counts the emitted bytes and the opening
-    // quotes of every unit under BOTH hypotheses (four popcounts and two wave sums), the flatten picks the pair that
-    // applies and leaves unit_cnt / unit_str, and k_str_emit derives the emit mask of a chunk from the three masks it
-    // streams anyway, stage2.hip.  Per chunk that is 24 B written here instead of 24 written + 24 read + 16 written.)
-    Arr<ChunkRec> rec;
-    Arr<u32> unit_cnt;
-    Arr<u32> unit_str;   // [units] strings that begin in the unit (opening quotes); null in the record form
-    Arr<u8> unit_copy;   // cleared here (WithCopyStrings(false): k_str_measure marks the units to compact)
+    // round 5: no records.  Phase A counts the emitted bytes (the fast formula of sj_strings.h: in-string bytes that are
+    // neither quotes nor escape starters; units with a \u escape are counted again by k_measure) and the opening quotes of
+    // every unit under BOTH hypotheses about the state at its start (four popcounts and two wave sums), the flatten -- the
+    // first place that knows the state -- picks the pair that applies and leaves unit_cnt / unit_str; k_str_emit derives the
+    // emit mask of a chunk from the three masks it streams anyway (stage2.hip).  (The first half of the round let the
+    // flatten read the masks back and write 16-byte records: 24 B written + 24 read + 16 written per chunk instead of 24
+    // written; the reads came back through the fabric, not from the L2.)
+    Arr<u32> unit_cnt;   // [units] emitted bytes of the unit
+    Arr<u32> unit_str;   // [units] strings that begin in the unit (opening quotes)
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
@@ -407,7 +402,6 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         u64 quote_bits = c.quote;
         u64 starters = 0;  // backslashes that begin an escape sequence
         u64 nonsimple = 0; // escaped characters other than " \\ / b f n r t
-        u32 carry_bit = 0; // the chunk's first byte is escaped by a backslash at the end of the chunk in front
         const u32 bs_any = (u32)c.bs | (u32)(c.bs >> 32);
         if (__ballot(bs_any != 0) != 0 || carry0 != 0) {  // wave-uniform: many waves see no backslash at all
             const bool all_bs = c.bs == ~0ull;
@@ -416,7 +410,6 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (__ballot(all_bs) != 0 && lane != 0) carry_in = peek_backslash_parity(base, lead, unit_off + (u64)lane * 64, end);
             const u64 escaped = escaped_mask(c.bs, carry_in);
             quote_bits &= ~escaped;
-            carry_bit = carry_in & 1u;
             if (AUX) {
                 starters = c.bs & ~escaped;
                 nonsimple = escaped & ~c.esc1;
@@ -470,9 +463,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
                         (__ballot(((u32)in_b | (u32)(in_b >> 32)) != 0) != 0 ? 2u : 0u);
         // unit totals of both counts at once (16-bit fields: a wave holds <= 4096 bits)
         const u32 incl = wave_incl_scan((u32)popc64(a) | ((u32)popc64(b) << 16));
-        // flatten needs the lane's offset inside the unit: kept instead of scanned again (13 bits per hypothesis; bit 15: the
-        // carry into the chunk, for the emit-mask records the whole parse leaves in flatten_tile)
-        pre[k * 64 + lane] = AUX ? incl | (carry_bit << 15) : incl;
+        pre[k * 64 + lane] = incl;  // flatten needs the lane's offset inside the unit: kept instead of scanned again
         const u32 tot = lane63(incl);
         // (whole parse, bit 28: the unit holds an escape starter -- k_str_emit does not read the st masks of the others)
         const u32 has_st = AUX && __ballot(((u32)starters | (u32)(starters >> 32)) != 0) != 0 ? 1u : 0u;
@@ -528,23 +519,6 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
 
     const bool err = lane < UNITS && ((v >> (26 + hl)) & 1u) != 0;  // any lane: the caller ballots
 
-    // whole parse: the string masks this lane stored for its chunks in phase A, an iteration ago (its own stores: they
-    // come back from the L2) -- requested now, used behind the copy-out of the positions
-    u64 s_qm[CH], s_q[CH], s_st[CH];
-    const bool recs = KIND && aux.rec;  // (uniform)
-    if (recs) {
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
-            s_qm[k] = s_q[k] = s_st[k] = 0;
-            if (un != VOID_UNIT && un * 4096 < lead + len_) {
-                const u64 ci = un * 64 + (u64)lane;
-                s_qm[k] = aux.qm[ci];
-                s_q[k] = aux.q[ci];
-                s_st[k] = aux.st[ci];
-            }
-        }
-    }
     u64 sel[CH];
     u32 upto[CH];  // structurals of the unit up to and including this lane's chunk
 #pragma unroll
@@ -552,12 +526,12 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
         sel[k] = m[(k * 2 + (int)h) * 64 + lane];
         const u32 both = pre[k * 64 + lane];
-        upto[k] = (h ? both >> 16 : both) & 0x1fffu;
+        upto[k] = h ? both >> 16 : both & 0xffffu;
         const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
         if (unit_h && lane == 0 && un * 4096 < lead + len_) {  // (a void unit lies behind everything)
             // bit 0: the state at the start of the unit; bit 1: the unit holds an escape starter
             unit_h[un] = (u8)(h | (((s_unit[k * WAVES + wave] >> 28) & 1u) << 1));
-            if (KIND && aux.unit_str) {  // every string copied: the unit's counts under the state that is now known
+            if (KIND && aux.unit_str) {  // whole parse: the unit's counts under the state that is now known
                 const uint2 c = s_ucnt[k * WAVES + wave];
                 aux.unit_cnt[un] = h ? (c.x >> 16) - (c.x & 0xffffu) : c.x & 0xffffu;
                 aux.unit_str[un] = h ? (c.y >> 16) - (c.y & 0xffffu) : c.y & 0xffffu;
@@ -652,29 +626,6 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
                 __builtin_amdgcn_wave_barrier();
                 copy_out(C - r0 < CAP ? C - r0 : CAP, g + r0);
                 __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    if (recs) {
-        // The emit mask of every chunk under the state that is now known (sj_strings.h str_chunk_masks_fast, the branch
-        // that does not touch the message): in-string bytes that are neither quotes nor escape starters; CHUNK_SLOW if an
-        // escaped character lies inside a string (k_str_emit translates it).  Units that hold a \u (or an invalid) escape
-        // are done again by k_measure (unit_slow).
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
-            if (un == VOID_UNIT || un * 4096 >= lead + len_) continue;  // (wave-uniform)
-            const u32 h = G ^ ((pre_mask >> (k * WAVES + wave)) & 1u);
-            const u32 carry = (pre[k * 64 + lane] >> 15) & 1u;
-            const u64 sm = (h ? ~s_qm[k] : s_qm[k]) & ~s_q[k];
-            const u64 em = sm & ~s_st[k];
-            const u64 e = ((s_st[k] << 1) | carry) & sm;
-            const u32 n = (u32)popc64(em);
-            const u32 incl = wave_incl_scan(n);
-            aux.rec[un * 64 + (u64)lane] = ChunkRec{em, (incl - n) | (e != 0 ? CHUNK_SLOW : 0u), 0u};
-            if (lane == 63) {
-                aux.unit_cnt[un] = incl;
-                aux.unit_copy[un] = 0;
             }
         }
     }
@@ -1185,7 +1136,7 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                                   hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
-                                  unsigned long long *h_state, bool aux_records) {
+                                  unsigned long long *h_state) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
@@ -1213,12 +1164,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.unit_h = SJ_ARR(a.unit_h, a.units, A_S1_UNIT_H);
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
         aux.unit_cnt = SJ_ARR(a.unit_cnt, a.units, A_S1_UNIT_CNT);
-        if (aux_records) {  // WithCopyStrings(false): the flatten leaves the emit-mask records
-            aux.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(a.rec), a.chunks, A_S1_REC);
-            aux.unit_copy = SJ_ARR(a.unit_copy, a.units, A_S1_UNIT_COPY);
-        } else {            // every string copied: unit counts only (k_str_emit derives the rest from the masks)
-            aux.unit_str = SJ_ARR(a.unit_str, a.units, A_S1_UNIT_STR);
-        }
+        aux.unit_str = SJ_ARR(a.unit_str, a.units, A_S1_UNIT_STR);
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
@@ -1267,10 +1213,10 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
-                         size_t zero2_bytes, bool aux_records) {
+                         size_t zero2_bytes) {
     hipError_t e = stage1_prepare(d_msg, len, ws, stream, zero2, zero2_bytes);
     if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state, aux_records);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
 }
 
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses of the stage-1 kernels since the

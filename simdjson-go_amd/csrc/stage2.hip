@@ -75,8 +75,9 @@ struct S2Dev {
     Arr<u32> nl_off;   // [n] tape offset of the r-th record-separating newline
     Arr<uint2> numq;   // [n] (message offset, tape offset) of every number token, in no particular order
     Arr<u32> bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
-    Arr<uint4> strq;   // [n/2 + 8] selective copy: (message offset, Strings.B offset, length) of the strings to copy (a string
-    u32 strq_cap;  //           token is followed by a token that is none, so a valid document has at most n/2 of them)
+    Arr<uint2> sinfo;  // [soff_cap] WithCopyStrings(false) on the masks, for the k-th string of the message: (Strings.B offset it has
+                       // if it is copied, raw length of its content); behind the last one (length of Strings.B, 0)  (k_str_emit)
+    Arr<u32> unit_tq;  // [units] ... and for a unit that ends inside a string: where that string's closing quote lies (k_measure)
     Arr<i32> br_depth; // [n] compact bracket view: depth after the c-th bracket (level 0 of the min tree)
     Arr<u32> br_off;   // [n]                       its tape offset
     Arr<u8> br_info;   // [n]                       kind | allowed contexts of the gap that ends with it << 4
@@ -159,78 +160,165 @@ __device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, i
     return (u32)__shfl((int)incl, 63, 64);
 }
 
+// ---- WithCopyStrings(false): which strings are copied, decided 64 bytes at a time (sj_strings.h chunk_sel) ---------------
+// The state at a unit's ends: does the string that is open at the start of unit u hold an escape starter in FRONT of the
+// unit (the starters behind the last quote of the nearest unit in front that holds a quote, and all starters of the units
+// in between), does the one open at its end hold one BEHIND it.  One unit per step, the whole wave; strings longer than
+// SEL_WALK_CAP units give the document to the per-string path (S2_ERR_SERIAL_STRINGS, like a surrogate run that is too long).
+static constexpr u32 SEL_WALK_CAP = 64;
+__device__ __forceinline__ u32 sel_unit_in(const S2Dev &p, u64 u, int lane, bool &giveup) {
+    u32 acc = 0;
+    for (u32 step = 0; u > 0; step++) {
+        u--;
+        if (step >= SEL_WALK_CAP) {
+            giveup = true;
+            break;
+        }
+        const u64 c = u * 64 + lane;
+        const u64 q = p.sv.q[c];
+        const u64 st = (p.sv.unit_h[u] & 2u) ? p.sv.st[c] : 0ull;
+        const u64 qb = __ballot(q != 0);
+        if (qb != 0) {
+            const int L = 63 - __builtin_clzll(qb);  // the last chunk with a quote; behind its last quote the string is open
+            bool m = lane > L && st != 0;
+            if (lane == L) {
+                const int hb = 63 - clz64(q);
+                m = hb < 63 && (st >> (hb + 1)) != 0;
+            }
+            acc |= __ballot(m) != 0 ? 1u : 0u;
+            break;
+        }
+        acc |= __ballot(st != 0) != 0 ? 1u : 0u;
+    }
+    return acc;
+}
+// (*tq: the aligned offset of that string's closing quote -- the first quote behind the unit)
+__device__ __forceinline__ u32 sel_unit_out(const S2Dev &p, u64 u, int lane, bool &giveup, u32 *tq) {
+    u32 acc = 0;
+    for (u32 step = 0; u + 1 < p.units; step++) {
+        u++;
+        if (step >= SEL_WALK_CAP) {
+            giveup = true;
+            break;
+        }
+        const u64 c = u * 64 + lane;
+        const u64 q = p.sv.q[c];
+        const u64 st = (p.sv.unit_h[u] & 2u) ? p.sv.st[c] : 0ull;
+        const u64 qb = __ballot(q != 0);
+        if (qb != 0) {
+            const int L = __builtin_ctzll(qb);  // the first chunk with a quote: the closing quote of the open string
+            bool m = lane < L && st != 0;
+            const int lb = q ? ctz64(q) : 0;
+            if (lane == L) m = lb > 0 && (st & ((1ull << lb) - 1ull)) != 0;
+            *tq = (u32)((u * 64 + (u64)L) * 64) + (u32)__builtin_amdgcn_readlane(lb, L);
+            acc |= __ballot(m) != 0 ? 1u : 0u;
+            break;
+        }
+        acc |= __ballot(st != 0) != 0 ? 1u : 0u;
+    }
+    return acc;
+}
+// The selected bytes of this lane's chunk: the two scans over the wave's 64 chunks (function composition, sel_then) applied
+// to the states at the unit's ends.
+__device__ __forceinline__ u64 sel_wave_mask(const ChunkSel &cs, u32 fin, u32 gout, int lane) {
+    u32 f = cs.fwd, g = cs.bwd;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 tf = (u32)__shfl_up((int)f, d, 64), tg = (u32)__shfl_down((int)g, d, 64);
+        if (lane >= d) f = sel_then(tf, f);         // chunks lane-2d+1 .. lane-d first, then lane-d+1 .. lane
+        if (lane + d < 64) g = sel_then(tg, g);     // the chunks behind first (the backward scan starts at the unit's end)
+    }
+    u32 fe = (u32)__shfl_up((int)f, 1, 64), ge = (u32)__shfl_down((int)g, 1, 64);
+    if (lane == 0) fe = 1u;   // identity
+    if (lane == 63) ge = 1u;
+    return chunk_sel_mask(cs, sel_apply(fe, fin), sel_apply(ge, gout));
+}
+// unit flags of the selective copy (S2Dev::unit_copy): the states at the unit's ends, left by k_measure for k_str_emit
+static constexpr u8 USEL_IN = 1u, USEL_OUT = 2u;
+
+// SEL = WithCopyStrings(false).
+template <bool SEL>
 __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nblocks, GenUnit *gu) {
     // Without touching the message (sj_strings.h str_chunk_masks_fast is the per-chunk statement): a chunk takes the
     // general routine only if it, or the chunk in front of it, holds an escaped character that no simple escape names.
-    // Persistent waves: unit wave_id, wave_id + waves, ...; the masks of the next unit are requested before the current
-    // one is worked on.
+    // Persistent waves: unit wave_id, wave_id + waves, ...
     const int lane = threadIdx.x & 63;
     const u64 nwaves = (u64)nblocks * 4;
-    u64 unit = (u64)block * 4 + (threadIdx.x >> 6);
+    u64 unit = (u64)block * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (unit >= p.units) return;  // whole waves
-    struct In {
-        u64 qm, q, st, stp, slow_w, slow_p;
-        u8 h;
-    };
-    auto load = [&](u64 u) {
-        const u64 c = u * 64 + lane;
-        In r;
-        r.qm = p.sv.qm[c];
-        r.q = p.sv.q[c];
-        r.st = p.sv.st[c];
-        r.stp = c ? p.sv.st[c - 1] : 0ull;
-        r.slow_w = p.sv.unit_slow[u];
-        r.slow_p = u ? p.sv.unit_slow[u - 1] : 0ull;
-        r.h = p.sv.unit_h[u] & 1u;
-        return r;
-    };
-    // Stage 1's flatten has left the record of every chunk and the count of every unit (stage1.hip flatten_tile, round 5);
-    // what is left for this pass are the units that hold an escaped character no simple escape names -- a \u, whose bytes
-    // may reach into the next chunk, or an invalid escape -- which unit_slow flags: those are done again here, whole.
+    // Every string copied: stage 1 has left the count of every unit and k_str_emit derives the emit masks itself; what is
+    // left for this pass are the units that hold an escaped character no simple escape names -- a \u, whose bytes may
+    // reach into the next chunk, or an invalid escape -- which unit_slow flags: their emit masks are computed here, escape
+    // by escape, and left as records.  WithCopyStrings(false): every unit is visited -- the bytes of the strings that are
+    // copied (the ones with an escape starter) are counted per unit, and the states at the unit's ends are left for k_str_emit.
     for (;; unit += nwaves) {
         if (unit >= p.units) return;
         const u64 sw = p.sv.unit_slow[unit], sp = unit ? p.sv.unit_slow[unit - 1] : 0ull;
-        if (sw == 0 && (sp >> 63) == 0) continue;  // (wave-uniform)
-        const In in = load(unit);
+        const bool slow = sw != 0 || (sp >> 63) != 0;  // (wave-uniform)
+        if (!SEL && !slow) continue;
         const u64 c = unit * 64 + lane;
-        const u64 stp = in.stp >> 63;
-        const bool prev_slow = lane ? ((in.slow_w >> (lane - 1)) & 1u) != 0 : (in.slow_p >> 63) != 0;
-        const u64 sm = (in.h ? ~in.qm : in.qm) & ~in.q;
-        const u64 e = ((in.st << 1) | stp) & sm;  // escaped characters inside strings
-        u64 em = sm & ~in.st;
-        u32 flags = e != 0 ? CHUNK_SLOW : 0u;
-        const bool own_slow = ((in.slow_w >> lane) & 1u) != 0 && e != 0;
-        const bool gen = own_slow || prev_slow;  // == str_chunk_needs_general(c)
-        if (__ballot(gen) != 0) {  // (wave-uniform) the unit takes the general routine
-            // escaped in-string characters in the last four bytes of the chunk in front (they may reach into this one)
-            u64 pe = (u64)__shfl_up((long long)e, 1, 64) >> 60;
-            if (lane == 0) pe = c ? (p.sv.esc(c - 1) & p.sv.sm(c - 1)) >> 60 : 0ull;
-            gu->em[lane] = em;
-            const u32 items = gen_unit_list(gu, own_slow ? e : 0ull, (lane == 0 && gen) ? pe : 0ull, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const u64 u0 = unit * 4096;
-            bool bad = false, over = false;
-            for (u32 j = (u32)lane; j < items; j += 64)
-                gen_item_masks(p.sv, u0, gu->list[j], &bad, &over,
-                               [&](u32 pos) { atomicAnd(&gu->em[pos >> 6], ~(1ull << (pos & 63))); });
-            if (bad) atomicOr(&p.st->err, 1u);
-            if (over) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (gen) {
-                em = gu->em[lane];
-                flags = (e != 0 || pe != 0) ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+        const u32 uh = p.sv.unit_h[unit], uhp = unit ? (u32)p.sv.unit_h[unit - 1] : 0u;
+        const u32 h = uh & 1u;
+        const u64 qm = p.sv.qm[c], q = p.sv.q[c];
+        const u64 st = (uh & 2u) ? p.sv.st[c] : 0ull;
+        const u64 stp = (c && ((lane ? uh : uhp) & 2u)) ? p.sv.st[c - 1] >> 63 : 0ull;
+        const ChunkFast cf = chunk_fast(qm, q, st, stp << 63, h);
+        const u64 e = cf.esc;  // escaped characters inside strings
+        u64 em = cf.em;
+        if (slow) {  // (wave-uniform)
+            const bool prev_slow = lane ? ((sw >> (lane - 1)) & 1u) != 0 : (sp >> 63) != 0;
+            u32 flags = e != 0 ? CHUNK_SLOW : 0u;
+            const bool own_slow = ((sw >> lane) & 1u) != 0 && e != 0;
+            const bool gen = own_slow || prev_slow;  // == str_chunk_needs_general(c)
+            if (__ballot(gen) != 0) {  // (wave-uniform) the unit takes the general routine
+                // escaped in-string characters in the last four bytes of the chunk in front (they may reach into this one)
+                u64 pe = (u64)__shfl_up((long long)e, 1, 64) >> 60;
+                if (lane == 0) pe = c ? (p.sv.esc(c - 1) & p.sv.sm(c - 1)) >> 60 : 0ull;
+                gu->em[lane] = em;
+                const u32 items = gen_unit_list(gu, own_slow ? e : 0ull, (lane == 0 && gen) ? pe : 0ull, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const u64 u0 = unit * 4096;
+                bool bad = false, over = false;
+                for (u32 j = (u32)lane; j < items; j += 64)
+                    gen_item_masks(p.sv, u0, gu->list[j], &bad, &over,
+                                   [&](u32 pos) { atomicAnd(&gu->em[pos >> 6], ~(1ull << (pos & 63))); });
+                if (bad) atomicOr(&p.st->err, 1u);
+                if (over) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (gen) {
+                    em = gu->em[lane];
+                    flags = (e != 0 || pe != 0) ? (CHUNK_SLOW | CHUNK_GENERAL) : 0u;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // the lists are read: the next unit may write them
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();  // the lists are read: the next unit may write them
+            const u32 n = (u32)popc64(em);
+            const u32 incl = wave_incl_sum(n);
+            p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};
+            if (!SEL && lane == 63) p.unit_cnt[unit] = incl;
         }
-        const u32 n = (u32)popc64(em);
-        const u32 incl = wave_incl_sum(n);
-        p.rec[c] = ChunkRec{em, (incl - n) | flags, 0u};  // .abs: k_str_emit
-        if (lane == 63) {
-            p.unit_cnt[unit] = incl;
-            if (p.unit_copy) p.unit_copy[unit] = 0;
+        if (SEL) {
+            const ChunkSel cs = chunk_sel(qm, q, st, h);
+            bool giveup = false;
+            // (a string is open at the start of the unit / at its end: only then do the neighbours matter)
+            const bool open_in = (u32)__builtin_amdgcn_readlane((int)(u32)(cs.in & ~cs.oq & 1ull), 0) != 0;
+            const bool open_out = unit + 1 < p.units && (u32)__builtin_amdgcn_readlane((int)(u32)(cs.in >> 63), 63) != 0;
+            const u32 fin = open_in ? sel_unit_in(p, unit, lane, giveup) : 0u;
+            u32 tq = 0;
+            const u32 gout = open_out ? sel_unit_out(p, unit, lane, giveup, &tq) : 0u;
+            u32 total = 0;
+            if ((uh & 2u) || fin || gout) {  // (uniform) without a starter in reach nothing of the unit is copied
+                const u64 sel = sel_wave_mask(cs, fin, gout, lane);
+                total = (u32)__shfl((int)wave_incl_sum((u32)popc64(em & sel)), 63, 64);
+            }
+            if (lane == 0) {
+                p.unit_cnt[unit] = total;
+                p.unit_copy[unit] = (u8)((fin ? USEL_IN : 0u) | (gout ? USEL_OUT : 0u));
+                p.unit_tq[unit] = tq;
+                if (giveup) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+            }
         }
     }
 }
@@ -460,18 +548,22 @@ __constant__ EscapeLut c_esc = make_escape_lut();
 // unit i its loads of the 64-byte chunks of unit i+1 and of the masks (records) of unit i+2 are in flight (one unit per
 // block left two dependent memory round trips -- record, then chunk -- exposed in front of every 4 KiB).
 //
-// DERIVE (every string copied, second half of round 5): there are no records for ordinary units.  The wave streams the
-// three masks stage 1 left (24 B per chunk, read here for the first and only time) and derives what the record held --
-// emit mask, escaped characters, the chunk's offset inside the unit (one packed wave scan) -- and, new, the OPENING QUOTES:
-// string number k of the message (k-th opening quote = k-th string token) starts at Strings.B offset
-// soff[k] = E(position of its quote), and since Strings.B is the concatenation of all strings its unescaped length is
-// soff[k + 1] - soff[k].  The wave writes soff[] for the quotes of its unit (unit_str: exclusive prefix of the units'
-// string counts, k_scans); k_s2_emit_planes reads it in order and does not touch masks or records any more (it gathered
-// two 16-byte records per string).  Only units with a \u (or invalid) escape -- whose emit masks k_measure computes
-// escape by escape -- come with records (unit_slow, the predicate of str_masks_body).
-// !DERIVE (WithCopyStrings(false)): records for every unit (stage 1's flatten / k_measure), only units marked by
-// k_str_measure are compacted, into the scratch buffer k_emit_strings copies from.
-template <bool DERIVE>
+// There are no records for ordinary units (second half of round 5).  The wave streams the three masks stage 1 left (24 B
+// per chunk, read here for the first and only time) and derives what a record held -- emit mask, escaped characters, the
+// chunk's offset inside the unit (one packed wave scan) -- and, new, the OPENING QUOTES: string number k of the message (k-th
+// opening quote = k-th string token) starts at Strings.B offset soff[k] = E(position of its quote), and since Strings.B is
+// the concatenation of the strings its unescaped length is soff[k + 1] - soff[k].  The wave writes soff[] for the quotes of
+// its unit (unit_str: exclusive prefix of the units' string counts, k_scans); k_s2_emit_planes reads it in order and does
+// not touch masks or records any more (it gathered two 16-byte records per string).  Only units with a \u (or invalid)
+// escape -- whose emit masks k_measure computes escape by escape -- come with records (unit_slow, the predicate of
+// str_masks_body).
+// SEL (WithCopyStrings(false)): the emit mask is restricted to the bytes of the strings that are copied -- the ones that
+// hold an escape starter (sj_strings.h chunk_sel; the states at the unit's ends come from k_measure) -- so Strings.B is
+// again a plain compaction and nothing else is read or written: chunks without a selected byte are not loaded.  A string
+// that is not copied needs its raw length: the wave also leaves the position of every CLOSING quote under the number of
+// its string (scq[]).  (Rounds 3-4 compacted every string into a scratch buffer, measured every string token with two record
+// gathers and copied the changed strings out of the scratch: k_str_measure + k_emit_strings, 165 us on configs[1].)
+template <bool SEL>
 __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
@@ -486,99 +578,150 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     const u64 nwaves = (u64)gridDim.x * 4;
     u64 unit = (u64)blockIdx.x * 4 + wave;
     struct Raw {   // what is requested two units ahead
-        u64 qm, q, st;       // DERIVE: the masks of the lane's chunk
+        u64 qm, q, st;       // the masks of the lane's chunk
         u32 stp_hi;          // ... and the upper half of st of the chunk in front (bit 31: its last byte starts an escape)
         ChunkRec r;          // record units
         u32 g, sb;           // exclusive prefixes of the unit: Strings.B offset, string ordinal
-        u32 h;
+        u32 h, uf;           // state at the start of the unit | it holds a starter << 1; SEL: the states at its ends (USEL_*)
         bool rec, live, last;
     };
     struct Unit {  // what the wave works with
-        u64 em, esc;      // emit mask; escaped characters that are emitted (DERIVE)
+        u64 em, esc;      // emit mask; escaped characters that are emitted
         u32 pre_raw;      // ChunkRec::pre: emitted bytes of the unit in front of the chunk | CHUNK_SLOW | CHUNK_GENERAL
         u32 g;
     };
-    auto load_raw = [&](u64 u) {
+    // The per-unit scalars (uniform loads) run one unit ahead of the vector loads they steer: requested and needed in the
+    // same place they cost a scalar-memory round trip in front of every unit's loads.
+    struct Sc {
+        u32 flags;     // 1: record unit, 2: the unit holds a starter, 4: the unit in front does, 8: state at the start of the unit
+        u32 g, sb;     // exclusive prefixes of the unit: Strings.B offset, string ordinal
+        u32 uf, tq;    // SEL: the states at the unit's ends (USEL_*), the closing quote of the string open at its end
+        bool live, last;
+    };
+    auto load_sc = [&](u64 u) {
+        Sc c;
+        c.flags = c.g = c.sb = c.uf = c.tq = 0;
+        c.live = u < p.units;
+        c.last = u + 1 == p.units;
+        if (!c.live) return c;
+        const u64 sw = p.sv.unit_slow[u], sp = u ? p.sv.unit_slow[u - 1] : 0ull;
+        const u32 uh = p.sv.unit_h[u], uhp = u ? (u32)p.sv.unit_h[u - 1] : 0u;
+        // (record units: the ones str_masks_body has done escape by escape)
+        c.flags = ((sw != 0 || (sp >> 63) != 0) ? 1u : 0u) | (uh & 2u) | ((uhp & 2u) << 1) | ((uh & 1u) << 3);
+        c.sb = p.unit_str[u];
+        c.g = p.unit_cnt[u];
+        if (SEL) {
+            c.uf = p.unit_copy[u];
+            c.tq = p.unit_tq[u];
+        }
+        return c;
+    };
+    auto load_raw = [&](u64 u, const Sc &sc) {
         Raw x;
         x.qm = x.q = x.st = 0;
         x.stp_hi = 0;
         x.r = ChunkRec{0, 0, 0};
-        x.g = x.sb = x.h = 0;
-        x.rec = false;
-        x.live = u < p.units;
-        x.last = u + 1 == p.units;
+        x.g = sc.g;
+        x.sb = sc.sb;
+        x.h = ((sc.flags >> 3) & 1u) | (sc.flags & 2u);
+        x.uf = sc.uf;
+        x.rec = (sc.flags & 1u) != 0;
+        x.live = sc.live;
+        x.last = sc.last;
         if (!x.live) return x;
         const u64 c = u * 64 + lane;
-        if (DERIVE) {
-            const u64 sw = p.sv.unit_slow[u], sp = u ? p.sv.unit_slow[u - 1] : 0ull;
-            x.rec = sw != 0 || (sp >> 63) != 0;  // (wave-uniform; the units str_masks_body has done again)
-            const u32 uh = p.sv.unit_h[u], uhp = u ? (u32)p.sv.unit_h[u - 1] : 0u;
-            x.qm = p.sv.qm[c];
-            x.q = p.sv.q[c];
-            // (the st masks of a unit without an escape starter are zero and stay unread: parking-citations has none at all)
-            if (uh & 2u) x.st = p.sv.st[c];
-            if (c && ((lane ? uh : uhp) & 2u)) x.stp_hi = reinterpret_cast<const u32 *>(arr_at(p.sv.st, c - 1, 1))[1];
-            x.h = uh & 1u;
-            x.sb = p.unit_str[u];
-            if (x.rec) x.r = p.rec[c];
-            x.g = p.unit_cnt[u];
-        } else if (!(p.unit_copy && p.unit_copy[u] == 0)) {
-            // (selective copy: a unit without a byte of a string that unescaping changes is not compacted -- nobody reads its
-            // stretch of the scratch buffer; its record reads as "nothing to emit")
-            x.rec = true;
-            x.r = p.rec[c];
-            x.g = p.unit_cnt[u];
-        }
+        x.qm = p.sv.qm[c];
+        x.q = p.sv.q[c];
+        // (the st masks of a unit without an escape starter are zero and stay unread: parking-citations has none at all)
+        if (sc.flags & 2u) x.st = p.sv.st[c];
+        if (c && (sc.flags & (lane ? 2u : 4u))) x.stp_hi = reinterpret_cast<const u32 *>(arr_at(p.sv.st, c - 1, 1))[1];
+        if (x.rec) x.r = p.rec[c];
         return x;
     };
-    // DERIVE: the offsets of the unit's strings are staged in the wave's escape list (free between two units' patches) and
-    // leave with coalesced stores; a lane writing the offsets of its chunk's strings straight to memory -- up to eight
-    // scattered 4-byte stores per unit and lane -- made this kernel 30-50 % slower (154 instead of 116 us on configs[1])
+    // The offsets of the unit's strings (SEL: and the positions of its closing quotes) are staged in the wave's escape list
+    // (free between two units' patches) and leave with coalesced stores; a lane writing the offsets of its chunk's strings
+    // straight to memory -- up to eight scattered 4-byte stores per unit and lane -- made this kernel 30-50 % slower
+    // (154 instead of 116 us on configs[1])
     u32 *const s_so = reinterpret_cast<u32 *>(&s_gu[wave].list[0]);
-    constexpr u32 SO_CAP = 1024;  // (GenUnit::list holds 2052 16-bit entries)
-    auto convert = [&](const Raw &x) {
+    uint2 *const s_so2 = reinterpret_cast<uint2 *>(&s_gu[wave].list[0]);
+    constexpr u32 SO_CAP = SEL ? 512 : 1024;  // (GenUnit::list holds 2052 16-bit entries = 1026 words = 513 pairs)
+    auto convert = [&](const Raw &x, u64 u, u32 tq) {
         Unit v;
         v.em = x.r.em;
         v.pre_raw = x.r.pre;
         v.esc = 0;
         v.g = x.g;
-        if (DERIVE) {
-            const ChunkFast f = chunk_fast(x.qm, x.q, x.st, (u64)x.stp_hi << 32, x.h);
-            u32 n, flags;
-            if (x.rec) {  // (uniform) emit mask and flags from k_measure's general routine
-                v.esc = ((x.st << 1) | (u64)(x.stp_hi >> 31)) & v.em;
-                n = (u32)popc64(v.em);
-                flags = v.pre_raw & ~CHUNK_PRE_MASK;
-            } else {
-                v.em = f.em;
-                v.esc = f.esc;
-                n = (u32)popc64(f.em);
-                flags = f.esc != 0 ? CHUNK_SLOW : 0u;
+        const u32 h = x.h & 1u;
+        const ChunkFast f = chunk_fast(x.qm, x.q, x.st, (u64)x.stp_hi << 32, h);
+        u32 flags;
+        if (x.rec) {  // (uniform) emit mask and flags from k_measure's general routine
+            v.esc = ((x.st << 1) | (u64)(x.stp_hi >> 31)) & v.em;
+            flags = v.pre_raw & ~CHUNK_PRE_MASK;
+        } else {
+            v.em = f.em;
+            v.esc = f.esc;
+            flags = f.esc != 0 ? CHUNK_SLOW : 0u;
+        }
+        u64 cq = 0;
+        if (SEL) {  // only the bytes of strings that hold an escape starter
+            u64 sel = 0;
+            if ((x.h & 2u) || x.uf)  // (uniform)
+                sel = sel_wave_mask(chunk_sel(x.qm, x.q, x.st, h), (x.uf & USEL_IN) ? 1u : 0u, (x.uf & USEL_OUT) ? 1u : 0u, lane);
+            v.em &= sel;
+            v.esc &= sel;
+            // (the flags stay: a chunk without an escaped character of its own may still receive the bytes of a \u escape that
+            // begins in the chunk in front -- it must park its bytes for the patch like in the other mode)
+            cq = x.q & ~f.oq;
+        }
+        const u32 n = (u32)popc64(v.em);
+        const u32 ns = (u32)popc64(f.oq);
+        const u32 incl = wave_incl_sum(n | (ns << 16));
+        const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 pre = (incl & 0xffffu) - n, spre = (incl >> 16) - ns, stotal = tot >> 16;
+        v.pre_raw = pre | flags;
+        // the strings that begin in this chunk: their number in the message and their Strings.B offset; SEL: and the raw length
+        // of their content -- the distance to their closing quote: in this chunk, or (the last string of the chunk only) in the
+        // next chunk of the unit that holds a closing quote, or (the last string of the unit only) where k_measure found it
+        if ((stotal != 0 || x.last) && x.live) {  // (uniform)
+            const bool staged = stotal <= SO_CAP;  // (uniform)
+            u32 far = 0;  // SEL: aligned offset of the first closing quote behind this chunk
+            if (SEL) {
+                const u64 cqb = __ballot(cq != 0);
+                const u64 above = lane < 63 ? cqb >> (lane + 1) : 0ull;
+                const int L = above ? lane + 1 + (int)ctz64(above) : lane;  // the next chunk of the unit with a closing quote
+                const u32 fb = (u32)__shfl(cq ? (int)ctz64(cq) : 0, L, 64);
+                far = above ? (u32)((u * 64 + (u64)L) * 64) + fb : tq;
             }
-            const u32 ns = (u32)popc64(f.oq);
-            const u32 incl = wave_incl_sum(n | (ns << 16));
-            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-            const u32 pre = (incl & 0xffffu) - n, spre = (incl >> 16) - ns, stotal = tot >> 16;
-            v.pre_raw = pre | flags;
-            // the strings that begin in this chunk: their number in the message and their Strings.B offset
-            if (stotal != 0 || x.last) {  // (uniform)
-                const bool staged = stotal <= SO_CAP;  // (uniform)
-                u32 i = spre;
-                for (u64 r = f.oq; r != 0; r &= r - 1, i++) {
-                    const u32 val = x.g + pre + (u32)popc64(v.em & ((1ull << ctz64(r)) - 1ull));
+            u32 i = spre;
+            for (u64 r = f.oq; r != 0; r &= r - 1, i++) {
+                const u32 b = (u32)ctz64(r);
+                const u32 val = x.g + pre + (u32)popc64(v.em & ((1ull << b) - 1ull));
+                if (SEL) {
+                    const u64 cqa = b < 63 ? cq & (~0ull << (b + 1)) : 0ull;  // closing quotes of the chunk behind the opening one
+                    const u32 open_at = (u32)((u * 64 + (u64)lane) * 64) + b;
+                    const u32 raw = (cqa ? (u32)((u * 64 + (u64)lane) * 64) + (u32)ctz64(cqa) : far) - open_at - 1u;
+                    if (staged) s_so2[i] = make_uint2(val, raw);
+                    else if (x.sb + i < p.soff_cap) p.sinfo[x.sb + i] = make_uint2(val, raw);
+                } else {
                     if (staged) s_so[i] = val;
                     else if (x.sb + i < p.soff_cap) p.soff[x.sb + i] = val;
                 }
-                if (staged) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    for (u32 j = (u32)lane; j < stotal; j += 64)
-                        if (x.sb + j < p.soff_cap) p.soff[x.sb + j] = s_so[j];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();  // (the next user of the list waits for these reads)
+            }
+            if (staged) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                for (u32 j = (u32)lane; j < stotal; j += 64) {
+                    if (x.sb + j >= p.soff_cap) continue;
+                    if (SEL) p.sinfo[x.sb + j] = s_so2[j];
+                    else p.soff[x.sb + j] = s_so[j];
                 }
-                // (behind the last string: the end of Strings.B, so that every length is a difference)
-                if (x.last && lane == 63 && x.sb + stotal < p.soff_cap) p.soff[x.sb + stotal] = x.g + (tot & 0xffffu);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // (the next user of the list waits for these reads)
+            }
+            // (behind the last string: the end of Strings.B, so that every length is a difference)
+            if (x.last && lane == 63 && x.sb + stotal < p.soff_cap) {
+                if (SEL) p.sinfo[x.sb + stotal] = make_uint2(x.g + (tot & 0xffffu), 0u);
+                else p.soff[x.sb + stotal] = x.g + (tot & 0xffffu);
             }
         }
         return v;
@@ -597,7 +740,9 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
         }
     };
-    Unit cur = convert(load_raw(unit)), nxt = convert(load_raw(unit + nwaves));
+    const Sc sc1 = load_sc(unit), sc2 = load_sc(unit + nwaves);
+    Sc sc3 = load_sc(unit + 2 * nwaves);
+    Unit cur = convert(load_raw(unit, sc1), unit, sc1.tq), nxt = convert(load_raw(unit + nwaves, sc2), unit + nwaves, sc2.tq);
     __syncthreads();
     if (unit >= p.units) return;
     u8 *in8 = &s_io[wave][0];
@@ -609,8 +754,9 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         const u64 c = unit * 64 + lane;
         const u64 next = unit + nwaves;
         const bool more = next < p.units;  // wave-uniform
-        const Raw nn = load_raw(next + nwaves);   // two units ahead
-        load_chunk(next, nxt.em, w_n);            // one unit ahead (its masks were requested an iteration ago)
+        const Raw nn = load_raw(next + nwaves, sc3);   // two units ahead (its scalars were requested an iteration ago)
+        load_chunk(next, nxt.em, w_n);                 // one unit ahead (its masks were requested an iteration ago)
+        const Sc sc4 = load_sc(next + 2 * nwaves);     // the scalars of the unit three ahead
         const u64 em = cur.em;
         const u32 pre_raw = cur.pre_raw;
         const u32 pre = pre_raw & CHUNK_PRE_MASK;
@@ -630,13 +776,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
                 // and the lanes take them round robin; the translated bytes go into the parked copy of the chunk they
                 // fall into, this one or the next (sj_strings.h str_chunk_patch is the per-chunk statement).
                 u64 le = 0, foreign = 0;
-                if (mine && general) {
-                    if (DERIVE) le = cur.esc;
-                    else {
-                        const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-                        le = ((stc << 1) | stp) & em;
-                    }
-                }
+                if (mine && general) le = cur.esc;
                 if (lane == 0 && general && c > 0)  // escapes of the chunk in front whose bytes reach into chunk 0
                     foreign = ((p.sv.esc(c - 1) & p.rec[c - 1].em) >> 60) & 0xfull;
                 GenUnit *gu = &s_gu[wave];
@@ -654,13 +794,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
             if (mine) {
                 if (!general) {  // simple escapes only: translated in place, nothing is read from the message
-                    u64 r;
-                    if (DERIVE) r = cur.esc;
-                    else {
-                        const u64 stc = p.sv.st[c], stp = c ? p.sv.st[c - 1] >> 63 : 0ull;
-                        r = ((stc << 1) | stp) & em;
-                    }
-                    for (; r != 0; r &= r - 1) {
+                    for (u64 r = cur.esc; r != 0; r &= r - 1) {
                         const u32 ix = byte_ix((u32)ctz64(r));
                         in8[ix] = s_esc[in8[ix]];
                     }
@@ -716,7 +850,8 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         if (!more) break;
         unit = next;
         cur = nxt;
-        nxt = convert(nn);
+        nxt = convert(nn, next + nwaves, sc3.tq);
+        sc3 = sc4;
 #pragma unroll
         for (int q = 0; q < 16; q++) w[q] = w_n[q];
     }
@@ -769,65 +904,9 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
     return pagg_comb<S>(before, pagg_dpp<S, 0x138, 0xf>(incl));  // wave_shr:1: the lane in front, identity in lane 0
 }
 
-// ---- selective copy on the emit masks: the length of every string, one string per lane ------------------------------
-// 1024 tokens per block: the string tokens are compacted into an LDS queue (a wave ballot per 64 tokens) and measured
-// with the lanes packed densely (sj_strings.h string_measure_masks: two record gathers and the closing quote).  Runs
-// between the string half and the token half of k_measure.
-__global__ __launch_bounds__(256) void k_str_measure(S2Dev p) {
-    __shared__ u32 s_q[1024];
-    __shared__ u32 s_n;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const u32 n = token_count(p);
-    const u32 t0 = blockIdx.x * 1024u;
-    if (t0 >= n) return;  // (the grid is sized for the upper bound)
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    u32 kv = 0;
-    const u32 i0 = t0 + (u32)tid * 4u;
-    if (i0 + 4 <= n) kv = *reinterpret_cast<const u32 *>(arr_at(p.kind, i0, 4));
-    else
-        for (u32 j = 0; i0 + j < n; j++) kv |= (u32)p.kind[i0 + j] << (8 * j);
-    u32 cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) cnt += ((kv >> (8 * j)) & 0xffu) == K_STRING ? 1u : 0u;
-    // queue slots: wave scan of the counts, one atomic per wave
-    const u32 incl = wave_incl_sum(cnt);
-    u32 wb = 0;
-    if (lane == 63 && incl) wb = atomicAdd(&s_n, incl);
-    u32 slot = (u32)__shfl((int)wb, 63, 64) + incl - cnt;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (((kv >> (8 * j)) & 0xffu) == K_STRING) s_q[slot++] = i0 + (u32)j;
-    __syncthreads();
-    // Two strings per lane and round, every load of both requested before the first use: the kernel is bound by the chain
-    // kinds -> queue -> positions -> records -> store of a block, not by instructions (one string per lane and round:
-    // 84 us on configs[1], 300 us on configs[4]'s 30 M strings)
-    const u32 ns = s_n;
-    for (u32 j = (u32)tid; j < ns; j += 512) {
-        const bool two = j + 256 < ns;
-        const u32 i0 = s_q[j], i1 = two ? s_q[j + 256] : i0;
-        const u64 pa0 = p.pos[i0], pb0 = i0 + 1 < n ? (u64)p.pos[i0 + 1] : p.len;
-        const u64 pa1 = p.pos[i1], pb1 = i1 + 1 < n ? (u64)p.pos[i1 + 1] : p.len;
-        const u64 a00 = pa0 + p.sv.lead + 1, a01 = pb0 + p.sv.lead, a10 = pa1 + p.sv.lead + 1, a11 = pb1 + p.sv.lead;
-        const ChunkRec r00 = p.rec[a00 >> 6], r01 = p.rec[a01 >> 6], r10 = p.rec[a10 >> 6], r11 = p.rec[a11 >> 6];
-        const u64 q0 = p.sv.q[a01 >> 6], q1 = p.sv.q[a11 >> 6];
-        const StrMeasure m0 = string_measure_loaded(p.sv, p.unit_cnt, a00, a01, r00, r01, q0);
-        const StrMeasure m1 = string_measure_loaded(p.sv, p.unit_cnt, a10, a11, r10, r11, q1);
-        p.dlen[i0] = m0.ok ? (m0.dl | (m0.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
-        if (two) p.dlen[i1] = m1.ok ? (m1.dl | (m1.copied ? DLEN_COPY : 0u)) : DLEN_INVALID;
-        // the units a string that will be copied reaches into: only those are compacted (k_str_emit)
-        if (m0.ok && m0.copied)
-            for (u64 u = a00 >> 12; u <= (a01 >> 12) && u < p.units; u++) p.unit_copy[u] = 1;
-        if (two && m1.ok && m1.copied)
-            for (u64 u = a10 >> 12; u <= (a11 >> 12) && u < p.units; u++) p.unit_copy[u] = 1;
-    }
-}
-
 // Both measuring passes in one launch (they are independent and neither fills the device on its own): blocks below
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
-// (WithCopyStrings(false) launches the halves one behind the other: the token half then measures the strings from the
-// records the string half leaves.)
 __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block);
 __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks);
 
@@ -1029,25 +1108,11 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
     const TileLane tl = tile_lane<TK_ITEMS>(p, t0, n, tid, s_edge);
     const Lane16 &m = tl.m;
     const u32 base = tl.base;
-    // selective copy (WithCopyStrings(false)): the Strings.B bytes of the strings that unescaping changes go through the
-    // scan; their lengths come from k_str_measure (emit masks) or, in the fallback, from a walk per string
+    // Strings.B offsets: with stage 1's masks (both copy modes) they are a property of the message -- k_str_emit leaves the
+    // offset of the k-th string in soff[k], and what goes through the scan is the NUMBER of strings; without the masks (the
+    // per-string fallback, S2_ERR_SERIAL_STRINGS) every string is walked here and the bytes to copy go through the scan
     u32 sbytes = 0;
-    if (p.sv.qm && !p.copy_strings) {
-        u32 dv[TK_ITEMS];
-        if (base + TK_ITEMS <= n) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(arr_at(p.dlen, base + 4 * q, 4));
-                dv[4 * q] = x.x; dv[4 * q + 1] = x.y; dv[4 * q + 2] = x.z; dv[4 * q + 3] = x.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < TK_ITEMS; k++) dv[k] = base + k < n ? p.dlen[base + k] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < TK_ITEMS; k++)
-            sbytes += (((m.str >> k) & 1u) && dv[k] != DLEN_INVALID && (dv[k] & DLEN_COPY)) ? (dv[k] & ~DLEN_COPY) : 0u;
-    } else if (!p.sv.qm) {
+    if (!p.sv.qm) {
         const MsgView mv{p.msg, p.len};
         for (u32 r = m.str; r != 0; r &= r - 1) {
             const u32 k = (u32)__builtin_ctz(r);
@@ -1063,9 +1128,8 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
             p.dlen[base + k] = out;
         }
     }
-    // (every string copied from the masks: the scan's byte field carries the NUMBER of strings instead -- the tile's first
-    // string is string number Agg::s of the message, whose Strings.B offset k_str_emit leaves in soff[])
-    if (p.sv.qm && p.copy_strings) sbytes = popc32(m.str);
+    // (the tile's first string is then string number Agg::s of the message)
+    if (p.sv.qm) sbytes = popc32(m.str);
     PAgg acc = lane16_pagg(m);
     acc.s = sbytes;
     const PAgg incl = pagg_wave_inclusive<true>(acc);
@@ -1080,33 +1144,39 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
 
 __global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
-    if (blockIdx.x < mblocks) str_masks_body(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
+    if (blockIdx.x < mblocks) {
+        if (p.copy_strings) str_masks_body<false>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
+        else str_masks_body<true>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
+    }
     else s2_reduce_planes(p, blockIdx.x - mblocks);
 }
 
 // ---- pass 3 on planes -----------------------------------------------------------------------------------------------
 // queue entry of a string / scalar: token index inside the tile | tape offset inside the tile << 12 | (string: object key
 // << 25) | (scalar: kind - 8 << 26)
-template <bool MASKS, int ITEMS>
+// MODE 0: no masks (the per-string fallback: lengths from the walks of the token reduce, both copy modes); 1: every string
+// copied, offsets from soff[]; 2: WithCopyStrings(false) on the masks -- soff[] and the closing quotes scq[]
+template <int MODE, int ITEMS>
 __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit_planes(S2Dev p) {
+    constexpr bool MASKS = MODE != 0;
     constexpr int BLK = S2_TILE / ITEMS, WAVES = BLK / 64;
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
-    // strings [0, S) | the tile's brackets [SB, SB + B) | atoms and numbers [SB + B, SB + B + D): a tile has 4096 tokens.
-    // MASKS (every string copied): no string queue -- [0, S] holds the Strings.B offsets of the tile's S strings and of the
-    // string behind them (soff[], left by k_str_emit in message order = token order), SB = S + 1; otherwise SB = S
-    __shared__ u32 s_q[S2_TILE + 8];
+    // strings [0, S) | the tile's brackets [S, S + B) | atoms and numbers [S + B, S + B + D): a tile has 4096 tokens.
+    // (MASKS: no string queue -- a lane reads the entries of its strings, consecutive ones of soff[] / sinfo[], straight
+    // from memory while the scalars and brackets are queued)
+    __shared__ u32 s_q[S2_TILE];
     __shared__ u32 s_edge[BLK + 2];
     __shared__ PAgg s_w[WAVES];
     __shared__ u32 s_wc[WAVES];
     __shared__ i32 s_gmin[S2_TILE / 64];
-    __shared__ u32 s_nnum, s_base, s_fill, s_ccnt, s_cbase, s_cfill;
+    __shared__ u32 s_nnum, s_base, s_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     const u32 t0 = blockIdx.x * S2_TILE;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    if (tid == 0) s_nnum = s_fill = s_ccnt = s_cfill = 0;
+    if (tid == 0) s_nnum = s_fill = 0;
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     {
@@ -1163,11 +1233,6 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     if (!MASKS) {  // the scan's s field carries bytes: the slots get a scan of their own
         const u32 incl = wave_incl_sum(cnts);
         if (lane == 63) s_wc[wave] = incl;
-        u32 nc = 0;
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) nc += dv[k] != 0u ? 1u : 0u;
-        nc = wave_incl_sum(nc);
-        if (lane == 63 && nc) atomicAdd(&s_ccnt, nc);  // the tile's strings that k_emit_strings will copy
         __syncthreads();
         cex = incl - cnts;
         ctot = 0;
@@ -1183,13 +1248,31 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         if (lane == 63 && nn) atomicAdd(&s_nnum, nn);
     }
     const u32 S = ctot & 0x1fffu, D = ctot >> 13, B = total.x >> 14;
-    const u32 SB = MASKS ? S + 1u : S;
-    if (MASKS) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
-        for (u32 j = (u32)tid; j <= S; j += BLK) s_q[j] = tp.s + j < p.soff_cap ? p.soff[tp.s + j] : 0u;
-    }
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
     const u32 lane_w = ex.x & 0x3fffu, lane_bc = ex.x >> 14, lane_open = ex.y & 0x1fffu, lane_nb = ex.y >> 13;
     bool bad = lane16_illegal(m);  // a token that is legal in no context at all
+    // MASKS: the lane's strings are strings number kb, kb + 1, ... of the message (k_measure counted them through the scan);
+    // their entries -- and the entry behind the last one, whose offset ends it -- are requested now and used behind the barrier
+    u32 sx[ITEMS], sy[ITEMS], s_end = 0;
+    if (MASKS) {
+        const u32 kb = tp.s + (cex & 0x1fffu);
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            sx[j] = sy[j] = 0;
+            const u32 kk = kb + popc32(m.str & ((1u << j) - 1u));
+            if (((m.str >> j) & 1u) && kk < p.soff_cap) {
+                if (MODE == 2) {
+                    const uint2 e = p.sinfo[kk];
+                    sx[j] = e.x;
+                    sy[j] = e.y;
+                } else {
+                    sx[j] = p.soff[kk];
+                }
+            }
+        }
+        const u32 ke = kb + popc32(m.str);
+        if (m.str != 0 && ke < p.soff_cap) s_end = MODE == 2 ? p.sinfo[ke].x : p.soff[ke];
+    }
     if (!MASKS) {
         u32 slot = cex & 0x1fffu, run = ex.s;
         for (u32 r = m.str; r != 0; r &= r - 1) {  // strings: worked on densely below
@@ -1204,7 +1287,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     {
-        u32 slot = SB + B + (cex >> 13);
+        u32 slot = S + B + (cex >> 13);
         for (u32 r = m.num | m.atom; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             const u32 kd = ((m.num >> j) & 1u) ? (u32)K_NUM : (u32)lane16_atom_kind(m, j);
@@ -1212,7 +1295,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     {
-        u32 slot = SB + lane_bc;
+        u32 slot = S + lane_bc;
         const u32 am_in = am_combine(tp.am, ex.z);
         for (u32 r = m.br; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), upto = (2u << j) - 1u;
@@ -1225,52 +1308,49 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         p.nl_off[tp.nb + lane_nb + popc32(m.nlr & ((1u << j) - 1u))] = T0 + lane_w + lane16_words_before(m, j);
     }
     __syncthreads();  // the queues and the bracket list are complete
-    // ---- strings, every string copied: string number (tp.s + index inside the tile) of the message -> its Strings.B offset,
-    // and the next string's offset ends it (Strings.B is the concatenation of all strings); both tape words in one 16-byte
-    // store (the tape is only 8-byte aligned: fine on gfx950).  No gathers: a lane's strings are consecutive entries.
+    // ---- strings on the masks: a string ends where the next one begins (Strings.B is the concatenation of the strings that
+    // are copied); both tape words in one 16-byte store (the tape is only 8-byte aligned: fine on gfx950).  MODE 2: a string
+    // of length 0 there is not copied (it holds no escape: every escape emits a byte) -- the tape points into the message
+    // and the length is the raw length of its content (stage2_build_tape_amd64.go:90-109)
     if (MASKS) {
-        u32 ks = cex & 0x1fffu;
-        for (u32 r = m.str; r != 0; r &= r - 1, ks++) {
-            const u32 j = (u32)__builtin_ctz(r), lo = lane_w + lane16_words_before(m, j);
-            const u32 so = s_q[ks], se = s_q[ks + 1];
-            const u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
+        u32 nextx = s_end;
+        u32 at[ITEMS];  // MODE 2: the positions of the lane's tokens, back from LDS in one go
+        if (MODE == 2 && m.str != 0) {
+#pragma unroll
+            for (int q = 0; q < ITEMS / 4; q++) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(&s_pos[tid * ITEMS + 4 * q]);
+                at[4 * q] = a.x; at[4 * q + 1] = a.y; at[4 * q + 2] = a.z; at[4 * q + 3] = a.w;
+            }
+        }
+#pragma unroll
+        for (int j = ITEMS - 1; j >= 0; j--) {
+            if (!((m.str >> j) & 1u)) continue;
+            const u32 so = sx[j], se = nextx, lo = lane_w + lane16_words_before(m, (u32)j);
+            nextx = so;
+            u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
+            if (MODE == 2 && se == so) {
+                w0 = string_word(false, 0, p.msg_base + at[j] + 1);
+                w1 = (u64)sy[j];
+            }
             *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
             if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((m.keystr >> j) & 1u);
         }
     }
-    // ---- selective copy: the lengths k_str_measure (or, in the fallback, the per-string walks of the token reduce) left;
-    // a string that unescaping changed points into Strings.B and is queued for k_emit_strings with everything that kernel
-    // needs, the others point into the message (parseString, stage2_build_tape_amd64.go:90-109)
+    // ---- the per-string fallback: the lengths the walks of the token reduce left; a string that is copied (every string, or
+    // with WithCopyStrings(false) one that unescaping changed) points into Strings.B -- k_emit_strings walks it again and
+    // writes its bytes at the offset left in str_off --, the others point into the message (parseString,
+    // stage2_build_tape_amd64.go:90-109)
     if (!MASKS) {
-        if (tid == 0 && s_ccnt != 0 && p.sv.qm) s_cbase = atomicAdd(&p.st->str_count, s_ccnt);
-        __syncthreads();
-        for (u32 j0 = 0; j0 < S; j0 += BLK) {  // (block-uniform trip count: the ballots below want whole waves)
-            const u32 j = j0 + (u32)tid;
-            bool queue = false;
-            u32 at = 0, so = 0, len = 0;
-            if (j < S) {
-                const u32 v = s_q[j], idx = v & 0xfffu, lo = (v >> 12) & 0x1fffu;
-                const u32 dlw = p.dlen[t0 + idx];
-                at = p.pos[t0 + idx];
-                so = tp.s + s_pos[idx];
-                if (dlw != DLEN_INVALID) {
-                    const bool cp = (dlw & DLEN_COPY) != 0;
-                    len = dlw & ~DLEN_COPY;
-                    const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = len;
-                    *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
-                    if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
-                    if (!p.sv.qm) p.str_off[t0 + idx] = so;  // (per-string walks: k_emit_strings looks the offset up per token)
-                    queue = cp && len != 0 && p.sv.qm;
-                }
-            }
-            // queue slots inside the tile's range: one LDS atomic per wave and pass, the lanes take consecutive entries
-            const u64 qm = __ballot(queue);
-            if (qm != 0) {
-                u32 qbase = 0;
-                if (lane == 0) qbase = atomicAdd(&s_cfill, (u32)__popcll(qm));
-                qbase = s_cbase + (u32)__builtin_amdgcn_readfirstlane((int)qbase);
-                const u32 slot = qbase + (u32)__popcll(qm & ((1ull << lane) - 1ull));
-                if (queue && slot < p.strq_cap) p.strq[slot] = make_uint4(at, so, len, 0u);
+        for (u32 j = (u32)tid; j < S; j += BLK) {
+            const u32 v = s_q[j], idx = v & 0xfffu, lo = (v >> 12) & 0x1fffu;
+            const u32 dlw = p.dlen[t0 + idx];
+            const u32 at = p.pos[t0 + idx], so = tp.s + s_pos[idx];
+            if (dlw != DLEN_INVALID) {
+                const bool cp = (dlw & DLEN_COPY) != 0;
+                const u64 w0 = string_word(cp, p.strings_base + so, p.msg_base + at + 1), w1 = dlw & ~DLEN_COPY;
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+                if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((v >> 25) & 1u);
+                p.str_off[t0 + idx] = so;
             }
         }
     }
@@ -1282,7 +1362,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         if (cnt != 0) __syncthreads();  // (block-uniform)
         const u32 qb = s_base;
         for (u32 j = (u32)tid; j < D; j += BLK) {
-            const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+            const u32 v = s_q[S + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
             const u8 ak = (u8)(8u + ((v >> 26) & 3u));
             if (ak == K_NUM) {
                 u64 iv = 0;
@@ -1306,7 +1386,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         const u32 G = (B + 63u) / 64u;
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // the minimum depth of every group of 64
             const u32 c = g * 64u + (u32)lane;
-            i32 v = c < B ? tbr_depth(s_q[SB + c]) : 0x7fffffff;
+            i32 v = c < B ? tbr_depth(s_q[S + c]) : 0x7fffffff;
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) {
                 const i32 o = __shfl_xor(v, sft, 64);
@@ -1319,7 +1399,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // wave-uniform
             const u32 c = g * 64u + (u32)lane;
             const bool valid = c < B;
-            const u32 e = valid ? s_q[SB + c] : 0u;
+            const u32 e = valid ? s_q[S + c] : 0u;
             const i32 drel = valid ? tbr_depth(e) : 0x7fffffff;
             const u8 kd = tbr_kind(e);
             const u32 gap = tbr_gap(e), oc = T0 + tbr_off(e);
@@ -1353,7 +1433,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 while (cand != 0 && pm != 0) {
                     const u32 gp = (u32)top_bit(cand);
                     cand &= ~(1ull << gp);
-                    const i32 dprev = tbr_depth(s_q[SB + gp * 64u + (u32)lane]);  // (a group in front is full)
+                    const i32 dprev = tbr_depth(s_q[S + gp * 64u + (u32)lane]);  // (a group in front is full)
                     for (u64 pp = pm; pp != 0;) {
                         const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pp));
                         const u64 at = __ballot(dprev <= v);
@@ -1373,7 +1453,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 bad |= !context_allowed(gap, CTX_ROOT);
                 done = true;
             } else if (res >= 0) {
-                const u32 ej = s_q[SB + (u32)res + 1u];  // partner (close) / parent (open)
+                const u32 ej = s_q[S + (u32)res + 1u];  // partner (close) / parent (open)
                 const u8 jk = tbr_kind(ej);
                 bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
                 done = true;
@@ -1671,47 +1751,8 @@ __device__ __forceinline__ void br_match_body(const S2Dev &p, u32 bid, u32 nb) {
     if (bad) atomicOr(&p.st->err, 1u);
 }
 __global__ __launch_bounds__(256) void k_br_match(S2Dev p) { br_match_body(p, blockIdx.x, gridDim.x); }
-// ---- selective copy: the strings that unescaping changes go to Strings.B, one string per lane --------------------
+// ---- the per-string fallback (no masks): every string that is copied is walked again, now writing (string_walk) -------
 __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
-    if (p.sv.qm) {
-        // on the emit masks: the unescaped bytes of every string wait in k_str_emit's compaction (str_out), the strings
-        // that changed were queued by k_s2_emit: one string per lane, grid-stride over the queue
-        u32 cnt = p.st->str_count;
-        if (cnt > p.strq_cap) cnt = p.strq_cap;
-        // two strings per lane and round, their entries, records and first eight bytes requested together (the kernel waits
-        // on dependent loads: entry -> record -> bytes)
-        const u32 stride = gridDim.x * 256;
-        for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += 2 * stride) {
-            const bool two = j + stride < cnt;
-            const uint4 e0 = p.strq[j], e1 = two ? p.strq[j + stride] : e0;
-            const u64 a0 = (u64)e0.x + p.sv.lead + 1, a1 = (u64)e1.x + p.sv.lead + 1;
-            const ChunkRec r0 = p.rec[a0 >> 6], r1 = p.rec[a1 >> 6];
-            const u32 u0 = p.unit_cnt[a0 >> 12], u1 = p.unit_cnt[a1 >> 12];
-            const u32 b0 = (u32)(a0 & 63), b1 = (u32)(a1 & 63);
-            const u64 s0 = (u64)u0 + (r0.pre & CHUNK_PRE_MASK) + (u64)popc64(b0 ? r0.em & (~0ull >> (64 - b0)) : 0ull);  // emitted_before()
-            const u64 s1 = (u64)u1 + (r1.pre & CHUNK_PRE_MASK) + (u64)popc64(b1 ? r1.em & (~0ull >> (64 - b1)) : 0ull);
-            const bool ok0 = (u64)e0.y + e0.z <= p.strings_cap, ok1 = two && (u64)e1.y + e1.z <= p.strings_cap;
-            const u8 *src0 = arr_at(p.str_out, s0, (u64)e0.z + 8), *src1 = arr_at(p.str_out, s1, (u64)e1.z + 8);  // (the tail reads 8:
-            const u64 h0 = load_u64(src0), h1 = load_u64(src1);                                                   // 64 bytes of slack)
-            if (ok0) {
-                u8 *dst = arr_at(p.strings, e0.y, e0.z);
-                const u32 n = e0.z;
-                u32 b = 0;
-                u64 w = h0;
-                for (; b + 8 <= n; b += 8, w = load_u64(src0 + b)) store_u64(dst + b, w);  // (neither side is aligned: fine on gfx950)
-                if (b < n) store_bytes(dst + b, w, n - b);
-            }
-            if (ok1) {
-                u8 *dst = arr_at(p.strings, e1.y, e1.z);
-                const u32 n = e1.z;
-                u32 b = 0;
-                u64 w = h1;
-                for (; b + 8 <= n; b += 8, w = load_u64(src1 + b)) store_u64(dst + b, w);
-                if (b < n) store_bytes(dst + b, w, n - b);
-            }
-        }
-        return;
-    }
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= token_count(p)) return;
     if (p.kind[i] != K_STRING) return;
@@ -1802,8 +1843,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.nl_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_NL_OFF);
     p.numq = SJ_ARR(reinterpret_cast<uint2 *>(carve(n * 8)), n, A_NUMQ);
     p.bigq = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 8)), 2 * n, A_BIGQ);
-    p.strq_cap = (u32)(n / 2 + 8);
-    p.strq = SJ_ARR(reinterpret_cast<uint4 *>(carve((size_t)p.strq_cap * 16)), p.strq_cap, A_STRQ);
+    u32 *const scq_mem = reinterpret_cast<u32 *>(carve(((size_t)n / 2 + 8) * 16));  // >= 4 (n + 2) bytes
     p.br_depth = SJ_ARR(reinterpret_cast<i32 *>(carve(n * 4)), n, A_BR_DEPTH);
     p.br_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_BR_OFF);
     p.tiles = (u32)((n + S2_TILE - 1) / S2_TILE);
@@ -1849,6 +1889,8 @@ static S2Dev stage2_view(const S2Args &a) {
     p.unit_cnt = nullptr;
     p.unit_str = nullptr;
     p.soff = nullptr;
+    p.sinfo = nullptr;
+    p.unit_tq = nullptr;
     p.soff_cap = 0;
     p.unit_copy = nullptr;
     p.units = 0;
@@ -1857,8 +1899,7 @@ static S2Dev stage2_view(const S2Args &a) {
     if (const char *e = getenv("SJHIP_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
 #endif
     p.str_out = p.strings;
-    if (a.str_aux && !p.copy_strings) p.str_out = SJ_ARR(a.d_strings_tmp, a.strings_cap, A_STR_OUT);
-    if (a.str_aux && (p.copy_strings || a.d_strings_tmp)) {
+    if (a.str_aux) {
         const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
         p.sv.qm = SJ_ARR((const u64 *)x.qm, x.chunks, A_SV_QM);
         p.sv.q = SJ_ARR((const u64 *)x.q, x.chunks, A_SV_Q);
@@ -1867,12 +1908,15 @@ static S2Dev stage2_view(const S2Args &a) {
         p.sv.unit_slow = SJ_ARR((const u64 *)x.unit_slow, x.units, A_SV_UNIT_SLOW);
         p.rec = SJ_ARR(reinterpret_cast<ChunkRec *>(x.rec), x.chunks, A_REC);
         p.unit_cnt = SJ_ARR(x.unit_cnt, x.units, A_UNIT_CNT);
-        if (!p.copy_strings) p.unit_copy = SJ_ARR(x.unit_copy, x.units, A_UNIT_COPY);
-        else {  // every string copied: the strings of the message are numbered, their Strings.B offsets go where the measured
-                // lengths of the other mode lie (dlen and str_off are adjacent: 2 x align_up(4n, 256) >= 4 (n + 2) bytes)
-            p.unit_str = SJ_ARR(x.unit_str, x.units, A_UNIT_STR);
-            p.soff_cap = (u32)(n + 2 < 0xffffffffull ? n + 2 : 0xffffffffull);
-            p.soff = SJ_ARR(arr_raw(p.dlen), p.soff_cap, A_SOFF);
+        // the strings of the message are numbered, their Strings.B offsets go where the per-string fallback keeps its lengths
+        // (dlen and str_off are adjacent: 2 x align_up(4n, 256) >= 4 (n + 2) bytes)
+        p.unit_str = SJ_ARR(x.unit_str, x.units, A_UNIT_STR);
+        p.soff_cap = (u32)(n + 2 < 0xffffffffull ? n + 2 : 0xffffffffull);
+        p.soff = SJ_ARR(arr_raw(p.dlen), p.soff_cap, A_SOFF);
+        if (!p.copy_strings) {  // the states at the units' ends (k_measure), the closing quotes
+            p.unit_copy = SJ_ARR(x.unit_copy, x.units, A_UNIT_COPY);
+            p.sinfo = SJ_ARR(reinterpret_cast<uint2 *>(scq_mem), p.soff_cap, A_STRQ);  // (8 n + 128 bytes)
+            p.unit_tq = SJ_ARR(x.unit_tq, x.units, A_UNIT_STR);
         }
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }
@@ -1893,14 +1937,11 @@ void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off) {
 hipError_t stage2_launch_measure(const S2Args &a) {
     const S2Dev p = stage2_view(a);
     if (a.n == 0) return hipSuccess;
-    if (p.sv.qm && !p.copy_strings) {
-        // selective copy: the token half measures every string from the records of the string half
-        const u32 mblocks = persistent_blocks(k_measure, (p.units + 3) / 4);
-        hipLaunchKernelGGL(k_measure, dim3(mblocks), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
-        hipLaunchKernelGGL(k_str_measure, dim3((u32)((a.n + 1023) / 1024)), dim3(256), 0, a.stream, p);
-        hipLaunchKernelGGL(k_measure, dim3(p.tiles), dim3(RD_BLOCK), 0, a.stream, p, 0u);
-    } else {
-        const u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) / 2 + 1 : 0;  // half of the device's slots
+    {
+        // (WithCopyStrings(false) visits every unit in the string half: all of the device's slots; otherwise only the units with
+        // a \u escape are worked on: half of them)
+        u32 mblocks = p.sv.qm ? persistent_blocks(k_measure, (p.units + 3) / 4) : 0;
+        if (p.sv.qm && p.copy_strings) mblocks = mblocks / 2 + 1;
         hipLaunchKernelGGL(k_measure, dim3(mblocks + p.tiles), dim3(RD_BLOCK), 0, a.stream, p, mblocks);
     }
     hipLaunchKernelGGL(k_scans, dim3(p.sv.qm ? p.unit_segs * (p.unit_str ? 2 : 1) + p.tile_segs : p.tile_segs), dim3(1024), 0, a.stream, p);
@@ -1920,18 +1961,22 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     // hold strings to be copied goes to the scratch buffer k_emit_strings takes them from.  (Rounds 3 and 4 could also run
     // k_str_emit on a second stream beside the tape kernels, SJHIP_S2_OVERLAP: -2 % / +3 % on the two workloads, never the
     // default; gone with the records the tape kernels read then.)
-    const bool masks_copy = p.sv.qm && p.copy_strings;  // every string copied: offsets and lengths straight from the emit masks
-    if (masks_copy) hipLaunchKernelGGL(k_str_emit<true>, dim3(persistent_blocks(k_str_emit<true>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
-    else if (p.sv.qm) hipLaunchKernelGGL(k_str_emit<false>, dim3(persistent_blocks(k_str_emit<false>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    const int mode = !p.sv.qm ? 0 : (p.copy_strings ? 1 : 2);
+    if (mode == 1) hipLaunchKernelGGL(k_str_emit<false>, dim3(persistent_blocks(k_str_emit<false>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
+    else if (mode == 2) hipLaunchKernelGGL(k_str_emit<true>, dim3(persistent_blocks(k_str_emit<true>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     {
         static const int items = getenv("SJHIP_S2_ITEMS") ? atoi(getenv("SJHIP_S2_ITEMS")) : 8;  // tokens per lane (A/B)
+#define SJ_EMIT(M, I) hipLaunchKernelGGL((k_s2_emit_planes<M, I>), dim3(p.tiles), dim3(S2_TILE / I), 0, a.stream, p)
         if (items == 16) {
-            if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
-            else hipLaunchKernelGGL((k_s2_emit_planes<false, 16>), dim3(p.tiles), dim3(S2_TILE / 16), 0, a.stream, p);
+            if (mode == 0) SJ_EMIT(0, 16);
+            else if (mode == 1) SJ_EMIT(1, 16);
+            else SJ_EMIT(2, 16);
         } else {
-            if (masks_copy) hipLaunchKernelGGL((k_s2_emit_planes<true, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
-            else hipLaunchKernelGGL((k_s2_emit_planes<false, 8>), dim3(p.tiles), dim3(S2_TILE / 8), 0, a.stream, p);
+            if (mode == 0) SJ_EMIT(0, 8);
+            else if (mode == 1) SJ_EMIT(1, 8);
+            else SJ_EMIT(2, 8);
         }
+#undef SJ_EMIT
     }
     {  // numbers, and beside them levels 1 and 2 of the min tree (grid-stride: the kernel uses the real bracket count).
         // (Measured and dropped in round 4: the numbers beside the bracket matcher instead -- both wait on dependent
@@ -1941,7 +1986,7 @@ hipError_t stage2_launch_emit(const S2Args &a) {
         const u32 lblocks = (u32)(want < 2048 ? want : 2048);
         hipLaunchKernelGGL(k_numbers, dim3(nblocks + lblocks), dim3(256), 0, a.stream, p, nblocks);
     }
-    if (!masks_copy) hipLaunchKernelGGL(k_emit_strings, dim3(p.sv.qm ? (gb < 2048 ? gb : 2048) : gb), dim3(256), 0, a.stream, p);
+    if (mode == 0) hipLaunchKernelGGL(k_emit_strings, dim3(gb), dim3(256), 0, a.stream, p);
     if (p.nlev > 3) hipLaunchKernelGGL(k_min_upper, dim3(1), dim3(1024), 0, a.stream, p);
     hipLaunchKernelGGL(k_br_match, dim3(gb < 2048 ? gb : 2048), dim3(256), 0, a.stream, p);  // (8 waves per SIMD resident)
     return hipGetLastError();
@@ -1969,7 +2014,7 @@ __global__ __launch_bounds__(256) void k_pack(const S2State *st, const u64 *tape
 }
 hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap) {
     hipLaunchKernelGGL(k_pack, dim3(128), dim3(256), 0, a.stream, (const S2State *)a.ws_zero, (const u64 *)a.d_tape, (const u8 *)a.d_strings,
-                       (a.str_aux && (a.flags & 2u)) ? 1u : 0u, (u8 *)h_dst, (u64)cap);
+                       a.str_aux ? 1u : 0u, (u8 *)h_dst, (u64)cap);
     return hipGetLastError();
 }
 
