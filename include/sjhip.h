@@ -163,6 +163,35 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
                        uint64_t *n_records, size_t *tape_len, size_t *strings_len);
 int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 
+/* Paths, typed values and key sets on the same device-resident result (round 5).  A path is n_keys keys, concatenated in
+ * `keys`, key j being key_lens[j] bytes long (at most 16 keys, 1024 bytes together); every call evaluates it on the root
+ * value of EVERY record (one record for a plain document) with the semantics of the reference's host API:
+ *   sjhip_find_path        Iter.FindElement(path...) (parsed_json.go:833-865) = Object.FindPath (parsed_object.go:256-313):
+ *                          into the root and into objects, not into arrays; at every level the first member with the key
+ *                          wins.  index_out[r] = tape index of the element's value (tape[index] is its tag word), or
+ *                          SJHIP_PATH_NOT_FOUND (ErrPathNotFound) or SJHIP_PATH_NOT_OBJECT (the root value, or the value
+ *                          of a key that is not the last one, is not an object: the reference's type errors).
+ *                          *records = number of records; cap = room in index_out (records).
+ *   sjhip_count_where_path number of records whose element at `path` exists and satisfies `op`:
+ *                          EXISTS; EQ_STRING (value = vlen bytes, compared after unescaping, Iter.StringBytes);
+ *                          EQ_INT / EQ_UINT / EQ_FLOAT (value = an int64_t / uint64_t / double, vlen 8; the element is
+ *                          converted the way Iter.Int / Uint / Float convert between the three number tags,
+ *                          parsed_json.go:560-727); EQ_BOOL (value = one byte); IS_NULL.  8 bytes cross PCIe.
+ *   sjhip_project_keys     Object.ForEach(fn, onlyKeys) (parsed_object.go:142-196) on the root object of every record: the
+ *                          members whose key is in the set, in document order, at most n_keys of them (the reference stops
+ *                          after len(onlyKeys) deliveries).  out[r * n_keys + j] = key number << 56 | tape index of the
+ *                          value of the j-th delivered member, ~0 when there is no j-th.  The keys must be distinct. */
+#define SJHIP_PATH_NOT_FOUND (~0ull)
+#define SJHIP_PATH_NOT_OBJECT (~0ull - 1ull)
+enum { SJHIP_OP_EXISTS = 0, SJHIP_OP_EQ_STRING = 1, SJHIP_OP_EQ_INT = 2, SJHIP_OP_EQ_UINT = 3, SJHIP_OP_EQ_FLOAT = 4,
+       SJHIP_OP_EQ_BOOL = 5, SJHIP_OP_IS_NULL = 6 };
+int sjhip_find_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *index_out,
+                    size_t cap, size_t *records);
+int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, int op,
+                           const void *value, size_t vlen, uint64_t *count);
+int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *out,
+                       size_t cap_records, size_t *records);
+
 /* ---- Serializer.Serialize on the device (parsed_serialize.go:200-431, format version 3) -----------------------------
  * Splits the device-resident tape of the last parse (SJHIP_FLAG_COPY_STRINGS) into the reference's three columns --
  * tags (one byte per tape entry), values (8 / 16 bytes per value-bearing entry), strings (= Strings.B, the reference's

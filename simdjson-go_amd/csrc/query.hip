@@ -370,6 +370,133 @@ __global__ __launch_bounds__(256) void k_q_copy(QView q, QRec o, u64 *out_tape, 
     for (u32 k = (u32)lane; k < slen; k += 64) out_strings[ns + k] = q.strings[sb + k];
 }
 
+// ---- paths, typed values, key sets (round 5: Iter.FindElement parsed_json.go:833-865, Object.FindPath parsed_object.go:256-313,
+// Object.ForEach with onlyKeys parsed_object.go:142-196) ----------------------------------------------------------------------
+// The keys of a path / of a key set travel concatenated in QView::key; QPath holds where each one ends.
+static constexpr int QPATH_MAX = 16;
+struct QPath {
+    u32 end[QPATH_MAX];  // key j = key[end[j - 1] .. end[j])
+    u32 n;
+};
+__device__ __forceinline__ bool key_is(const QView &q, const QPath &pth, u32 j, u64 word, u64 len) {
+    const u32 b = j ? pth.end[j - 1] : 0u;
+    return str_equals(q, word, len, q.key + b, pth.end[j] - b);
+}
+__device__ __forceinline__ u64 skip_value(const QView &q, u64 v) {  // index behind the value whose first word is tape[v]
+    const u64 vw = q.tape[v];
+    const u32 vt = (u32)(vw >> 56);
+    if (vt == '{' || vt == '[') return vw & PAYLOAD;  // behind the matching close
+    return (vt == '"' || vt == 'l' || vt == 'u' || vt == 'd') ? v + 2 : v + 1;
+}
+// FindElement on record r: into the root, into objects, not into arrays; the first member with the key wins at every
+// level.  Returns the tape index of the element's value, SJHIP_PATH_NOT_FOUND (ErrPathNotFound) or SJHIP_PATH_NOT_OBJECT
+// ("type ... found before object was found" / "value of key ... is not an object").
+__device__ u64 record_find_path(const QView &q, const QPath &pth, u32 r) {
+    const u32 o = rec_open(q, r);
+    const u64 w = q.tape[o + 1];
+    if ((w >> 56) != '{') return SJHIP_PATH_NOT_OBJECT;
+    u64 end = (w & PAYLOAD) - 1;  // index of the closing '}'
+    u64 i = (u64)o + 2;
+    u32 seg = 0;
+    while (i < end) {
+        const u64 v = i + 2;
+        if (key_is(q, pth, seg, q.tape[i], q.tape[i + 1])) {
+            if (seg + 1 == pth.n) return v;
+            const u64 vw = q.tape[v];
+            if ((vw >> 56) != '{') return SJHIP_PATH_NOT_OBJECT;
+            end = (vw & PAYLOAD) - 1;
+            i = v + 1;
+            seg++;
+            continue;
+        }
+        i = skip_value(q, v);
+    }
+    return SJHIP_PATH_NOT_FOUND;
+}
+// the typed comparisons: what Iter.String / Int / Uint / Float / Bool return for the element (parsed_json.go:560-749:
+// integers, unsigned integers and floats convert into each other where the value fits), compared with the wanted value
+__device__ bool element_is(const QView &q, u64 v, int op, u64 want) {
+    const u64 w = q.tape[v];
+    const u32 t = (u32)(w >> 56);
+    switch (op) {
+    case SJHIP_OP_EXISTS: return true;
+    case SJHIP_OP_EQ_STRING: return t == '"' && str_equals(q, w, q.tape[v + 1], q.val, q.vlen);
+    case SJHIP_OP_EQ_BOOL: return (t == 't' && want != 0) || (t == 'f' && want == 0);
+    case SJHIP_OP_IS_NULL: return t == 'n';
+    case SJHIP_OP_EQ_INT: {
+        const u64 raw = (t == 'l' || t == 'u' || t == 'd') ? q.tape[v + 1] : 0;
+        if (t == 'l') return (long long)raw == (long long)want;
+        if (t == 'u') return raw <= 0x7fffffffffffffffull && (long long)raw == (long long)want;
+        if (t == 'd') {
+            // Iter.Int: an error above math.MaxInt64 / below math.MinInt64 (as float64 constants: 2^63 and -2^63), else int64(v) --
+            // which for v == 2^63 is the amd64 conversion's "integer indefinite", MinInt64
+            const double d = __longlong_as_double((long long)raw);
+            if (d > 9223372036854775808.0 || d < -9223372036854775808.0) return false;
+            const long long iv = d >= 9223372036854775808.0 || d != d ? (long long)0x8000000000000000ull : (long long)d;
+            return iv == (long long)want;
+        }
+        return false;
+    }
+    case SJHIP_OP_EQ_UINT: {
+        const u64 raw = (t == 'l' || t == 'u' || t == 'd') ? q.tape[v + 1] : 0;
+        if (t == 'u') return raw == want;
+        if (t == 'l') return (long long)raw >= 0 && raw == want;
+        if (t == 'd') {
+            const double d = __longlong_as_double((long long)raw);
+            if (!(d >= 0.0) || !(d < 18446744073709551616.0)) return false;
+            return (u64)d == want;
+        }
+        return false;
+    }
+    case SJHIP_OP_EQ_FLOAT: {
+        const double wd = __longlong_as_double((long long)want);
+        if (t == 'd') return __longlong_as_double((long long)q.tape[v + 1]) == wd;
+        if (t == 'l') return (double)(long long)q.tape[v + 1] == wd;
+        if (t == 'u') return (double)q.tape[v + 1] == wd;
+        return false;
+    }
+    }
+    return false;
+}
+__global__ __launch_bounds__(256) void k_q_find_path(QView q, QPath pth, u64 *out) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r <= q.R) out[r] = record_find_path(q, pth, r);
+}
+__global__ __launch_bounds__(256) void k_q_count_path(QView q, QPath pth, int op, u64 want, unsigned long long *count) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    bool m = false;
+    if (r <= q.R) {
+        const u64 v = record_find_path(q, pth, r);
+        m = v < SJHIP_PATH_NOT_OBJECT && element_is(q, v, op, want);
+    }
+    const u64 b = __ballot(m);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+// ForEach(fn, onlyKeys) on the root object of record r: the members whose key is in the set, in document order, until as
+// many members as the set has keys have been delivered (parsed_object.go:190-194: a key that occurs twice counts twice).
+// out[r * n + j] = key number << 56 | tape index of the value of the j-th delivered member; ~0: no further member
+__global__ __launch_bounds__(256) void k_q_project(QView q, QPath set, u64 *out) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r > q.R) return;
+    u64 *dst = out + (u64)r * set.n;
+    u32 n = 0;
+    const u32 o = rec_open(q, r);
+    const u64 w = q.tape[o + 1];
+    if ((w >> 56) == '{') {
+        const u64 end = (w & PAYLOAD) - 1;
+        for (u64 i = (u64)o + 2; i < end && n < set.n;) {
+            const u64 v = i + 2;
+            for (u32 j = 0; j < set.n; j++)
+                if (key_is(q, set, j, q.tape[i], q.tape[i + 1])) {
+                    dst[n++] = ((u64)j << 56) | v;
+                    break;
+                }
+            i = skip_value(q, v);
+        }
+    }
+    for (; n < set.n; n++) dst[n] = ~0ull;
+}
+
 }  // namespace
 
 namespace sj {
@@ -506,5 +633,115 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
         HIPCHK(hipMemcpyAsync(strings_dst, ctx->d_qstrings.p, ctx->q_strings_len, hipMemcpyDeviceToHost, ctx->stream),
                "D2H filtered strings");
     HIPCHK(hipStreamSynchronize(ctx->stream), "fetch sync");
+    return SJHIP_OK;
+}
+
+// ---- paths, typed values, key sets ------------------------------------------------------------------------------------------
+static int make_path_view(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, const uint8_t *val,
+                          size_t vlen, QView *q, QPath *pth, uint32_t *records) {
+    if (!ctx || !keys || !key_lens || n_keys == 0) return SJHIP_ERR_ARG;
+    if (n_keys > (uint32_t)QPATH_MAX) {
+        ctx_set_error(ctx, "a path / key set holds at most %d keys", QPATH_MAX);
+        return SJHIP_ERR_ARG;
+    }
+    size_t total = 0;
+    for (uint32_t j = 0; j < n_keys; j++) {
+        total += key_lens[j];
+        if (total > (size_t)QMAX) {
+            ctx_set_error(ctx, "the keys of a path / key set are longer than %d bytes together", QMAX);
+            return SJHIP_ERR_ARG;
+        }
+        pth->end[j] = (u32)total;
+    }
+    for (uint32_t j = n_keys; j < (uint32_t)QPATH_MAX; j++) pth->end[j] = (u32)total;
+    pth->n = n_keys;
+    static const uint8_t none = 0;
+    return make_view(ctx, keys, total, val ? val : &none, val ? vlen : 0, q, records);
+}
+
+int sjhip_find_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *index_out,
+                    size_t cap, size_t *records) {
+    if (!index_out || !records) return SJHIP_ERR_ARG;
+    QView q;
+    QPath pth;
+    uint32_t n = 0;
+    int rc = make_path_view(ctx, keys, key_lens, n_keys, nullptr, 0, &q, &pth, &n);
+    if (rc) return rc;
+    *records = n;
+    if (cap < n) {
+        ctx_set_error(ctx, "sjhip_find_path: room for %zu records, the result holds %u", cap, n);
+        return SJHIP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    rc = arena_reserve(ctx, ctx->d_kat, (size_t)n * 8 + 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_q_find_path, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, pth, (u64 *)ctx->d_kat.p);
+    HIPCHK(hipGetLastError(), "find_path launch");
+    HIPCHK(hipMemcpyAsync(index_out, ctx->d_kat.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H path indexes");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "find_path sync");
+    return SJHIP_OK;
+}
+
+int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, int op,
+                           const void *value, size_t vlen, uint64_t *count) {
+    if (!count || op < SJHIP_OP_EXISTS || op > SJHIP_OP_IS_NULL) return SJHIP_ERR_ARG;
+    const bool is_str = op == SJHIP_OP_EQ_STRING;
+    u64 want = 0;
+    if (op == SJHIP_OP_EQ_INT || op == SJHIP_OP_EQ_UINT || op == SJHIP_OP_EQ_FLOAT) {
+        if (!value || vlen != 8) return SJHIP_ERR_ARG;  // int64_t / uint64_t / double
+        memcpy(&want, value, 8);
+    } else if (op == SJHIP_OP_EQ_BOOL) {
+        if (!value || vlen != 1) return SJHIP_ERR_ARG;
+        want = *(const uint8_t *)value != 0;
+    } else if (is_str && !value && vlen) {
+        return SJHIP_ERR_ARG;
+    }
+    QView q;
+    QPath pth;
+    uint32_t n = 0;
+    int rc = make_path_view(ctx, keys, key_lens, n_keys, is_str ? (const uint8_t *)value : nullptr, is_str ? vlen : 0, &q, &pth, &n);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    rc = arena_reserve(ctx, ctx->d_kat, 64);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, 8, ctx->stream), "count memset");
+    hipLaunchKernelGGL(k_q_count_path, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, pth, op, want, (unsigned long long *)ctx->d_kat.p);
+    HIPCHK(hipGetLastError(), "count_where_path launch");
+    unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
+    HIPCHK(hipMemcpyAsync(h, ctx->d_kat.p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H count");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "count sync");
+    *count = *h;
+    return SJHIP_OK;
+}
+
+int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *out,
+                       size_t cap_records, size_t *records) {
+    if (!out || !records) return SJHIP_ERR_ARG;
+    QView q;
+    QPath set;
+    uint32_t n = 0;
+    int rc = make_path_view(ctx, keys, key_lens, n_keys, nullptr, 0, &q, &set, &n);
+    if (rc) return rc;
+    for (uint32_t a = 0; a < n_keys; a++)  // a set: the reference's onlyKeys is a map
+        for (uint32_t b = a + 1; b < n_keys; b++) {
+            const u32 ab = a ? set.end[a - 1] : 0, bb = set.end[b - 1];
+            if (set.end[a] - ab == set.end[b] - bb && memcmp(keys + ab, keys + bb, set.end[a] - ab) == 0) {
+                ctx_set_error(ctx, "sjhip_project_keys: key %u and key %u are equal", a, b);
+                return SJHIP_ERR_ARG;
+            }
+        }
+    *records = n;
+    if (cap_records < n) {
+        ctx_set_error(ctx, "sjhip_project_keys: room for %zu records, the result holds %u", cap_records, n);
+        return SJHIP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t bytes = (size_t)n * n_keys * 8;
+    rc = arena_reserve(ctx, ctx->d_kat, bytes + 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_q_project, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, set, (u64 *)ctx->d_kat.p);
+    HIPCHK(hipGetLastError(), "project_keys launch");
+    HIPCHK(hipMemcpyAsync(out, ctx->d_kat.p, bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H projected members");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "project_keys sync");
     return SJHIP_OK;
 }

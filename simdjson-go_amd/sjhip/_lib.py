@@ -54,6 +54,9 @@ SYMBOLS = {
     "sjhip_count_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p]),
     "sjhip_filter_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p, szp, szp]),
     "sjhip_fetch_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sjhip_find_path": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, szp]),
+    "sjhip_count_where_path": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, u64p]),
+    "sjhip_project_keys": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, szp]),
     "sjhip_serialize": (C.c_int, [C.c_void_p, szp, szp, szp, szp]),
     "sjhip_serialize_ex": (C.c_int, [C.c_void_p, C.c_uint32, szp, szp, szp, szp]),
     "sjhip_deserialize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, szp, szp, szp]),

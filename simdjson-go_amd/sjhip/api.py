@@ -211,6 +211,64 @@ class Context:
         self._check(L.sjhip_fetch_filtered(self._h, tape.ctypes.data, strings.ctypes.data))
         return n.value, ParsedJson(b"", tape, strings)
 
+    # ---- paths, typed values, key sets (include/sjhip.h: sjhip_find_path / _count_where_path / _project_keys) --------
+    PATH_NOT_FOUND = 0xFFFFFFFFFFFFFFFF
+    PATH_NOT_OBJECT = 0xFFFFFFFFFFFFFFFE
+    OP_EXISTS, OP_EQ_STRING, OP_EQ_INT, OP_EQ_UINT, OP_EQ_FLOAT, OP_EQ_BOOL, OP_IS_NULL = range(7)
+
+    @staticmethod
+    def _keys(keys):
+        ks = [bytes(k) for k in keys]
+        lens = (C.c_uint32 * max(len(ks), 1))(*[len(k) for k in ks])
+        return b"".join(ks), lens, len(ks)
+
+    def find_path(self, *path):
+        """Iter.FindElement(path...) (parsed_json.go:833-865) on the root of every record of the last parse, on the device.
+        -> uint64 array, one entry per record: the tape index of the element's value, PATH_NOT_FOUND or PATH_NOT_OBJECT"""
+        blob, lens, n = self._keys(path)
+        L = _lib.lib()
+        cnt = C.c_size_t(0)
+        probe = np.empty(1, dtype=np.uint64)
+        L.sjhip_find_path(self._h, blob, lens, n, probe.ctypes.data, 0, C.byref(cnt))  # (no room: only the record count is set)
+        out = np.empty(max(cnt.value, 1), dtype=np.uint64)
+        self._check(L.sjhip_find_path(self._h, blob, lens, n, out.ctypes.data, out.size, C.byref(cnt)))
+        return out[: cnt.value]
+
+    def count_where_path(self, path, op, value=None):
+        """records whose element at `path` exists and satisfies op (OP_*): value = bytes for OP_EQ_STRING, an int for
+        OP_EQ_INT / OP_EQ_UINT, a float for OP_EQ_FLOAT, a bool for OP_EQ_BOOL"""
+        import struct
+        blob, lens, n = self._keys(path)
+        if op == self.OP_EQ_STRING:
+            v = bytes(value)
+        elif op == self.OP_EQ_INT:
+            v = struct.pack("<q", int(value))
+        elif op == self.OP_EQ_UINT:
+            v = struct.pack("<Q", int(value))
+        elif op == self.OP_EQ_FLOAT:
+            v = struct.pack("<d", float(value))
+        elif op == self.OP_EQ_BOOL:
+            v = b"\x01" if value else b"\x00"
+        else:
+            v = b""
+        buf = C.create_string_buffer(v, max(len(v), 1))
+        cnt = C.c_uint64(0)
+        self._check(_lib.lib().sjhip_count_where_path(self._h, blob, lens, n, int(op), buf, len(v), C.byref(cnt)))
+        return cnt.value
+
+    def project_keys(self, keys):
+        """Object.ForEach(fn, onlyKeys) (parsed_object.go:142-196) on the root object of every record, on the device.
+        -> uint64 array [records, len(keys)]: key number << 56 | tape index of the value of the j-th delivered member,
+        2^64 - 1 where there is none"""
+        blob, lens, n = self._keys(keys)
+        L = _lib.lib()
+        cnt = C.c_size_t(0)
+        probe = np.empty(1, dtype=np.uint64)
+        L.sjhip_project_keys(self._h, blob, lens, n, probe.ctypes.data, 0, C.byref(cnt))  # (no room: only the record count is set)
+        out = np.empty((max(cnt.value, 1), n), dtype=np.uint64)
+        self._check(L.sjhip_project_keys(self._h, blob, lens, n, out.ctypes.data, out.shape[0], C.byref(cnt)))
+        return out[: cnt.value]
+
     def serialize(self, fetch=True, dedup=False):
         """Serializer.Serialize (format v3, CompressNone) of the device-resident result of the last parse.
         -> the framed stream as a uint8 array (what the reference's Deserialize reads), or its sizes with fetch=False.

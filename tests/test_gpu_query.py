@@ -160,3 +160,115 @@ def test_filtered_stream():
     # without a match anywhere
     none = list(sjhip.parse_nd_stream(io.BytesIO(stream), block_size=bs, inflight=2, where=(b"Make", b"no such make")))
     assert len(none) == len(blocks) and all(pj.records == 0 and len(pj.Tape) == 0 for pj in none)
+
+
+# ---- paths, typed values, key sets (sjhip_find_path / _count_where_path / _project_keys) against the restated walks -------
+import query_walk as Q  # noqa: E402
+import test_query_walk as TQ  # noqa: E402
+
+
+def _walk_of(pj):
+    return Q.Walk(pj.Tape, pj.Strings, pj.Message)
+
+
+def check_paths(ctx, doc, nd, paths, copy=True):
+    pj = ctx.parse(doc, ndjson=nd, copy_strings=copy)
+    w = _walk_of(pj)
+    roots = w.records()
+    for path in paths:
+        got = ctx.find_path(*path)
+        want = np.array([w.find_path(r, list(path)) for r in roots], dtype=np.uint64)
+        assert np.array_equal(got, want), (path, nd, copy, got[:5], want[:5])
+    return w, roots
+
+
+def test_find_path_tables_of_the_reference(ctx):
+    # TestObject_FindPath (parsed_object_test.go:10-132) on the device, both copy modes
+    for copy in (True, False):
+        w, (root,) = check_paths(ctx, TQ.FINDPATH_INPUT, False, [tuple(p.encode() for p in path) for path, _ in TQ.FINDPATH_CASES], copy)
+        for path, want in TQ.FINDPATH_CASES:
+            (v,) = ctx.find_path(*[p.encode() for p in path])
+            if want is None:
+                assert v == Q.NOT_FOUND
+            else:
+                assert TQ.value_at(w, int(v)) == want
+        assert ctx.find_path(b"Alt", b"x")[0] == Q.NOT_OBJECT
+        assert ctx.find_path(b"Image", b"IDs", b"0")[0] == Q.NOT_OBJECT
+    # a root that is not an object: "type ... found before object was found"
+    ctx.parse(b"[1,2,3]")
+    assert ctx.find_path(b"a")[0] == Q.NOT_OBJECT
+
+
+def test_project_keys_table_of_the_reference(ctx):
+    # TestObject_ForEach with onlyKeys (parsed_object_test.go:134-240)
+    pj = ctx.parse(TQ.FOREACH_INPUT)
+    w = _walk_of(pj)
+    for keys, want in TQ.FOREACH_CASES:
+        got = ctx.project_keys([k.encode() for k in keys])
+        assert got.shape == (1, len(keys))
+        found = {}
+        for e in got[0]:
+            e = int(e)
+            if e != 0xFFFFFFFFFFFFFFFF:
+                found[keys[e >> 56]] = TQ.value_at(w, e & Q.MASK)
+        assert found == want, keys
+    with pytest.raises(Exception):
+        ctx.project_keys([b"key1", b"key1"])  # a set: equal keys are refused
+
+
+def test_paths_on_records(ctx):
+    """every record of an ND message: nested paths, duplicate keys (the first member wins), type errors, escaped keys"""
+    rnd = random.Random(5)
+    lines = []
+    for i in range(3000):
+        kind = rnd.randrange(8)
+        if kind == 0:
+            lines.append(b'{"a":{"b":{"c":%d}},"x":"y"}' % i)
+        elif kind == 1:
+            lines.append(b'{"a":{"b":[1,2,{"c":3}]},"a":{"b":{"c":7}}}')       # the first "a" wins; its "b" is an array
+        elif kind == 2:
+            lines.append(b'{"a":{"b":{"c":null,"c":5}}}')
+        elif kind == 3:
+            lines.append(b'[{"a":{"b":{"c":1}}}]')                                # the root is an array
+        elif kind == 4:
+            lines.append(b'{"a":"str","k\\u00e9y":{"c":true}}')
+        elif kind == 5:
+            lines.append(b'{"zz":[%s],"a":{"bb":1,"b":{"cc":2,"c":%d.5}}}' % (b",".join(b"{}" for _ in range(rnd.randrange(5))), i))
+        elif kind == 6:
+            lines.append(b'{}')
+        else:
+            lines.append(b'{"a":{"b":{"c":"' + bytes(rnd.choice(b"abc\\n") for _ in range(0)) + b'v%d"}}}' % (i % 7))
+    doc = b"\n".join(lines)
+    paths = [(b"a",), (b"a", b"b"), (b"a", b"b", b"c"), (b"x",), ("kéy".encode(), b"c"), (b"missing",), (b"a", b"b", b"c", b"d")]
+    for copy in (True, False):
+        w, roots = check_paths(ctx, doc, True, paths, copy)
+        # typed comparisons at the end of a path, against the restated Iter conversions
+        for op, val in ((Q.OP_EXISTS, None), (Q.OP_EQ_INT, 5), (Q.OP_EQ_INT, 7), (Q.OP_EQ_UINT, 7), (Q.OP_EQ_FLOAT, 7.0), (Q.OP_EQ_FLOAT, 12.5),
+                        (Q.OP_EQ_STRING, b"v3"), (Q.OP_IS_NULL, None), (Q.OP_EQ_BOOL, True)):
+            for path in ((b"a", b"b", b"c"), ("kéy".encode(), b"c")):
+                want = 0
+                for r in roots:
+                    v = w.find_path(r, list(path))
+                    want += v < Q.NOT_OBJECT and w.element_is(v, op, val)
+                assert ctx.count_where_path(path, op, val) == want, (path, op, val, copy)
+        keys = [b"a", b"x", b"zz"]
+        got = ctx.project_keys(keys)
+        assert got.shape == (len(roots), 3)
+        for r, row in zip(roots, got):
+            want = w.project_keys(r, keys)
+            have = [(int(e) >> 56, int(e) & Q.MASK) for e in row if int(e) != 0xFFFFFFFFFFFFFFFF]
+            assert have == want
+
+
+def test_paths_on_fixtures(ctx):
+    park = fixtures.load("parking-citations")
+    check_paths(ctx, park, True, [(b"Make",), (b"Fine amount",), (b"nope",), (b"Make", b"x")])
+    ctx.parse(park, ndjson=True)
+    assert ctx.count_where_path((b"Make",), ctx.OP_EQ_STRING, b"HOND") == ctx.count_where(b"Make", b"HOND") == 116
+    tw = fixtures.load("twitter")
+    w, (root,) = check_paths(ctx, tw, False, [(b"search_metadata", b"count"), (b"search_metadata", b"max_id_str"), (b"statuses",), (b"statuses", b"0")])
+    (v,) = ctx.find_path(b"search_metadata", b"count")
+    assert TQ.value_at(w, int(v)) == 100
+    assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_INT, 100) == 1
+    assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_FLOAT, 100.0) == 1
+    assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_UINT, 99) == 0
