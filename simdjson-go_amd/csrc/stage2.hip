@@ -908,7 +908,7 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
 __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block);
-__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks);
+__global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks);
 
 // ---- pass 2: exclusive scan over the tile aggregates (in place) + totals: SCAN_SEGS blocks ---------------------
 // Inside a segment every thread owns K consecutive tiles (K <= 32 per round), so a block scans once per round
@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
     }
 }
 
-__global__ __launch_bounds__(RD_BLOCK) void k_measure(S2Dev p, u32 mblocks) {
+__global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
     if (blockIdx.x < mblocks) {
         if (p.copy_strings) str_masks_body<false>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
@@ -1161,10 +1161,15 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     constexpr bool MASKS = MODE != 0;
     constexpr int BLK = S2_TILE / ITEMS, WAVES = BLK / 64;
     __shared__ __attribute__((aligned(16))) u32 s_pos[S2_TILE + 4];
-    // strings [0, S) | the tile's brackets [S, S + B) | atoms and numbers [S + B, S + B + D): a tile has 4096 tokens.
-    // (MASKS: no string queue -- a lane reads the entries of its strings, consecutive ones of soff[] / sinfo[], straight
-    // from memory while the scalars and brackets are queued)
-    __shared__ u32 s_q[S2_TILE];
+    // strings [0, S) | the tile's brackets [SB, SB + B) | atoms and numbers [SB + B, SB + B + D): a tile has 4096 tokens.
+    // MASKS: no string queue -- [0, S] holds the Strings.B offsets of the tile's S strings and of the string behind them
+    // (soff[] / sinfo[].x, left by k_str_emit in message order = token order), SB = S + 1; MODE 2: the raw lengths of the
+    // tile's strings (sinfo[].y) behind everything else, from SC on -- a string is followed by a token that is none, so
+    // 2 S + B + D fits the 4096 + 8 entries in every document that parses; where it does not the lengths are read from
+    // memory.  (A lane reading the entries of its own strings
+    // straight from memory -- nine sparsely populated load instructions per wave -- was measured 3 % / 6 % slower over
+    // the whole parse of configs[1] / configs[4] than this staging with full-width loads.)
+    __shared__ u32 s_q[S2_TILE + 8];
     __shared__ u32 s_edge[BLK + 2];
     __shared__ PAgg s_w[WAVES];
     __shared__ u32 s_wc[WAVES];
@@ -1251,27 +1256,19 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
     const u32 lane_w = ex.x & 0x3fffu, lane_bc = ex.x >> 14, lane_open = ex.y & 0x1fffu, lane_nb = ex.y >> 13;
     bool bad = lane16_illegal(m);  // a token that is legal in no context at all
-    // MASKS: the lane's strings are strings number kb, kb + 1, ... of the message (k_measure counted them through the scan);
-    // their entries -- and the entry behind the last one, whose offset ends it -- are requested now and used behind the barrier
-    u32 sx[ITEMS], sy[ITEMS], s_end = 0;
-    if (MASKS) {
-        const u32 kb = tp.s + (cex & 0x1fffu);
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            sx[j] = sy[j] = 0;
-            const u32 kk = kb + popc32(m.str & ((1u << j) - 1u));
-            if (((m.str >> j) & 1u) && kk < p.soff_cap) {
-                if (MODE == 2) {
-                    const uint2 e = p.sinfo[kk];
-                    sx[j] = e.x;
-                    sy[j] = e.y;
-                } else {
-                    sx[j] = p.soff[kk];
-                }
+    const u32 SB = MASKS ? S + 1u : S, SC = SB + B + D;
+    const bool y_staged = SC + S <= (u32)S2_TILE + 8u;  // (block-uniform)
+    if (MASKS) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
+        for (u32 j = (u32)tid; j <= S; j += BLK) {
+            const bool in = tp.s + j < p.soff_cap;
+            if (MODE == 2) {
+                const uint2 e = in ? p.sinfo[tp.s + j] : make_uint2(0u, 0u);
+                s_q[j] = e.x;
+                if (y_staged && j < S) s_q[SC + j] = e.y;
+            } else {
+                s_q[j] = in ? p.soff[tp.s + j] : 0u;
             }
         }
-        const u32 ke = kb + popc32(m.str);
-        if (m.str != 0 && ke < p.soff_cap) s_end = MODE == 2 ? p.sinfo[ke].x : p.soff[ke];
     }
     if (!MASKS) {
         u32 slot = cex & 0x1fffu, run = ex.s;
@@ -1287,7 +1284,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     {
-        u32 slot = S + B + (cex >> 13);
+        u32 slot = SB + B + (cex >> 13);
         for (u32 r = m.num | m.atom; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), idx = (u32)tid * ITEMS + j;
             const u32 kd = ((m.num >> j) & 1u) ? (u32)K_NUM : (u32)lane16_atom_kind(m, j);
@@ -1295,7 +1292,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     {
-        u32 slot = S + lane_bc;
+        u32 slot = SB + lane_bc;
         const u32 am_in = am_combine(tp.am, ex.z);
         for (u32 r = m.br; r != 0; r &= r - 1) {
             const u32 j = (u32)__builtin_ctz(r), upto = (2u << j) - 1u;
@@ -1313,24 +1310,14 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     // of length 0 there is not copied (it holds no escape: every escape emits a byte) -- the tape points into the message
     // and the length is the raw length of its content (stage2_build_tape_amd64.go:90-109)
     if (MASKS) {
-        u32 nextx = s_end;
-        u32 at[ITEMS];  // MODE 2: the positions of the lane's tokens, back from LDS in one go
-        if (MODE == 2 && m.str != 0) {
-#pragma unroll
-            for (int q = 0; q < ITEMS / 4; q++) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(&s_pos[tid * ITEMS + 4 * q]);
-                at[4 * q] = a.x; at[4 * q + 1] = a.y; at[4 * q + 2] = a.z; at[4 * q + 3] = a.w;
-            }
-        }
-#pragma unroll
-        for (int j = ITEMS - 1; j >= 0; j--) {
-            if (!((m.str >> j) & 1u)) continue;
-            const u32 so = sx[j], se = nextx, lo = lane_w + lane16_words_before(m, (u32)j);
-            nextx = so;
+        u32 ks = cex & 0x1fffu;
+        for (u32 r = m.str; r != 0; r &= r - 1, ks++) {
+            const u32 j = (u32)__builtin_ctz(r), lo = lane_w + lane16_words_before(m, j);
+            const u32 so = s_q[ks], se = s_q[ks + 1];
             u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
             if (MODE == 2 && se == so) {
-                w0 = string_word(false, 0, p.msg_base + at[j] + 1);
-                w1 = (u64)sy[j];
+                w0 = string_word(false, 0, p.msg_base + s_pos[(u32)tid * ITEMS + j] + 1);
+                w1 = (u64)(y_staged ? s_q[SC + ks] : (tp.s + ks < p.soff_cap ? p.sinfo[tp.s + ks].y : 0u));
             }
             *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
             if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((m.keystr >> j) & 1u);
@@ -1362,7 +1349,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         if (cnt != 0) __syncthreads();  // (block-uniform)
         const u32 qb = s_base;
         for (u32 j = (u32)tid; j < D; j += BLK) {
-            const u32 v = s_q[S + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+            const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
             const u8 ak = (u8)(8u + ((v >> 26) & 3u));
             if (ak == K_NUM) {
                 u64 iv = 0;
@@ -1386,7 +1373,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         const u32 G = (B + 63u) / 64u;
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // the minimum depth of every group of 64
             const u32 c = g * 64u + (u32)lane;
-            i32 v = c < B ? tbr_depth(s_q[S + c]) : 0x7fffffff;
+            i32 v = c < B ? tbr_depth(s_q[SB + c]) : 0x7fffffff;
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) {
                 const i32 o = __shfl_xor(v, sft, 64);
@@ -1399,7 +1386,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // wave-uniform
             const u32 c = g * 64u + (u32)lane;
             const bool valid = c < B;
-            const u32 e = valid ? s_q[S + c] : 0u;
+            const u32 e = valid ? s_q[SB + c] : 0u;
             const i32 drel = valid ? tbr_depth(e) : 0x7fffffff;
             const u8 kd = tbr_kind(e);
             const u32 gap = tbr_gap(e), oc = T0 + tbr_off(e);
@@ -1433,7 +1420,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 while (cand != 0 && pm != 0) {
                     const u32 gp = (u32)top_bit(cand);
                     cand &= ~(1ull << gp);
-                    const i32 dprev = tbr_depth(s_q[S + gp * 64u + (u32)lane]);  // (a group in front is full)
+                    const i32 dprev = tbr_depth(s_q[SB + gp * 64u + (u32)lane]);  // (a group in front is full)
                     for (u64 pp = pm; pp != 0;) {
                         const i32 v = __builtin_amdgcn_readlane(q, __builtin_ctzll(pp));
                         const u64 at = __ballot(dprev <= v);
@@ -1453,7 +1440,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 bad |= !context_allowed(gap, CTX_ROOT);
                 done = true;
             } else if (res >= 0) {
-                const u32 ej = s_q[S + (u32)res + 1u];  // partner (close) / parent (open)
+                const u32 ej = s_q[SB + (u32)res + 1u];  // partner (close) / parent (open)
                 const u8 jk = tbr_kind(ej);
                 bad |= !context_allowed(gap, jk == K_OPEN_OBJ ? (u8)CTX_OBJ : (u8)CTX_ARR);
                 done = true;
