@@ -16,13 +16,16 @@ def short(name):
 
 
 def main(summary, out_k, out_p):
-    kern = {v: {} for v in NAMES.values()}
-    pmc = {v: {} for v in NAMES.values()}
+    keys = list(NAMES.values()) + [v + "_nocopy" for v in NAMES.values()]
+    kern = {v: {} for v in keys}
+    pmc = {v: {} for v in keys}
     sect, wl = "", None
     for line in open(summary):
         if line.startswith("=="):
             sect = line
             wl = next((v for k, v in NAMES.items() if f"_{k}" in line), None)
+            if wl and "nocopy" in line:  # (WithCopyStrings(false): its own table)
+                wl += "_nocopy"
             continue
         if wl is None:
             continue
@@ -32,7 +35,10 @@ def main(summary, out_k, out_p):
         m = re.match(r"\s+pmc (.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=(\d+) mean=([\d.]+)", line)
         if m:
             pmc[wl].setdefault(short(m.group(1)), {})[m.group(2) + "_KB"] = float(m.group(4))
-    for wl in kern:
+    for wl in list(kern):
+        if not kern[wl] and not pmc[wl]:
+            del kern[wl], pmc[wl]
+            continue
         per_parse = {}
         calls = [v["calls"] for v in kern[wl].values()]
         parses = max(1, min(c for c in calls if c > 0)) if calls else 1
@@ -43,7 +49,7 @@ def main(summary, out_k, out_p):
         for k, v in pmc[wl].items():
             if "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
                 v["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024)
-    kern["source"] = "rocprofv3 --kernel-trace --stats -- python tools/parse_loop.py <workload> (tools/profile_r4.sh)"
+    kern["source"] = "rocprofv3 --kernel-trace --stats -- python tools/parse_loop.py <workload> (tools/profile_r5.sh)"
     pmc["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2"
     json.dump(kern, open(out_k, "w"), indent=1)
     json.dump(pmc, open(out_p, "w"), indent=1)
