@@ -17,6 +17,7 @@
 #include "../../include/sjhip.h"
 #include "sj_ctx.h"
 #include "sj_device.h"
+#include "sj_bounds.h"
 #include "sj_stage2.h"
 
 using namespace sj;
@@ -33,13 +34,17 @@ static constexpr u64 PAYLOAD = 0x00ffffffffffffffull;  // JSONVALUEMASK, parsed_
 static constexpr u32 NONE32 = 0xffffffffu;
 static constexpr int QMAX = 1024;  // longest key / value a query may name (they travel as kernel arguments)
 
+// (Arr: sj_bounds.h -- a plain pointer in the product build; in the debug build (-DSJ_DEBUG_BOUNDS) every index that comes out
+// of a tape word -- the end of a container, the offset and length of a string -- is checked against the array it is used on,
+// and a violation fails the query instead of reading outside the arenas)
 struct QView {
-    const u64 *tape;
+    Arr<const u64> tape;
     u64 tape_len;
-    const u8 *strings;
+    Arr<const u8> strings;
     u64 strings_len;
-    const u8 *msg;     // device copy of the message (strings that were not copied point into it)
-    const u32 *nl_off; // tape offset of the close root of record r (r < R)
+    Arr<const u8> msg; // device copy of the message (strings that were not copied point into it)
+    u64 msg_len;
+    Arr<const u32> nl_off; // tape offset of the close root of record r (r < R)
     u32 R;             // record-separating newline runs: R + 1 records
     u8 key[QMAX], val[QMAX];
     u32 klen, vlen;
@@ -48,13 +53,13 @@ struct QView {
 __device__ __forceinline__ u32 rec_open(const QView &q, u32 r) { return r == 0 ? 0u : q.nl_off[r - 1] + 1u; }
 __device__ __forceinline__ u32 rec_close(const QView &q, u32 r) { return r == q.R ? (u32)q.tape_len - 1u : q.nl_off[r]; }
 
-__device__ __forceinline__ const u8 *str_bytes(const QView &q, u64 word) {
+__device__ __forceinline__ const u8 *str_bytes(const QView &q, u64 word, u64 len) {
     const u64 p = word & PAYLOAD;
-    return (p & STRINGBUFBIT) ? q.strings + (p & (STRINGBUFBIT - 1)) : q.msg + p;
+    return (p & STRINGBUFBIT) ? arr_at(q.strings, p & (STRINGBUFBIT - 1), len) : arr_at(q.msg, p, len);
 }
 __device__ __forceinline__ bool str_equals(const QView &q, u64 word, u64 len, const u8 *want, u32 wlen) {
     if (len != wlen) return false;
-    const u8 *s = str_bytes(q, word);
+    const u8 *s = str_bytes(q, word, len);
     for (u32 k = 0; k < wlen; k++)
         if (s[k] != want[k]) return false;
     return true;
@@ -504,6 +509,24 @@ namespace sj {
 void stage2_records_view(void *ws, size_t n_tokens, const uint32_t **nl_off);
 }
 
+// debug build (-DSJ_DEBUG_BOUNDS): an out-of-bounds access of a query kernel fails the call (this translation unit's record)
+static int query_bounds_check(sjhip_ctx *ctx) {
+#if defined(SJ_DEBUG_BOUNDS)
+    BoundsHit h = {};
+    if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_bounds_hit), sizeof h) != hipSuccess) return SJHIP_OK;
+    if (h.hits) {
+        const BoundsHit zero = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_hit), &zero, sizeof zero);
+        ctx_set_error(ctx, "bounds check (query): %u out-of-bounds accesses, the first to array %u (sj_bounds.h ArrId) at element %llu of %llu",
+                      h.hits, h.id, h.index, h.size);
+        return SJHIP_ERR_HIP;
+    }
+#else
+    (void)ctx;
+#endif
+    return SJHIP_OK;
+}
+
 static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q,
                      uint32_t *records) {
     if (!ctx || !key || !val) return SJHIP_ERR_ARG;
@@ -517,12 +540,13 @@ static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint
     }
     const uint32_t *nl = nullptr;
     stage2_records_view(ctx->d_s2.p, ctx->p_nlay, &nl);
-    q->tape = (const u64 *)ctx->d_tape.p;
+    q->tape = SJ_ARR((const u64 *)ctx->d_tape.p, ctx->tape_len, A_TAPE);
     q->tape_len = ctx->tape_len;
-    q->strings = (const u8 *)ctx->d_strings.p;
+    q->strings = SJ_ARR((const u8 *)ctx->d_strings.p, ctx->strings_len, A_STRINGS);
     q->strings_len = ctx->strings_len;
-    q->msg = (const u8 *)ctx->p_msg;
-    q->nl_off = nl;
+    q->msg = SJ_ARR((const u8 *)ctx->p_msg, ctx->p_len, A_MSG);
+    q->msg_len = ctx->p_len;
+    q->nl_off = SJ_ARR(nl, ctx->q_records, A_NL_OFF);
     q->R = ctx->q_records;
     memset(q->key, 0, QMAX);
     memset(q->val, 0, QMAX);
@@ -550,7 +574,7 @@ int sjhip_count_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uin
     HIPCHK(hipMemcpyAsync(h, ctx->d_kat.p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H count");
     HIPCHK(hipStreamSynchronize(ctx->stream), "count sync");
     *count = *h;
-    return SJHIP_OK;
+    return query_bounds_check(ctx);
 }
 
 int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen,
@@ -613,7 +637,7 @@ int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const ui
     if (n_records) *n_records = h[0];
     if (tape_len) *tape_len = ctx->q_tape_len;
     if (strings_len) *strings_len = ctx->q_strings_len;
-    if (h[0] == 0) return SJHIP_OK;
+    if (h[0] == 0) return query_bounds_check(ctx);
     hipLaunchKernelGGL(k_q_copy, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, q, o, (u64 *)ctx->d_qtape.p, (u8 *)ctx->d_qstrings.p,
                        (u32)h[1]);
     HIPCHK(hipGetLastError(), "filter copy launch");
@@ -633,7 +657,7 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
         HIPCHK(hipMemcpyAsync(strings_dst, ctx->d_qstrings.p, ctx->q_strings_len, hipMemcpyDeviceToHost, ctx->stream),
                "D2H filtered strings");
     HIPCHK(hipStreamSynchronize(ctx->stream), "fetch sync");
-    return SJHIP_OK;
+    return query_bounds_check(ctx);  // (debug build: the copy kernel of sjhip_filter_where has finished here)
 }
 
 // ---- paths, typed values, key sets ------------------------------------------------------------------------------------------
@@ -679,7 +703,7 @@ int sjhip_find_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_len
     HIPCHK(hipGetLastError(), "find_path launch");
     HIPCHK(hipMemcpyAsync(index_out, ctx->d_kat.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H path indexes");
     HIPCHK(hipStreamSynchronize(ctx->stream), "find_path sync");
-    return SJHIP_OK;
+    return query_bounds_check(ctx);
 }
 
 int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, int op,
@@ -711,7 +735,7 @@ int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *
     HIPCHK(hipMemcpyAsync(h, ctx->d_kat.p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H count");
     HIPCHK(hipStreamSynchronize(ctx->stream), "count sync");
     *count = *h;
-    return SJHIP_OK;
+    return query_bounds_check(ctx);
 }
 
 int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *out,
@@ -743,5 +767,5 @@ int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_
     HIPCHK(hipGetLastError(), "project_keys launch");
     HIPCHK(hipMemcpyAsync(out, ctx->d_kat.p, bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H projected members");
     HIPCHK(hipStreamSynchronize(ctx->stream), "project_keys sync");
-    return SJHIP_OK;
+    return query_bounds_check(ctx);
 }

@@ -2,7 +2,7 @@
 path behind a checked view, a violation fails the parse.  CPU: the product build says it is not a debug build and the
 parse kernels compile under the flag.  GPU: the debug library's self-test records its two deliberate violations, and
 documents of every kind parse to the oracle's result with no violation (tools/gpu_debug_bounds.sh runs the whole GPU
-suite on that build; profiles/r04_debug_bounds.txt keeps the run)."""
+suite on that build; profiles/r05_debug_bounds.txt keeps the run).  Round 5: the views of query.hip are checked as well."""
 import os
 import subprocess
 import sys
@@ -59,3 +59,43 @@ print("OK")
     env = dict(os.environ, SJHIP_LIB=lib)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith(b"OK"), (out.stdout[-2000:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_queries_run_clean_on_the_debug_build():
+    """query.hip's kernels chase indexes that come out of tape words (the end of a container, the offset and length of a
+    string); in the debug build their views are checked (sj_bounds.h) and a violation fails the call.  The queries of the
+    suite on fixtures and generated records, in both copy modes, in their own interpreter on libsjhip_dbg.so."""
+    import __graft_entry__ as G
+    lib = G.build_lib(debug_bounds=True)
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import fixtures, sjhip, query_walk as Q
+assert sjhip.lib().sjhip_debug_bounds_selftest() == 2
+ctx = sjhip.Context(0)
+park = fixtures.load('parking-citations')
+for copy in (True, False):
+    pj = ctx.parse(park * 3, ndjson=True, copy_strings=copy)
+    w = Q.Walk(pj.Tape, pj.Strings, pj.Message)
+    roots = w.records()
+    assert ctx.count_where(b'Make', b'HOND') == 348
+    for path in ((b'Make',), (b'Fine amount',), (b'Make', b'x'), (b'nope',)):
+        got = ctx.find_path(*path)
+        want = np.array([w.find_path(r, list(path)) for r in roots], dtype=np.uint64)
+        assert np.array_equal(got, want), path
+    assert ctx.count_where_path((b'Fine amount',), ctx.OP_EXISTS) == sum(w.find_path(r, [b'Fine amount']) < Q.NOT_OBJECT for r in roots)
+    got = ctx.project_keys([b'Color', b'Make'])
+    assert got.shape == (len(roots), 2)
+    if copy:
+        n, sub = ctx.filter_where(b'Make', b'HOND')
+        assert n == 348
+tw = fixtures.load('twitter')
+ctx.parse(tw)
+assert ctx.count_where_path((b'search_metadata', b'count'), ctx.OP_EQ_INT, 100) == 1
+print('ok')
+""" % (PKG, HERE)
+    env = dict(os.environ, SJHIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith(b"ok"), (out.stdout[-2000:], out.stderr[-3000:])
