@@ -31,7 +31,7 @@ struct StrView {
     Arr<const u8> base;  // 64-byte aligned base of the message (Arr: sj_bounds.h, a plain pointer in the product build)
     u64 lead, end;   // the message occupies [lead, end) of it
     Arr<const u64> qm, q, st;
-    Arr<const u8> unit_h;  // per unit: bit 0 = state at its start (1: inside a string), bit 1 = it holds an escape starter
+    Arr<const u8> unit_h;  // per unit: bit 0 = state at its start (1: inside a string), bit 1 = it holds an escape starter, bit 2 = an unescaped quote
     Arr<const u64> unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
     // the 16 bytes at a .. a+15 as two little-endian words (two unaligned 8-byte loads away from the message ends)

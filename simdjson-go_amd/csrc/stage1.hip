@@ -331,6 +331,7 @@ __device__ __forceinline__ int lookback_eval(const u64 (&d)[4], LookBack &lb, in
 // priority through the whole phase (wave 0 of the barrier kernels: it has the look-back to resolve afterwards).
 // s_unit[u] = parity << 31 | ctrl-in-string(inside) << 27 | ctrl-in-string(outside) << 26 |
 //             count(inside) << 13 | count(outside)          for unit u = pass * WAVES + wave.
+__device__ __forceinline__ bool par_ballot_any(u64 m) { return __ballot(((u32)m | (u32)(m >> 32)) != 0) != 0; }
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
@@ -467,9 +468,11 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         const u32 tot = lane63(incl);
         // (whole parse, bit 28: the unit holds an escape starter -- k_str_emit does not read the st masks of the others)
         const u32 has_st = AUX && __ballot(((u32)starters | (u32)(starters >> 32)) != 0) != 0 ? 1u : 0u;
+        // (bit 29: the unit holds an unescaped quote -- the walks of the selective copy pass over units without one 64 at a time)
+        const u32 has_q = AUX && par_ballot_any(quote_bits) ? 1u : 0u;
         if (lane == 0)
             s_unit[k * WAVES + wave] =
-                (((u32)popc64(par_ballot) & 1u) << 31) | (has_st << 28) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
+                (((u32)popc64(par_ballot) & 1u) << 31) | (has_q << 29) | (has_st << 28) | (bad << 26) | ((tot >> 16) << 13) | (tot & 0x1fffu);
     }
 }
 
@@ -529,8 +532,8 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         upto[k] = h ? both >> 16 : both & 0xffffu;
         const u64 un = tile_unit<UNITS>(tm, t, k * WAVES + wave);
         if (unit_h && lane == 0 && un * 4096 < lead + len_) {  // (a void unit lies behind everything)
-            // bit 0: the state at the start of the unit; bit 1: the unit holds an escape starter
-            unit_h[un] = (u8)(h | (((s_unit[k * WAVES + wave] >> 28) & 1u) << 1));
+            // bit 0: the state at the start of the unit; bit 1: the unit holds an escape starter; bit 2: it holds an unescaped quote
+            unit_h[un] = (u8)(h | (((s_unit[k * WAVES + wave] >> 28) & 3u) << 1));
             if (KIND && aux.unit_str) {  // whole parse: the unit's counts under the state that is now known
                 const uint2 c = s_ucnt[k * WAVES + wave];
                 aux.unit_cnt[un] = h ? (c.x >> 16) - (c.x & 0xffffu) : c.x & 0xffffu;

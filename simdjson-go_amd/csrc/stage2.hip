@@ -163,58 +163,82 @@ __device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, i
 // ---- WithCopyStrings(false): which strings are copied, decided 64 bytes at a time (sj_strings.h chunk_sel) ---------------
 // The state at a unit's ends: does the string that is open at the start of unit u hold an escape starter in FRONT of the
 // unit (the starters behind the last quote of the nearest unit in front that holds a quote, and all starters of the units
-// in between), does the one open at its end hold one BEHIND it.  One unit per step, the whole wave; strings longer than
-// SEL_WALK_CAP units give the document to the per-string path (S2_ERR_SERIAL_STRINGS, like a surrogate run that is too long).
-static constexpr u32 SEL_WALK_CAP = 64;
+// in between), does the one open at its end hold one BEHIND it.  The whole wave walks; a string that stays open for more
+// than SEL_WALK_CAP steps gives the document to the per-string path (S2_ERR_SERIAL_STRINGS, like a surrogate run that is too long).
+static constexpr u32 SEL_WALK_CAP = 64;  // steps of 64 units: strings of up to 16 MiB
+// Units without a quote lie wholly inside the open string: the walk passes over them 64 at a time on the unit flags stage 1
+// leaves (unit_h: bit 1 "holds an escape starter", bit 2 "holds an unescaped quote"), and looks only at the masks of the
+// one unit that holds the quote it is after.
 __device__ __forceinline__ u32 sel_unit_in(const S2Dev &p, u64 u, int lane, bool &giveup) {
     u32 acc = 0;
     for (u32 step = 0; u > 0; step++) {
-        u--;
         if (step >= SEL_WALK_CAP) {
             giveup = true;
-            break;
+            return acc;
         }
-        const u64 c = u * 64 + lane;
+        // lane l looks at unit u - 1 - l
+        const bool have = (u64)lane < u;
+        const u32 f = have ? (u32)p.sv.unit_h[u - 1 - (u64)lane] : 0u;
+        const u64 qb = __ballot(have && (f & 4u)), sb = __ballot(have && (f & 2u));
+        if (qb == 0) {  // 64 more units (or all that are left) inside the string
+            acc |= sb != 0 ? 1u : 0u;
+            if (u <= 64) break;
+            u -= 64;
+            continue;
+        }
+        const int near = __builtin_ctzll(qb);  // the nearest unit in front with a quote; the ones in between hold none
+        acc |= (sb & ((1ull << near) - 1ull)) != 0 ? 1u : 0u;
+        const u64 v = u - 1 - (u64)near;
+        const u64 c = v * 64 + lane;
         const u64 q = p.sv.q[c];
-        const u64 st = (p.sv.unit_h[u] & 2u) ? p.sv.st[c] : 0ull;
-        const u64 qb = __ballot(q != 0);
-        if (qb != 0) {
-            const int L = 63 - __builtin_clzll(qb);  // the last chunk with a quote; behind its last quote the string is open
+        const u64 st = (sb >> near) & 1ull ? p.sv.st[c] : 0ull;
+        const u64 qc = __ballot(q != 0);
+        if (qc != 0) {  // (always: the flag says so)
+            const int L = 63 - __builtin_clzll(qc);  // the last chunk with a quote; behind its last quote the string is open
             bool m = lane > L && st != 0;
             if (lane == L) {
                 const int hb = 63 - clz64(q);
                 m = hb < 63 && (st >> (hb + 1)) != 0;
             }
             acc |= __ballot(m) != 0 ? 1u : 0u;
-            break;
         }
-        acc |= __ballot(st != 0) != 0 ? 1u : 0u;
+        break;
     }
     return acc;
 }
 // (*tq: the aligned offset of that string's closing quote -- the first quote behind the unit)
 __device__ __forceinline__ u32 sel_unit_out(const S2Dev &p, u64 u, int lane, bool &giveup, u32 *tq) {
     u32 acc = 0;
-    for (u32 step = 0; u + 1 < p.units; step++) {
-        u++;
+    u64 w = u + 1;  // the first unit behind
+    for (u32 step = 0; w < p.units; step++) {
         if (step >= SEL_WALK_CAP) {
             giveup = true;
-            break;
+            return acc;
         }
-        const u64 c = u * 64 + lane;
+        const bool have = w + (u64)lane < p.units;  // lane l looks at unit w + l
+        const u32 f = have ? (u32)p.sv.unit_h[w + (u64)lane] : 0u;
+        const u64 qb = __ballot(have && (f & 4u)), sb = __ballot(have && (f & 2u));
+        if (qb == 0) {
+            acc |= sb != 0 ? 1u : 0u;
+            w += 64;
+            continue;
+        }
+        const int near = __builtin_ctzll(qb);
+        acc |= (sb & ((1ull << near) - 1ull)) != 0 ? 1u : 0u;
+        const u64 v = w + (u64)near;
+        const u64 c = v * 64 + lane;
         const u64 q = p.sv.q[c];
-        const u64 st = (p.sv.unit_h[u] & 2u) ? p.sv.st[c] : 0ull;
-        const u64 qb = __ballot(q != 0);
-        if (qb != 0) {
-            const int L = __builtin_ctzll(qb);  // the first chunk with a quote: the closing quote of the open string
+        const u64 st = (sb >> near) & 1ull ? p.sv.st[c] : 0ull;
+        const u64 qc = __ballot(q != 0);
+        if (qc != 0) {
+            const int L = __builtin_ctzll(qc);  // the first chunk with a quote: the closing quote of the open string
             bool m = lane < L && st != 0;
             const int lb = q ? ctz64(q) : 0;
             if (lane == L) m = lb > 0 && (st & ((1ull << lb) - 1ull)) != 0;
-            *tq = (u32)((u * 64 + (u64)L) * 64) + (u32)__builtin_amdgcn_readlane(lb, L);
+            *tq = (u32)((v * 64 + (u64)L) * 64) + (u32)__builtin_amdgcn_readlane(lb, L);
             acc |= __ballot(m) != 0 ? 1u : 0u;
-            break;
         }
-        acc |= __ballot(st != 0) != 0 ? 1u : 0u;
+        break;
     }
     return acc;
 }

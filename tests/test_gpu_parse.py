@@ -778,3 +778,19 @@ def test_units_without_tokens(ctx):
         n = rnd.choice([0, 4200, 8300, 12345])
         lines.append('{%s%s"s":"%s"%s}' % (filler, "," if filler else "", "y" * n, " " * rnd.choice([0, 4100, 9000])))
     check(ctx, "\n".join(lines).encode(), True, "nd long strings")
+
+
+def test_very_long_strings_without_copy(ctx):
+    """WithCopyStrings(false) decides per string whether it is copied; for a string that runs over many 4 KiB units the units'
+    ends are resolved by walking to the unit that holds its quote -- 64 quote-free units per step on the unit flags of stage 1,
+    at most 64 steps (16 MiB), beyond which the document takes the per-string path.  Strings of 300 KB, 3 MB and 17 MB whose
+    only escape lies at the very beginning, the very end, or nowhere; both copy modes."""
+    for n in (300_000, 3_000_000, 17_000_000):
+        for where in ("none", "front", "back"):
+            body = b"z" * n
+            if where == "front":
+                body = b"\\n" + body
+            elif where == "back":
+                body = body + b"\\t"
+            doc = b'{"a":"short","big":"' + body + b'","b":[1,"x\\\\y",true],"c":"' + b"q" * 5000 + b'"}'
+            check(ctx, doc, False, "long string %d %s" % (n, where))
