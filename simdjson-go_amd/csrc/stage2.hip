@@ -1198,14 +1198,12 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     __shared__ PAgg s_w[WAVES];
     __shared__ u32 s_wc[WAVES];
     __shared__ i32 s_gmin[S2_TILE / 64];
-    __shared__ u32 s_nnum, s_base, s_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
     const u32 t0 = blockIdx.x * S2_TILE;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    if (tid == 0) s_nnum = s_fill = 0;
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
     const u32 endpos = (u32)p.len;
     {
@@ -1271,10 +1269,6 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
             cex += w < wave ? x : 0u;
             ctot += x;
         }
-    }
-    {  // numbers of the tile (their slots in the global queue are drawn with one atomic per tile)
-        const u32 nn = wave_incl_sum(popc32(m.num));
-        if (lane == 63 && nn) atomicAdd(&s_nnum, nn);
     }
     const u32 S = ctot & 0x1fffu, D = ctot >> 13, B = total.x >> 14;
     const u32 T0 = tp.w + 1u;  // tape offset of the tile's first word (word 0 is the opening root, write_tape(0,'r'), :172)
@@ -1366,27 +1360,32 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         }
     }
     // ---- atoms: validated from the 8 message bytes at the token; numbers: a plain integer of up to 18 digits is parsed
-    // here (sj_number.h parse_int_fast), the others move to the global queue (k_numbers; the order does not matter)
-    {
-        const u32 cnt = s_nnum;
-        if (cnt != 0 && tid == 0) s_base = atomicAdd(&p.st->num_count, cnt);
-        if (cnt != 0) __syncthreads();  // (block-uniform)
-        const u32 qb = s_base;
-        for (u32 j = (u32)tid; j < D; j += BLK) {
-            const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
-            const u8 ak = (u8)(8u + ((v >> 26) & 3u));
-            if (ak == K_NUM) {
-                u64 iv = 0;
-                const bool fast = parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
-                if (fast) {
-                    const u64 tw = (u64)'l' << 56;
-                    *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
-                }
-                p.numq[qb + atomicAdd(&s_fill, 1u)] = make_uint2(fast ? 0xffffffffu : at, o);
-            } else {
-                bad |= !atom_valid_word(load8_guarded(mv, at), p.len - at, ak);
-                p.tape[o] = atom_word(ak);
+    // here (sj_number.h parse_int_fast); only the others -- floats, long integers -- move to the global queue (k_numbers; the
+    // order does not matter): a wave draws the slots of its queued numbers with one atomic (round 4 queued every number and
+    // marked the parsed ones: 10 MB of entries on configs[1] that k_numbers read only to skip them)
+    for (u32 j = (u32)tid; j < D; j += BLK) {
+        const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+        const u8 ak = (u8)(8u + ((v >> 26) & 3u));
+        bool slow = false;
+        if (ak == K_NUM) {
+            u64 iv = 0;
+            const bool fast = parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
+            if (fast) {
+                const u64 tw = (u64)'l' << 56;
+                *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
             }
+            slow = !fast;
+        } else {
+            bad |= !atom_valid_word(load8_guarded(mv, at), p.len - at, ak);
+            p.tape[o] = atom_word(ak);
+        }
+        const u64 mq = __ballot(slow);  // (the lanes still in the loop)
+        if (mq != 0) {
+            const int leader = __builtin_ctzll(mq);
+            u32 qb = 0;
+            if (lane == leader) qb = atomicAdd(&p.st->num_count, (u32)__popcll(mq));
+            qb = (u32)__shfl((int)qb, leader, 64);
+            if (slow) p.numq[qb + (u32)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(at, o);
         }
     }
     // ---- brackets: matched inside the tile (sj_stage2.h bracket_resolve is the per-bracket statement, k_br_match the
@@ -1548,7 +1547,6 @@ __device__ __forceinline__ void numbers_body(const S2Dev &p, u32 bid, u32 nblock
     for (u32 j = bid * 256 + threadIdx.x; j < cnt; j += nblocks * 256) {
         const uint2 q = p.numq[j];
         const u32 at = q.x;
-        if (at == 0xffffffffu) continue;  // an integer k_s2_emit has parsed itself
         const u64 rest = p.len - at;
         u32 *w = s_nb[threadIdx.x];
         if (rest >= 32) {
