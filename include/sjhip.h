@@ -44,7 +44,8 @@ typedef struct sjhip_ctx sjhip_ctx;
 #define SJHIP_ERR_STAGE1 1  /* "Failed to find all structural indices for stage 1" parse_json_amd64.go:93 */
 #define SJHIP_ERR_STAGE2 2  /* "Bad parsing while executing stage 2"               parse_json_amd64.go:81 */
 #define SJHIP_ERR_NODEVICE 3 /* "Host CPU does not meet target specs" analogue     simdjson_amd64.go:43  */
-#define SJHIP_ERR_TOOBIG 4  /* message longer than 4 GiB - 64 (positions are uint32 like the reference's index stream) */
+#define SJHIP_ERR_TOOBIG 4  /* plain stage 1: message longer than 4 GiB - 64 (it hands out uint32 positions); whole parse: more than
+                             * 2^32 tokens / tape words / bytes of Strings.B, tokens 4 GiB apart, or a message beyond 256 GiB */
 #define SJHIP_ERR_ARG 5
 #define SJHIP_STREAM_FULL 6  /* sjhip_stream_acquire: every slot holds a block: take a result first */
 #define SJHIP_STREAM_EMPTY 7 /* sjhip_stream_next: nothing submitted is outstanding */

@@ -210,7 +210,8 @@ static void invalidate_result(sjhip_ctx *ctx) {
 // would hand positions to other streams before they are visible there.)
 int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                        uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
-    if (len >= 0xffffffc0ull) {
+    // (plain stage 1 hands out 32-bit positions: up to 4 GiB - 64; the whole parse -- str_aux -- lets them wrap, parse_api.hip)
+    if (len >= 0xffffffc0ull && !str_aux) {
         ctx_set_error(ctx, "message too long for uint32 positions");
         return SJHIP_ERR_TOOBIG;
     }

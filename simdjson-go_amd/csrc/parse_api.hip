@@ -59,11 +59,15 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     return a;
 }
 
-// One context parses messages of up to 4 GiB - 64 bytes (uint32 positions).  A longer ND message is cut into shards of
-// SJHIP_ND_SHARD_BYTES (default 1 GiB) at record boundaries -- SJHIP_ND_LIMIT_BYTES moves the threshold (tests: the
-// sharded path on documents of a few megabytes).  A single document beyond the limit is SJHIP_ERR_TOOBIG: it does not
-// shard, and the reference's own tape could hold it only because its index stream is deltas.
+// An ND message of more than 4 GiB - 128 bytes is cut into shards of SJHIP_ND_SHARD_BYTES (default 1 GiB) at record boundaries --
+// SJHIP_ND_LIMIT_BYTES moves the threshold (tests: the sharded path on documents of a few megabytes).  A single document does
+// not shard; since round 5 it may be longer than 4 GiB all the same (the reference's index stream is deltas for exactly that,
+// README.md:567-569): the 32-bit positions of stage 1 wrap, and every 4096-token tile of the token kernels rebuilds its true
+// offsets from the unit its first token lies in (stage2.hip k_s2_emit_planes).  What stays 32 bits wide: the number of tokens,
+// the tape length in words, the length of Strings.B, the distance between two neighbouring tokens -- a document beyond one of
+// those is SJHIP_ERR_TOOBIG / a failed parse, as is a document beyond SINGLE_LIMIT.
 static constexpr size_t ND_LIMIT = 0xffffffc0ull - 64;
+static constexpr size_t SINGLE_LIMIT = (size_t)1 << 38;  // 256 GiB: the positions' workspace alone is 5 bytes per message byte
 static size_t env_bytes(const char *name, size_t dflt) {
     const char *e = getenv(name);
     const size_t v = e ? (size_t)strtoull(e, nullptr, 0) : 0;
@@ -90,8 +94,8 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->ms_valid = 0;
     ctx->f_valid = 0;
     if (len == 0) return SJHIP_ERR_STAGE1;  // indexTotal == 0 (stage1_find_marks_amd64.go:147)
-    if (len > ND_LIMIT) {  // (an ND message of this size went to parse_nd_big; a single document does not shard)
-        ctx_set_error(ctx, "document of %zu bytes: one context parses up to 4 GiB - 128 (uint32 positions); only ND messages are sharded", len);
+    if (len > SINGLE_LIMIT) {  // (an ND message beyond 4 GiB went to parse_nd_big)
+        ctx_set_error(ctx, "document of %zu bytes: one context parses up to %zu", len, SINGLE_LIMIT);
         return SJHIP_ERR_TOOBIG;
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
@@ -163,6 +167,10 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
         if (hs->err & S2_ERR_SERIAL_STRINGS) {  // pathological surrogate run: measure again with the per-string walks
+            if (len > ND_LIMIT) {
+                ctx_set_error(ctx, "the per-string path (a surrogate run or a string beyond the byte-parallel path) works on documents of up to 4 GiB");
+                return SJHIP_ERR_TOOBIG;
+            }
             ctx->p_aux = nullptr;
             HIPCHK(hipMemsetAsync(ctx->d_s2z.p, 0, stage2_zero_bytes(), ctx->stream), "stage2 state reset");
             HIPCHK(stage2_launch_measure(s2_args(ctx, 0, 0, 0)), "stage2 launch (measure, per-string)");
@@ -236,6 +244,10 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     if ((hs->err & S2_ERR_SERIAL_STRINGS) && ctx->p_aux) {
         // a run of > SURROGATE_WALK_CAP adjacent high-surrogate escapes (sj_strings.h): the byte-parallel string path
         // gave up, nothing of this run is a verdict.  Stage 2 again with the per-string walks (linear in the run).
+        if (ctx->p_len > ND_LIMIT) {
+            ctx_set_error(ctx, "the per-string path (a surrogate run or a string beyond the byte-parallel path) works on documents of up to 4 GiB");
+            return SJHIP_ERR_TOOBIG;
+        }
         ctx->p_aux = nullptr;
         HIPCHK(hipMemsetAsync(ctx->d_s2z.p, 0, stage2_zero_bytes(), ctx->stream), "stage2 state reset");
         HIPCHK(stage2_launch_measure(s2_args(ctx, tape_base, strings_base, msg_base)), "stage2 launch (measure, per-string)");
@@ -247,7 +259,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         return SJHIP_ERR_HIP;
     }
     if (hs->err & 4u) {
-        ctx_set_error(ctx, "tape longer than 2^32 words");
+        ctx_set_error(ctx, "tape longer than 2^32 words, or Strings.B longer than 4 GiB");
         return SJHIP_ERR_TOOBIG;
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
@@ -326,8 +338,8 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
         ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
         return parse_nd_big(ctx, msg, len, flags, false, nd_shard_bytes(), tape_len, strings_len, nullptr, nullptr);
     }
-    if (mlen > ND_LIMIT) {  // before 4 GiB are copied to the device
-        ctx_set_error(ctx, "document of %zu bytes: one context parses up to 4 GiB - 128 (uint32 positions); only ND messages are sharded", mlen);
+    if (mlen > SINGLE_LIMIT) {  // before anything is copied to the device
+        ctx_set_error(ctx, "document of %zu bytes: one context parses up to %zu", mlen, SINGLE_LIMIT);
         return SJHIP_ERR_TOOBIG;
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");

@@ -94,6 +94,7 @@ struct StrAux {
     uint64_t *qm, *q, *st;
     void *rec;  // ChunkRec[chunks]
     uint32_t *unit_cnt;
+    uint32_t *tile_unit;  // [units + 1] the unit that holds token 4096 T (stage1.hip; positions wrap beyond 4 GiB)
     uint32_t *unit_str;   // per unit: strings that begin in it, then (k_scans) their exclusive prefix (every string copied)
     uint8_t *unit_h;
     uint64_t *unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (a \u or an invalid escape)
@@ -116,6 +117,7 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     a.rec = carve(a.chunks * 16);
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
     a.unit_str = reinterpret_cast<uint32_t *>(carve(a.units * 4));
+    a.tile_unit = reinterpret_cast<uint32_t *>(carve((a.units + 1) * 4));
     a.unit_h = reinterpret_cast<uint8_t *>(carve(a.units));
     a.unit_slow = reinterpret_cast<uint64_t *>(carve(a.units * 8));
     a.unit_copy = reinterpret_cast<uint8_t *>(carve(a.units));

@@ -51,6 +51,8 @@ struct S1Aux {
     // written; the reads came back through the fabric, not from the L2.)
     Arr<u32> unit_cnt;   // [units] emitted bytes of the unit
     Arr<u32> unit_str;   // [units] strings that begin in the unit (opening quotes)
+    Arr<u32> tile_unit;  // [units + 1] the unit that holds token 4096 T: the positions are 32 bits wide and wrap in a message of
+                         // more than 4 GiB -- the token kernels rebuild a tile's positions from the unit its first token lies in
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
@@ -548,6 +550,10 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         else __builtin_amdgcn_s_setprio(1);
         const u32 C = (u32)__builtin_amdgcn_readlane((int)cl, u);
         const u64 g = BASE + ((u32)__builtin_amdgcn_readlane((int)incl, u) - C);
+        if (KIND && aux.tile_unit && lane == 0 && C != 0) {  // (a unit holds at most 4096 tokens: at most one 4096-token tile begins in it)
+            const u64 T = (g + 4095) >> 12;
+            if (T * 4096 < g + C) aux.tile_unit[T] = (u32)tile_unit<UNITS>(tm, t, u);
+        }
         const u64 s = sel[k];
         const u32 lo0 = (u32)s, hi0 = (u32)(s >> 32);
         const u32 n = (u32)__builtin_popcount(lo0) + (u32)__builtin_popcount(hi0);
@@ -1168,6 +1174,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
         aux.unit_cnt = SJ_ARR(a.unit_cnt, a.units, A_S1_UNIT_CNT);
         aux.unit_str = SJ_ARR(a.unit_str, a.units, A_S1_UNIT_STR);
+        aux.tile_unit = SJ_ARR(a.tile_unit, a.units + 1, A_S1_UNIT_STR);
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \

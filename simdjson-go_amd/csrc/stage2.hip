@@ -73,8 +73,11 @@ struct S2Dev {
     Arr<u32> dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     Arr<u32> str_off;  // [n] selective copy only: Strings.B offset of a copied string
     Arr<u32> nl_off;   // [n] tape offset of the r-th record-separating newline
-    Arr<uint2> numq;   // [n] (message offset, tape offset) of every number token, in no particular order
-    Arr<u32> bigq;     // [2n] (message offset, tape offset) of numbers that need the big-integer tie-break
+    Arr<uint4> numq;   // [n/2] (message offset lo, hi, tape offset, -) of the numbers k_numbers has to parse, in no particular order
+    Arr<uint4> bigq;   // [n/2] ... of those that need the big-integer tie-break  (a number is followed by a token that is none:
+    u32 numq_cap;      //       a document that parses holds at most n/2; entries beyond the room are dropped, the parse fails anyway)
+    Arr<const u32> tile_unit;  // [units + 1] the unit that holds token 4096 T (stage 1): the 32-bit positions wrap in a message of more
+                               // than 4 GiB; a tile's true positions = position of its first token (from its unit) + wrapped differences
     Arr<uint2> sinfo;  // [soff_cap] WithCopyStrings(false) on the masks, for the k-th string of the message: (Strings.B offset it has
                        // if it is copied, raw length of its content); behind the last one (length of Strings.B, 0)  (k_str_emit)
     Arr<u32> unit_tq;  // [units] ... and for a unit that ends inside a string: where that string's closing quote lies (k_measure)
@@ -491,7 +494,10 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
             s_prefix = before.s;
             if (seg == p.unit_segs - 1) {
                 if (STR) p.st->n_strings = (u32)(before.s + tot);
-                else p.st->strings_len_masks = before.s + tot;
+                else {
+                    p.st->strings_len_masks = before.s + tot;
+                    if (before.s + tot > 0xfffffff0ull) atomicOr(&p.st->err, 4u);  // (Strings.B offsets are 32 bits wide)
+                }
             }
         }
     }
@@ -1180,7 +1186,8 @@ __global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks) {
 // << 25) | (scalar: kind - 8 << 26)
 // MODE 0: no masks (the per-string fallback: lengths from the walks of the token reduce, both copy modes); 1: every string
 // copied, offsets from soff[]; 2: WithCopyStrings(false) on the masks -- soff[] and the closing quotes scq[]
-template <int MODE, int ITEMS>
+// WIDE: a message of 4 GiB or more (the 32-bit positions wrap: every tile rebuilds its true offsets, below)
+template <int MODE, int ITEMS, bool WIDE>
 __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit_planes(S2Dev p) {
     constexpr bool MASKS = MODE != 0;
     constexpr int BLK = S2_TILE / ITEMS, WAVES = BLK / 64;
@@ -1205,7 +1212,17 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
     const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
-    const u32 endpos = (u32)p.len;
+    // The positions are 32 bits wide: in a message of more than 4 GiB they are the true offsets modulo 2^32.  A tile keeps them
+    // relative to the true offset of its first token -- which follows from the unit that token lies in (stage 1's tile_unit) --
+    // and adds the 64-bit base where a byte of the message is addressed (tokens of a tile less than 4 GiB apart: else the parse fails)
+    // (a message below 4 GiB: the base is 0 at compile time -- as a run-time case the look-up and the additions cost the parse of
+    // configs[4] 1-2 %)
+    u64 tbase = 0;
+    if (MASKS && WIDE) {
+        const u32 first = p.pos[t0];
+        tbase = (u64)p.tile_unit[blockIdx.x] * 4096u + (((u64)first + p.sv.lead) & 4095u) - p.sv.lead;
+    }
+    const u32 endpos = (u32)(p.len - tbase);
     {
         const u32 base = t0 + (u32)tid * ITEMS;
         u32 pp[ITEMS];
@@ -1219,10 +1236,14 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) pp[k] = base + k < n ? p.pos[base + k] : endpos;
         }
+        if (MASKS) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) pp[k] = base + k < n ? pp[k] - (u32)tbase : endpos;  // (wrapped differences)
+        }
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++)
             *reinterpret_cast<uint4 *>(&s_pos[tid * ITEMS + 4 * q]) = make_uint4(pp[4 * q], pp[4 * q + 1], pp[4 * q + 2], pp[4 * q + 3]);
-        if (tid == 2) s_pos[S2_TILE] = (u64)t0 + S2_TILE < n ? p.pos[t0 + S2_TILE] : endpos;
+        if (tid == 2) s_pos[S2_TILE] = (u64)t0 + S2_TILE < n ? p.pos[t0 + S2_TILE] - (u32)tbase : endpos;
     }
     const TileLane tl = tile_lane<ITEMS>(p, t0, n, tid, s_edge);  // (holds the block barrier behind the stores above)
     const Lane16 &m = tl.m;
@@ -1334,7 +1355,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
             const u32 so = s_q[ks], se = s_q[ks + 1];
             u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
             if (MODE == 2 && se == so) {
-                w0 = string_word(false, 0, p.msg_base + s_pos[(u32)tid * ITEMS + j] + 1);
+                w0 = string_word(false, 0, p.msg_base + tbase + s_pos[(u32)tid * ITEMS + j] + 1);
                 w1 = (u64)(y_staged ? s_q[SC + ks] : (tp.s + ks < p.soff_cap ? p.sinfo[tp.s + ks].y : 0u));
             }
             *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
@@ -1364,12 +1385,13 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     // order does not matter): a wave draws the slots of its queued numbers with one atomic (round 4 queued every number and
     // marked the parsed ones: 10 MB of entries on configs[1] that k_numbers read only to skip them)
     for (u32 j = (u32)tid; j < D; j += BLK) {
-        const u32 v = s_q[SB + B + j], idx = v & 0xfffu, at = s_pos[idx], o = T0 + ((v >> 12) & 0x1fffu);
+        const u32 v = s_q[SB + B + j], idx = v & 0xfffu, o = T0 + ((v >> 12) & 0x1fffu);
+        const u64 at = tbase + s_pos[idx];
         const u8 ak = (u8)(8u + ((v >> 26) & 3u));
         bool slow = false;
         if (ak == K_NUM) {
             u64 iv = 0;
-            const bool fast = parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, (u64)at + 8), load8_guarded(mv, (u64)at + 16), &iv);
+            const bool fast = parse_int_fast(load8_guarded(mv, at), load8_guarded(mv, at + 8), load8_guarded(mv, at + 16), &iv);
             if (fast) {
                 const u64 tw = (u64)'l' << 56;
                 *reinterpret_cast<uint4 *>(arr_at(p.tape, o, 2)) = make_uint4((u32)tw, (u32)(tw >> 32), (u32)iv, (u32)(iv >> 32));
@@ -1385,7 +1407,8 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
             u32 qb = 0;
             if (lane == leader) qb = atomicAdd(&p.st->num_count, (u32)__popcll(mq));
             qb = (u32)__shfl((int)qb, leader, 64);
-            if (slow) p.numq[qb + (u32)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(at, o);
+            const u32 slot = qb + (u32)__popcll(mq & ((1ull << lane) - 1ull));
+            if (slow && slot < p.numq_cap) p.numq[slot] = make_uint4((u32)at, (u32)(at >> 32), o, 0u);
         }
     }
     // ---- brackets: matched inside the tile (sj_stage2.h bracket_resolve is the per-bracket statement, k_br_match the
@@ -1542,11 +1565,13 @@ __device__ __forceinline__ void tree12_body(const S2Dev &p, u32 bid, u32 nb) {
 }
 __device__ __forceinline__ void numbers_body(const S2Dev &p, u32 bid, u32 nblocks) {
     __shared__ u32 s_nb[256][9];  // 32-byte windows, 36-byte stride (bank-conflict free)
-    const u32 cnt = p.st->num_count;
-    bool bad = false;
+    u32 cnt = p.st->num_count;
+    bool bad = cnt > p.numq_cap;  // (more numbers than a document that parses can hold: entries were dropped)
+    if (bad) cnt = p.numq_cap;
     for (u32 j = bid * 256 + threadIdx.x; j < cnt; j += nblocks * 256) {
-        const uint2 q = p.numq[j];
-        const u32 at = q.x;
+        const uint4 q4 = p.numq[j];
+        const u64 at = ((u64)q4.y << 32) | q4.x;
+        const uint2 q = make_uint2(q4.x, q4.z);  // (.y: the tape offset)
         const u64 rest = p.len - at;
         u32 *w = s_nb[threadIdx.x];
         if (rest >= 32) {
@@ -1567,8 +1592,7 @@ __device__ __forceinline__ void numbers_body(const S2Dev &p, u32 bid, u32 nblock
             p.tape[q.y + 1] = val;
             if (st == NUM_NEEDS_BIGNUM) {
                 const u32 slot = atomicAdd(&p.st->bignum_count, 1u);
-                p.bigq[2 * slot] = at;
-                p.bigq[2 * slot + 1] = q.y;
+                if (slot < p.numq_cap) p.bigq[slot] = q4;
             }
         }
     }
@@ -1776,13 +1800,17 @@ __global__ __launch_bounds__(256) void k_emit_strings(S2Dev p) {
 
 // ---- exact tie-break for >19-digit mantissas whose neighbours disagree --------------------------------------------
 __global__ __launch_bounds__(64) void k_bignum(S2Dev p) {
-    const u32 cnt = p.st->bignum_count;
+    u32 cnt = p.st->bignum_count;
+    if (cnt > p.numq_cap) cnt = p.numq_cap;
     Big X, Y;
     for (u32 q = blockIdx.x * 64 + threadIdx.x; q < cnt; q += gridDim.x * 64) {
-        const u32 at = p.bigq[2 * q], o = p.bigq[2 * q + 1];
+        const uint4 e = p.bigq[q];
+        const u64 at = ((u64)e.y << 32) | e.x;
+        const u32 o = e.z;
         u64 tag, val;
         u32 numlen = 0;
-        (void)parse_number(arr_at(p.msg, at, p.len - at), (u32)(p.len - at), &tag, &val, &numlen);
+        const u64 room = p.len - at;
+        (void)parse_number(arr_at(p.msg, at, room), (u32)(room < 0x7fffffffu ? room : 0x7fffffffu), &tag, &val, &numlen);
         const u64 cand = p.tape[o + 1];
         const u64 sign = cand & 0x8000000000000000ull;
         const u64 r = bignum_round(arr_at(p.msg, at, numlen), numlen, cand & ~0x8000000000000000ull, X, Y);
@@ -1812,7 +1840,8 @@ size_t stage2_zero_bytes() { return (sizeof(S2State) + 3 * SCAN_SEGS * sizeof(Se
 size_t stage2_workspace_bytes(size_t n) {
     size_t b = 256;
     b += align_up(n + 16, 256);                     // br_info
-    b += align_up(n * 4, 256) * 9;                  // dlen str_off nl_off numq(x2) bigq(x2) br_depth br_off
+    b += align_up(n * 4, 256) * 5;                  // dlen str_off nl_off br_depth br_off
+    b += align_up((n / 2 + 8) * 16, 256) * 2;       // numq bigq
     b += align_up((n / 2 + 8) * 16, 256);           // strq
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
@@ -1850,8 +1879,10 @@ static S2Dev stage2_view(const S2Args &a) {
     p.dlen = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_DLEN);
     p.str_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_STR_OFF);
     p.nl_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_NL_OFF);
-    p.numq = SJ_ARR(reinterpret_cast<uint2 *>(carve(n * 8)), n, A_NUMQ);
-    p.bigq = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 8)), 2 * n, A_BIGQ);
+    p.numq_cap = (u32)(n / 2 + 8);
+    p.numq = SJ_ARR(reinterpret_cast<uint4 *>(carve((size_t)p.numq_cap * 16)), p.numq_cap, A_NUMQ);
+    p.bigq = SJ_ARR(reinterpret_cast<uint4 *>(carve((size_t)p.numq_cap * 16)), p.numq_cap, A_BIGQ);
+    p.tile_unit = nullptr;
     u32 *const scq_mem = reinterpret_cast<u32 *>(carve(((size_t)n / 2 + 8) * 16));  // >= 4 (n + 2) bytes
     p.br_depth = SJ_ARR(reinterpret_cast<i32 *>(carve(n * 4)), n, A_BR_DEPTH);
     p.br_off = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_BR_OFF);
@@ -1920,6 +1951,7 @@ static S2Dev stage2_view(const S2Args &a) {
         // the strings of the message are numbered, their Strings.B offsets go where the per-string fallback keeps its lengths
         // (dlen and str_off are adjacent: 2 x align_up(4n, 256) >= 4 (n + 2) bytes)
         p.unit_str = SJ_ARR(x.unit_str, x.units, A_UNIT_STR);
+        p.tile_unit = SJ_ARR((const u32 *)x.tile_unit, x.units + 1, A_UNIT_STR);
         p.soff_cap = (u32)(n + 2 < 0xffffffffull ? n + 2 : 0xffffffffull);
         p.soff = SJ_ARR(arr_raw(p.dlen), p.soff_cap, A_SOFF);
         if (!p.copy_strings) {  // the states at the units' ends (k_measure), the closing quotes
@@ -1975,7 +2007,12 @@ hipError_t stage2_launch_emit(const S2Args &a) {
     else if (mode == 2) hipLaunchKernelGGL(k_str_emit<true>, dim3(persistent_blocks(k_str_emit<true>, (p.units + 3) / 4)), dim3(256), 0, a.stream, p);
     {
         static const int items = getenv("SJHIP_S2_ITEMS") ? atoi(getenv("SJHIP_S2_ITEMS")) : 8;  // tokens per lane (A/B)
-#define SJ_EMIT(M, I) hipLaunchKernelGGL((k_s2_emit_planes<M, I>), dim3(p.tiles), dim3(S2_TILE / I), 0, a.stream, p)
+        const bool wide = mode != 0 && p.len >= (1ull << 32);
+#define SJ_EMIT(M, I)                                                                                                     \
+    do {                                                                                                                  \
+        if (wide) hipLaunchKernelGGL((k_s2_emit_planes<M, I, (M) != 0>), dim3(p.tiles), dim3(S2_TILE / I), 0, a.stream, p); \
+        else hipLaunchKernelGGL((k_s2_emit_planes<M, I, false>), dim3(p.tiles), dim3(S2_TILE / I), 0, a.stream, p);       \
+    } while (0)
         if (items == 16) {
             if (mode == 0) SJ_EMIT(0, 16);
             else if (mode == 1) SJ_EMIT(1, 16);

@@ -4,7 +4,8 @@ sjhip_parse / sjhip_parse_device cut an ND message longer than 4 GiB - 128 into 
 library (csrc/multi_api.hip parse_nd_big) and the merged result must be the ParsedJson of the whole message.  The
 threshold and the shard size can be moved with SJHIP_ND_LIMIT_BYTES / SJHIP_ND_SHARD_BYTES, which lets the same path run
 on megabytes against the oracle; the real thing (4.8 GB) is checked through the closed form of its tape.  A single
-document beyond the limit does not shard: SJHIP_ERR_TOOBIG, before anything is copied."""
+document does not shard; since round 5 it parses all the same -- the 32-bit positions wrap and the token kernels rebuild them
+tile by tile (test_single_document_beyond_4GiB)."""
 import os
 
 import numpy as np
@@ -137,17 +138,62 @@ def test_nd_message_beyond_4GiB():
     ctx.close()
 
 
-def test_single_document_beyond_the_limit_is_refused():
-    """A single JSON document does not shard: sjhip_parse refuses it with SJHIP_ERR_TOOBIG before it
-    copies anything (the 4 GiB below are never touched: only the ends are read, by TrimSpace)."""
+def _periodic_form(t2, t3):
+    """A document  [ B , B , ... , B ]  of N equal blocks has a tape that is periodic with a linear drift: the words of block b are
+    the words of block 0 plus b times a per-word step (indexes into the tape advance by the block's words, string offsets by its
+    Strings.B bytes or message bytes, everything else stays).  Steps, head and tail are read off the oracle's tapes of the
+    documents with two and three blocks and checked on the third block.  -> (words per block, block 0, step, head(N), tail(N))"""
+    tb = len(t3) - len(t2)
+    head = 2  # r [
+    b0, b1, b2 = (t3[head + k * tb: head + (k + 1) * tb] for k in range(3))
+    step = b1 - b0
+    assert np.array_equal(b2, b0 + np.uint64(2) * step) and np.array_equal(t2[head:head + tb], b0) and np.array_equal(t2[head + tb:head + 2 * tb], b1)
+
+    def ends(n):
+        out = []
+        for w2, w3 in ((t2[0], t3[0]), (t2[1], t3[1]), (t2[-2], t3[-2]), (t2[-1], t3[-1])):
+            d = int(w3) - int(w2)
+            assert d in (0, tb)
+            out.append(np.uint64(int(w3) + (n - 3) * d))
+        return out[:2], out[2:]
+    return tb, b0, step, ends
+
+
+def test_single_document_beyond_4GiB():
+    """The reference parses "arbitrarily large" inputs because its index stream is deltas (README.md:567-569,
+    flatten_bits_amd64.s:30-44).  Here the positions are 32 bits wide and simply wrap: every 4096-token tile of the token kernels
+    rebuilds its true offsets from the unit its first token lies in.  A JSON array of 4.6 GiB (13 000 copies of parking-citations
+    as arrays of records) against the closed form of its tape, every block, both copy modes; plain stage 1 -- whose contract is
+    32-bit positions -- still refuses such a message."""
+    import psutil
     import sjhip
+    if psutil.virtual_memory().available < (64 << 30):
+        pytest.skip("needs ~45 GB of host memory")
+    park = fixtures.load("parking-citations")
+    block = b"[" + b",".join(l for l in park.split(b"\n") if l) + b"]"
+    mk = lambda n: b"[" + b",".join([block] * n) + b"]"
+    copies = (4700 << 20) // (len(block) + 1) + 1
+    doc = np.frombuffer(mk(copies), dtype=np.uint8)
+    assert doc.size > (1 << 32) + (256 << 20)
     ctx = sjhip.Context(0)
-    doc = np.zeros((1 << 32) - 64, dtype=np.uint8)
-    doc[0] = ord("[")
-    doc[-1] = ord("]")
-    with pytest.raises(sjhip.ParseError) as e:
-        ctx.parse(doc, ndjson=False)
-    assert e.value.code == 4 and "4 GiB" in str(e.value)
+    for copy in (True, False):
+        r2, r3 = O.parse(mk(2), copy_strings=copy), O.parse(mk(3), copy_strings=copy)
+        assert r2.rc == 0 and r3.rc == 0
+        tb, b0, step, ends = _periodic_form(r2.tape, r3.tape)
+        sb = len(r3.strings) - len(r2.strings)
+        pj = ctx.parse(doc, ndjson=False, copy_strings=copy)
+        assert len(pj.Tape) == 4 + copies * tb and len(pj.Strings) == copies * sb, (copy, len(pj.Tape), len(pj.Strings))
+        head, tail = ends(copies)
+        assert list(pj.Tape[:2]) == head and list(pj.Tape[-2:]) == tail
+        tape = pj.Tape[2:-2].reshape(copies, tb)
+        for b in range(copies):
+            want = b0 + np.uint64(b) * step
+            if not np.array_equal(tape[b], want):
+                d = np.nonzero(tape[b] != want)[0]
+                raise AssertionError((copy, b, d[:5], [hex(int(x)) for x in tape[b][d[:3]]], [hex(int(x)) for x in want[d[:3]]]))
+        if sb:
+            assert (pj.Strings.reshape(copies, sb) == r2.strings[None, :sb]).all()
+        del pj, tape
     with pytest.raises(sjhip.ParseError) as e:
         ctx.stage1(doc)
     assert e.value.code == 4
