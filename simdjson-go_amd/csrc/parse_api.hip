@@ -125,8 +125,23 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         // A small document is not worth a host round trip in the middle: stage 2 is queued behind stage 1 with arenas
         // and grids sized for the upper bound (a token is at least one byte), the kernels read the token count on the
         // device, and stage 1's verdict is taken after the one synchronisation at the end.  (A shard needs its sizes first.)
-        ctx->p_deferred = !(tape_len || strings_len) && len <= small_document_bytes() && !ctx->p_no_defer;
-        if (ctx->p_deferred) {
+        // ... and round 5: neither is a LARGE document once the context has seen the token density of its kind -- the layout
+        // is then the density of the context's last parse plus a quarter (a benchmark loop, the blocks of a stream and a
+        // pool's contexts parse the same kind of data again and again); the first large parse of a context, and a document
+        // denser than the one before it, take the synchronous path.  configs[1] 0.531 -> 0.515 ms, configs[4] 0.849 -> 0.840 ms
+        // (same box): the host round trip between stage 1 and stage 2 and the launch gap behind it.
+        const bool small = len <= small_document_bytes();
+        const bool known = ctx->p_density_q != 0 && small_document_bytes() != 0;
+        ctx->p_deferred = !(tape_len || strings_len) && (small || known) && !ctx->p_no_defer;
+        if (ctx->p_deferred && !small) {
+            rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
+                                ctx->d_s2z.p, stage2_zero_bytes());
+            const size_t est = (size_t)(((unsigned __int128)len * ctx->p_density_q * 5 / 4) >> 10) + 65536;  // tokens per KiB, + 25 %
+            n = est < len ? est : len;
+            ok = 1;
+            ctx->p_last = last_byte;
+            ctx->p_have_last = have_last;
+        } else if (ctx->p_deferred) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
             // The stage-2 arrays are laid out for one token per four bytes (the densest fixture, marine_ik, has 0.22):
@@ -263,6 +278,8 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         return SJHIP_ERR_TOOBIG;
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
+    // the token density of this parse (tokens per KiB, rounded up): what the next large parse of the context is laid out for
+    if (ctx->p_len) ctx->p_density_q = (uint32_t)(((unsigned __int128)ctx->p_n * 1024 + ctx->p_len - 1) / ctx->p_len) + 1;
     ctx->tape_len = (size_t)hs->tape_len;
     ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
@@ -279,9 +296,10 @@ static int parse_on_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32
     int rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
     if (rc) return rc;
     rc = parse_finish(ctx, 0, 0, 0, tape_len, strings_len);
-    if (rc == PARSE_AGAIN_SYNCHRONOUS) {  // a small document with more than one token per four bytes
+    if (rc == PARSE_AGAIN_SYNCHRONOUS) {  // a document denser than its layout: a small one with more than one token per four bytes,
+                                          // a large one denser than the context's last parse (this parse leaves the new density)
         ctx->p_no_defer = 1;
-        ctx->p_dense = 1;  // (minified numeric arrays come in series: the next ones are laid out for one token per byte)
+        if (len <= small_document_bytes()) ctx->p_dense = 1;  // (minified numeric arrays come in series: the next ones are laid out for one token per byte)
         ctx->want_pack = want_pack;
         rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, nullptr, nullptr);
         ctx->p_no_defer = 0;

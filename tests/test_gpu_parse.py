@@ -794,3 +794,22 @@ def test_very_long_strings_without_copy(ctx):
                 body = body + b"\\t"
             doc = b'{"a":"short","big":"' + body + b'","b":[1,"x\\\\y",true],"c":"' + b"q" * 5000 + b'"}'
             check(ctx, doc, False, "long string %d %s" % (n, where))
+
+
+def test_large_documents_of_changing_density():
+    """A large document (beyond SJHIP_SMALL_BYTES) is parsed without the host round trip between the stages once its context has
+    seen a parse: the stage-2 arrays are laid out for the token density of the context's last parse + 25 %.  A denser document
+    than the one before must fall back to the synchronous path (and teach the context its density), a sparser one must not
+    mind; every result against the oracle, own context so that the order of the densities is the test's."""
+    import sjhip
+    c = sjhip.Context(0)
+    sparse = ('[' + ','.join('"%s"' % ('s' * 900) for _ in range(7000)) + ']').encode()        # 6.3 MB, 0.002 tokens per byte
+    medium = workloads.c2_twitter_array(9)                                                      # 5.7 MB, 0.09
+    dense = ('[' + ','.join('1' for _ in range(3_000_000)) + ']').encode()                      # 6 MB, 1 token per byte
+    nd = (fixtures.load("parking-citations") * 14)                                              # 5.2 MB ND, 0.21
+    for doc, is_nd in ((sparse, False), (medium, False), (sparse, False), (dense, False), (medium, False), (nd, True), (dense, False), (sparse, False)):
+        for copy in (True, False):
+            ref = O.parse(doc, ndjson=is_nd, copy_strings=copy)
+            pj = c.parse(doc, ndjson=is_nd, copy_strings=copy)
+            assert ref.rc == 0 and np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), (len(doc), copy)
+    c.close()
