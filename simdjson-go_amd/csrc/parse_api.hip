@@ -136,8 +136,23 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         if (ctx->p_deferred && !small) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
-            const size_t est = (size_t)(((unsigned __int128)len * ctx->p_density_q * 5 / 4) >> 10) + 65536;  // tokens per KiB, + 25 %
-            n = est < len ? est : len;
+            // tokens per KiB, + 1/16 -- and, where the context's arenas already hold more (the same document again: exactly its
+            // count), as much as they hold: a layout that needs no allocation and fails for as few documents as possible
+            const size_t est = (size_t)(((unsigned __int128)len * ctx->p_density_q * 17 / 16) >> 10) + 4096;
+            size_t fit = ctx->d_tape.cap / 16 > 2 ? ctx->d_tape.cap / 16 - 2 : 0;  // (2 n + 2 tape words)
+            if ((flags & SJHIP_FLAG_KEY_FLAGS) && ctx->d_keyflag.cap < fit + 9) fit = ctx->d_keyflag.cap > 9 ? ctx->d_keyflag.cap - 9 : 0;
+            if (fit > 0 && stage2_workspace_bytes(fit) > ctx->d_s2.cap) {  // the largest n whose workspace fits
+                size_t lo = 0, hi = fit;
+                while (hi - lo > 1) {
+                    const size_t mid = lo + (hi - lo) / 2;
+                    if (stage2_workspace_bytes(mid) <= ctx->d_s2.cap) lo = mid;
+                    else hi = mid;
+                }
+                fit = lo;
+            }
+            if (fit > 4 * est) fit = 4 * est;  // (grids are sized for the layout: not for a much larger document of the past)
+            n = est > fit ? est : fit;
+            if (n > len) n = len;
             ok = 1;
             ctx->p_last = last_byte;
             ctx->p_have_last = have_last;

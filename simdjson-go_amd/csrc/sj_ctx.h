@@ -53,7 +53,7 @@ struct sjhip_ctx {
     int p_deferred = 0;   // stage 1's result has not been collected yet (small documents: one synchronisation per parse)
     int p_no_defer = 0;   // the deferred run met more tokens than its layout holds: this parse takes the synchronous path
     uint32_t p_density_q = 0;  // tokens per KiB of the context's last successful parse (+1), 0: none yet -- a large document is
-                               // then parsed without the host round trip between the stages, laid out for that density + 25 %
+                               // then parsed without the host round trip between the stages, laid out for that density + 1/16 (or what the arenas hold)
     int p_dense = 0;      // sticky: a document of this context was denser than one token per four bytes -- later deferred
                           // parses are laid out for one token per byte instead of paying the second parse again
     uint8_t p_last = 0;   // ... its caller-supplied last byte
