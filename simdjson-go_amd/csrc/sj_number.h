@@ -208,7 +208,7 @@ enum NumStatus : int { NUM_FAIL = 0, NUM_OK = 1, NUM_NEEDS_BIGNUM = 2 };
 
 // ---- the common case in the token kernel: a plain integer of up to 18 digits ------------------------------------------
 // parseNumber (parse_number.go:65-135) turns [-]digits without '.', 'e', 'E' into an int64 when strconv.ParseInt takes
-// it; up to 18 digits always fit.  k_s2_emit has the token's position anyway: with the first 24 bytes of the number in
+// it; up to 18 digits always fit.  the emit pass has the token's position anyway: with the first 24 bytes of the number in
 // three words (first byte = lowest byte of w0, zero behind the end of the message) this decides in registers whether
 // the number is of that shape -- optional '-', 1..18 digits, no leading zero in front of another digit, and then one of
 // the bytes that end a value for parseNumber (',' '}' ']' ' ' '\t' '\r' '\n' ':', :75-84) -- and returns its value.  Every

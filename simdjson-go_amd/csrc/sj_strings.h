@@ -16,7 +16,8 @@
 //         half's positions and nothing at the low half's.
 //   UM  = positions of the 'u' of unicode escapes inside strings (kept for inspection; pass 2 re-derives them).
 // E(a) = emitted bytes in front of aligned offset a = unit_base[a>>12] + chunk_pre[a>>6] + popc(EM & below),
-// which gives every string token its Strings.B offset and unescaped length without walking the string.
+// which gives every string its Strings.B offset and unescaped length without walking it: k_str_emit evaluates E at the
+// opening quote of every string and leaves it under the string's number (round 5: soff[]; the tape kernels read it in order).
 // All quirks of the reference's string parser are kept (sj_stage2.h string_walk is the per-string
 // statement of the same rules and is still used for WithCopyStrings(false)).
 #pragma once
@@ -432,7 +433,8 @@ SJ_HD u32 sel_then(u32 first, u32 second) {  // first, then second
 // the bytes of the chunk that belong to strings which are copied; F / G: the states at the start / at the end of the chunk
 SJ_HD u64 chunk_sel_mask(const ChunkSel &c, u32 F, u32 G) { return c.local | (F ? c.hr : 0ull) | (G ? c.tr : 0ull); }
 
-// the same from the absolute chunk offset k_str_emit leaves in the record (the form k_s2_emit uses: one load)
+// the same from an absolute chunk offset in the record (rounds 3-4: what the emit pass gathered per string; the host replay
+// still holds soff[] against both forms)
 SJ_HD u64 emitted_before_abs(Arr<const ChunkRec> rec, u64 a) {
     const ChunkRec r = rec[a >> 6];
     const u32 bit = (u32)(a & 63);

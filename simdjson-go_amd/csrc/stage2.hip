@@ -5,22 +5,25 @@
 // sj_number.h / sj_bignum.h (host+device, replayed on the CPU by the test-suite); this file holds the
 // kernels, the device-wide scan and the launcher.  No host synchronisation happens between the kernels.
 //
-// Launches of one parse, behind stage 1 (one token = one structural index):
-//   k_measure   two independent measuring passes in one launch: the string masks of stage 1 -> emit masks, one 16-byte
-//               record per 64-byte chunk and one count per 4 KiB unit (general \u routine escape by escape: GenUnit);
-//               the token kinds (written by stage 1) -> scan element per token, one aggregate per 4096-token tile
-//   k_scans     both exclusive scans (unit counts; tile aggregates) + totals: tape length, records, brackets
-//   k_str_emit  Strings.B: the emitted bytes of every chunk, compacted through LDS
-//   k_s2_emit   (512 threads x 8 tokens) rebuilds the elements, scans inside the tile, sorts the tokens by kind into LDS
-//               queues and writes every tape word that does not depend on a bracket partner: strings, atoms; numbers
-//               go to a global queue, brackets to a compact view (depth, tape offset, kind, allowed-context set of the
-//               gap in front), newlines that separate records leave their tape offset
+// Launches of one parse, behind stage 1 (one token = one structural index), the same seven in both copy modes:
+//   k_measure   two independent measuring passes in one launch.  String half: the units with a \u (or invalid) escape get
+//               their emit masks escape by escape (GenUnit) as 16-byte records; WithCopyStrings(false): every unit -- the bytes
+//               of the strings that hold an escape starter are selected 64 at a time and counted (sj_strings.h chunk_sel).
+//               Token half: the kinds of 16 tokens per lane on bit planes (sj_tok16.h) -> one aggregate per 4096-token tile
+//   k_scans     the exclusive scans (unit byte counts, unit string counts, tile aggregates) + totals: tape length,
+//               Strings.B length, records, brackets
+//   k_str_emit  Strings.B: emit mask, escaped characters and opening quotes of a chunk from stage 1's three masks; the
+//               emitted (selected) bytes compacted through LDS; the Strings.B offset (and raw length) of the k-th string of
+//               the message in soff[] / sinfo[]
+//   k_s2_emit_planes  the token pass on bit planes: one packed block scan gives tape offsets, bracket ordinals and queue slots;
+//               strings from soff[] / sinfo[] in order, atoms and short integers on the spot, other numbers to a global
+//               queue; the tile's brackets matched inside the tile, the rest to the compact view (depth, tape offset, kind,
+//               allowed-context set of the gap in front); newlines that separate records leave their tape offset
 //   k_numbers   the queued numbers; in the same launch levels 1 and 2 of the 64-ary min tree over the bracket depths
 //   k_min_upper the upper levels of the tree
-//   k_br_match  previous-smaller-value queries over the compact bracket view: partners' tape words, the grammar check
-//               of every gap against the type of its container, root words
-// plus k_emit_strings (selective copy), k_bignum (on demand) and k_pack (small documents: the result straight into
-// pinned host memory).
+//   k_br_match  previous-smaller-value queries over the compact bracket view for the brackets the tiles left open: partners'
+//               tape words, the grammar check of every gap against the type of its container, root words
+// plus k_emit_strings (the per-string fallback), k_bignum (on demand) and k_pack (small documents: the result straight into pinned host memory).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -98,19 +101,20 @@ struct S2Dev {
     Arr<u8> strings;
     Arr<u8> keyflag;   // null, or [tape_cap / 2 + 8]: [tape offset of a string entry >> 1] = 1 iff the string is an object key
                        // (SJHIP_FLAG_KEY_FLAGS: marshal.hip reads them instead of recovering them from the token kinds)
-    Arr<u8> str_out;   // where k_str_emit writes the unescaped bytes of ALL strings: `strings` when every string is copied; a
-                   // scratch buffer with WithCopyStrings(false), from which k_emit_strings takes the strings that changed
+    Arr<u8> str_out;   // where k_str_emit writes: `strings` (both copy modes: with WithCopyStrings(false) it only compacts the bytes of
+                   // the strings that are copied)
     u64 tape_cap, strings_cap;
     u64 tape_base, strings_base, msg_base;  // NDJSON shard: rebasing of every stored index (0 if unsharded)
     // byte-parallel string path (copy_strings): masks from stage 1 and what the string kernels derive from them
     StrView sv;           // base / lead / end / qm q st unit_h (null qm: path not used)
-    Arr<ChunkRec> rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag)
+    Arr<ChunkRec> rec;        // [chunks] emit mask + emitted bytes of the unit in front of the chunk (+ patch flag): only the units with
+                              //          a \u or invalid escape (k_measure's general routine) have them
     Arr<u32> unit_cnt;        // [units]  emitted bytes of the unit, then (k_str_scan) their exclusive prefix
-    Arr<u32> unit_str;        // [units]  every string copied: strings that begin in the unit, then their exclusive prefix
+    Arr<u32> unit_str;        // [units]  strings that begin in the unit, then their exclusive prefix
     Arr<u32> soff;            // [soff_cap] every string copied: Strings.B offset of the k-th string of the message, and behind
     u32 soff_cap;             //          the last one the length of Strings.B (k_str_emit; the storage is dlen's and str_off's)
-    Arr<u8> unit_copy;        // [units]  selective copy only (else null): 1 iff the unit holds bytes of a string that unescaping
-                              // changes -- cleared with the unit's count, set by k_str_measure; k_str_emit compacts only those units
+    Arr<u8> unit_copy;        // [units]  WithCopyStrings(false) only (else null): the states of the selective copy at the unit's ends
+                              //          (USEL_*, k_measure -> k_str_emit)
     u64 units;
     u32 exp;  // SJ_EXP builds only: bit mask of parts to leave out (A/B timing of the kernels' parts; results are wrong)
 };
@@ -1072,7 +1076,7 @@ __global__ __launch_bounds__(1024) void k_scans(S2Dev p) {
 __device__ __forceinline__ int top_bit(u64 m) { return 63 - __builtin_clzll(m); }  // m != 0
 
 // ==== round 5: the token pass on bit planes, sixteen tokens per lane (sj_tok16.h) ====================================
-// k_measure's token half and k_s2_emit in their plane form.  A tile is still 4096 tokens (the packed scan form PAgg and
+// k_measure's token half and the emit pass in their plane form.  A tile is still 4096 tokens (the packed scan form PAgg and
 // the tile aggregates are unchanged); a block is 256 threads x 16 tokens.  What changed against the per-token kernels
 // above (kept as variant 0 for A/B runs, SJHIP_S2_VARIANT):
 //   * the scan element of a lane comes from ~150 boolean instructions on 19-bit windows of the kind planes instead of 16
@@ -1519,7 +1523,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
 // The first 32 bytes of each number go to LDS (two unaligned 16-byte loads instead of one dependent byte load
 // per digit); longer numbers fall back to the message itself.
 // The same launch builds levels 1 and 2 of the min tree over the bracket depths in its blocks from `nblocks` on (both
-// only need k_s2_emit's output; as launches of their own they cost 25 us): a block takes 4096 depths -- one level-2
+// only need the emit pass's output; as launches of their own they cost 25 us): a block takes 4096 depths -- one level-2
 // entry -- at a time, one wave per 64 of them (a level-1 entry), and folds the 64 minima through LDS.
 __device__ __forceinline__ MinTree make_tree(const S2Dev &p);
 // bid / nb: this block's index among the nb blocks that share the role (several roles run in one launch)
@@ -1842,7 +1846,7 @@ size_t stage2_workspace_bytes(size_t n) {
     b += align_up(n + 16, 256);                     // br_info
     b += align_up(n * 4, 256) * 5;                  // dlen str_off nl_off br_depth br_off
     b += align_up((n / 2 + 8) * 16, 256) * 2;       // numq bigq
-    b += align_up((n / 2 + 8) * 16, 256);           // strq
+    b += align_up((n / 2 + 8) * 16, 256);           // sinfo (WithCopyStrings(false): 8 bytes per string)
     const size_t tiles = (n + S2_TILE - 1) / S2_TILE + 1;
     b += align_up(tiles * sizeof(TileAgg), 256);
     size_t lv = n;
