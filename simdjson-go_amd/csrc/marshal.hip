@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "../../include/sjhip.h"
+#include "sj_bounds.h"
 #include "sj_ctx.h"
 #include "sj_device.h"
 #include "sj_ftoa.h"
@@ -44,6 +45,7 @@ struct MsView {
     u32 tiles;
     const u8 *strings;
     const u8 *msg;
+    u64 strings_len, msg_len;    // (the debug build checks every string a tape word names against them, ms_string)
     long long *tile_last;        // [tiles] sj_tapewalk.h, or null: the tiles look for their anchor themselves
     unsigned long long *cnt_b;   // [tiles] text bytes of the tile           -> exclusive prefix
     unsigned long long *cnt_s;   // [tiles] string entries of the tile       -> exclusive prefix
@@ -68,6 +70,20 @@ struct KeyView {
     u8 *keyflag;
 };
 
+// the bytes of a string entry: offset and length come out of tape words -- in the debug build (-DSJ_DEBUG_BOUNDS) they are
+// checked against the buffer they point into, a violation is recorded (sj_bounds.h) and the call fails
+__device__ __forceinline__ const u8 *ms_string(const MsView &p, bool inbuf, u64 off, u64 len) {
+#if defined(SJ_DEBUG_BOUNDS)
+    const u64 size = inbuf ? p.strings_len : p.msg_len;
+    if (off > size || len > size - off) {
+        bounds_report(inbuf ? A_STRINGS : A_MSG, off + len, size);
+        off = 0;
+    }
+#else
+    (void)len;
+#endif
+    return (inbuf ? p.strings : p.msg) + off;
+}
 __device__ __forceinline__ const u8 *entry_string(const MsView &p, u64 word) {
     const u64 v = word & TW_PAYLOAD;
     return (v & STRINGBUFBIT) ? p.strings + (v & (STRINGBUFBIT - 1)) : p.msg + v;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             const u32 e = (u32)e64, idx = e & 0x7ffu;
             const u64 len = (e >> 23) & 0x3fu;
             const bool inbuf = (e >> 22) & 1u;
-            const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+            const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
             const u8 *lim = inbuf ? p.strings_end : p.msg_end;
             u32 el = 0;
             for (u64 q = 0; q < len; q += 8) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             const u32 e = (u32)e64, idx = e & 0x7ffu;
             const u64 len = p.tape[tb + idx + 1];
             const bool inbuf = (e >> 22) & 1u;
-            const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+            const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
             const u8 *lim = inbuf ? p.strings_end : p.msg_end;
             u64 el = 0;
             for (u64 q = (u64)lane * 8; q < len; q += 512) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         const u32 e = (u32)e64, idx = e & 0x7ffu;
         const u64 len = (e >> 23) & 0x3fu;
         const bool inbuf = (e >> 22) & 1u;
-        const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+        const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
         const u8 *lim = inbuf ? p.strings_end : p.msg_end;
         u8 *o = tbase + s_len[idx];
         *o++ = '"';
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         const u32 e = (u32)e64, idx = e & 0x7ffu;
         const u64 len = p.tape[tb + idx + 1];
         const bool inbuf = (e >> 22) & 1u;
-        const u8 *sp = (inbuf ? p.strings : p.msg) + (e64 >> 32);
+        const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
         const u8 *lim = inbuf ? p.strings_end : p.msg_end;
         u8 *o = tbase + s_len[idx];
         if (lane == 0) *o = '"';
@@ -611,6 +627,24 @@ static void launch_ms_tile(const MsView &p, hipStream_t st) {
 }
 }  // namespace
 
+// debug build (-DSJ_DEBUG_BOUNDS): an out-of-bounds string of a MarshalJSON kernel fails the call (this translation unit's record)
+static int marshal_bounds_check(sjhip_ctx *ctx) {
+#if defined(SJ_DEBUG_BOUNDS)
+    BoundsHit hit = {};
+    if (hipMemcpyFromSymbol(&hit, HIP_SYMBOL(g_bounds_hit), sizeof hit) != hipSuccess) return SJHIP_OK;
+    if (hit.hits) {
+        const BoundsHit zero = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_hit), &zero, sizeof zero);
+        ctx_set_error(ctx, "bounds check (MarshalJSON): %u out-of-bounds strings, the first in array %u (sj_bounds.h ArrId) at byte %llu of %llu",
+                      hit.hits, hit.id, hit.index, hit.size);
+        return SJHIP_ERR_HIP;
+    }
+#else
+    (void)ctx;
+#endif
+    return SJHIP_OK;
+}
+
 int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     if (!ctx) return SJHIP_ERR_ARG;
     ctx->ms_len = 0;
@@ -629,6 +663,8 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     p.tiles = (u32)((p.n + TW_TILE - 1) / TW_TILE);
     p.strings = (const u8 *)ctx->d_strings.p;
     p.msg = (const u8 *)ctx->p_msg;
+    p.strings_len = ctx->strings_len;
+    p.msg_len = ctx->p_msg ? ctx->p_len : 0;
     p.strings_end = p.strings + ctx->strings_len;
     p.msg_end = p.msg ? p.msg + ctx->p_len : nullptr;
     KeyView kv;
@@ -717,7 +753,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
             ctx->ms_len = (size_t)h[0];
             ctx->ms_valid = 1;
             if (text_len) *text_len = ctx->ms_len;
-            return SJHIP_OK;
+            return marshal_bounds_check(ctx);
         }
         no_local_anchor = (h[2] & 4ull) != 0;  // (the counting pass below starts with the global anchors right away)
         HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
@@ -767,5 +803,5 @@ int sjhip_fetch_marshaled(sjhip_ctx *ctx, uint8_t *dst) {
     if (ctx->ms_len && dst)
         HIPCHK(hipMemcpyAsync(dst, ctx->d_qtape.p, ctx->ms_len, hipMemcpyDeviceToHost, ctx->stream), "D2H JSON text");
     HIPCHK(hipStreamSynchronize(ctx->stream), "fetch sync");
-    return SJHIP_OK;
+    return marshal_bounds_check(ctx);  // (debug build: the writing pass has finished here)
 }

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "../../include/sjhip.h"
+#include "sj_bounds.h"
 #include "sj_ctx.h"
 #include "sj_device.h"
 #include "sj_stage2.h"
@@ -58,10 +59,23 @@ struct SerView {
     u32 *slot_off;               // [SER_SLOTS] column offset of that string
     unsigned long long *cnt_s;   // [tiles] kept string bytes of the tile -> exclusive prefix
     const u8 *strings;           // Strings.B
+    u64 strings_len;             // (the debug build checks the offset and length a tape word names against it, ser_string)
     u8 *scol;                    // the string column
 };
 static constexpr u32 SER_SLOT_BITS = 20, SER_SLOTS = 1u << SER_SLOT_BITS;
 
+// the bytes of a string entry of Strings.B: offset and length come out of tape words -- checked in the debug build
+__device__ __forceinline__ const u8 *ser_string(const SerView &p, u64 off, u64 len) {
+#if defined(SJ_DEBUG_BOUNDS)
+    if (off > p.strings_len || len > p.strings_len - off) {
+        bounds_report(A_STRINGS, off + len, p.strings_len);
+        off = 0;
+    }
+#else
+    (void)len;
+#endif
+    return p.strings + off;
+}
 // hash of a string for the de-duplication table (any deterministic function: equal bytes are compared afterwards)
 __device__ __forceinline__ u32 ser_hash(const u8 *p, u64 len) {
     u64 h = 0x9e3779b97f4a7c15ull ^ len;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_ser_tile(SerView p) {
         if (dedup && t == '"') {
             const u64 so = w[k] & PAYLOAD & ~STRINGBUFBIT, sl = w[k + 1];
             if (sl != 0) {
-                slot[k] = ser_hash(p.strings + so, sl);
+                slot[k] = ser_hash(ser_string(p, so, sl), sl);
                 if (MODE == 0) {
                     atomicMin(&p.table[slot[k]], (u32)i);
                 } else {
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_ser_tile(SerView p) {
                         keep[k] = true;
                     } else {  // the first string of the slot lies in front of this one
                         const u64 fo = p.tape[first] & PAYLOAD & ~STRINGBUFBIT, fl = p.tape[first + 1];
-                        keep[k] = !(fl == sl && ser_equal(p.strings + fo, p.strings + so, sl));
+                        keep[k] = !(fl == sl && ser_equal(ser_string(p, fo, fl), ser_string(p, so, sl), sl));
                     }
                     if (keep[k]) nstr += sl;
                 }
@@ -200,7 +214,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_ser_tile(SerView p) {
         for (int k = 0; k < ST_ITEMS; k++) {
             if (!keep[k]) continue;
             const u64 so = w[k] & PAYLOAD & ~STRINGBUFBIT, sl = w[k + 1];
-            for (u64 b = 0; b < sl; b++) p.scol[co + b] = p.strings[so + b];
+            {
+                const u8 *src = ser_string(p, so, sl);
+                for (u64 b = 0; b < sl; b++) p.scol[co + b] = src[b];
+            }
             if (p.table[slot[k]] == (u32)(base + k)) p.slot_off[slot[k]] = (u32)co;
             co += sl;
         }
@@ -288,6 +305,7 @@ int sjhip_serialize_ex(sjhip_ctx *ctx, uint32_t flags, size_t *tags_len, size_t 
     p.tags = (u8 *)ctx->d_qstrings.p;
     p.table = p.slot_off = nullptr;
     p.strings = (const u8 *)ctx->d_strings.p;
+    p.strings_len = ctx->strings_len;
     p.scol = nullptr;
     if (dedup) {
         rc = arena_reserve(ctx, ctx->d_stab, (size_t)SER_SLOTS * 8);
@@ -321,6 +339,17 @@ int sjhip_serialize_ex(sjhip_ctx *ctx, uint32_t flags, size_t *tags_len, size_t 
         HIPCHK(hipStreamSynchronize(ctx->stream), "serialize sync");
         if (h[3] == 0) break;
     }
+#if defined(SJ_DEBUG_BOUNDS)
+    {   // debug build: a string entry outside Strings.B fails the call (this translation unit's record, sj_bounds.h)
+        BoundsHit hit = {};
+        if (hipMemcpyFromSymbol(&hit, HIP_SYMBOL(g_bounds_hit), sizeof hit) == hipSuccess && hit.hits) {
+            const BoundsHit zero = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_hit), &zero, sizeof zero);
+            ctx_set_error(ctx, "bounds check (Serialize): %u out-of-bounds strings, the first at byte %llu of %llu", hit.hits, hit.index, hit.size);
+            return SJHIP_ERR_HIP;
+        }
+    }
+#endif
     ctx->ser_tags = (size_t)h[0];
     ctx->ser_vals = (size_t)h[1];
     ctx->ser_dedup = dedup;

@@ -2,7 +2,8 @@
 path behind a checked view, a violation fails the parse.  CPU: the product build says it is not a debug build and the
 parse kernels compile under the flag.  GPU: the debug library's self-test records its two deliberate violations, and
 documents of every kind parse to the oracle's result with no violation (tools/gpu_debug_bounds.sh runs the whole GPU
-suite on that build; profiles/r05_debug_bounds.txt keeps the run).  Round 5: the views of query.hip are checked as well."""
+suite on that build; profiles/r05_debug_bounds.txt keeps the run).  Round 5: the views of query.hip are checked as well,
+and the string bytes that marshal.hip / serialize.hip reach through a tape word (ms_string, ser_string)."""
 import os
 import subprocess
 import sys
@@ -94,6 +95,38 @@ for copy in (True, False):
 tw = fixtures.load('twitter')
 ctx.parse(tw)
 assert ctx.count_where_path((b'search_metadata', b'count'), ctx.OP_EQ_INT, 100) == 1
+print('ok')
+""" % (PKG, HERE)
+    env = dict(os.environ, SJHIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith(b"ok"), (out.stdout[-2000:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_marshal_and_serialize_run_clean_on_the_debug_build():
+    """MarshalJSON and Serialize form a pointer into Strings.B (or the message, without copy) from the offset a tape word
+    holds and the length in front of the bytes; the debug build checks both (ms_string, ser_string) and fails the call."""
+    import __graft_entry__ as G
+    lib = G.build_lib(debug_bounds=True)
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import fixtures, oracle_lib as O, sjhip
+assert sjhip.lib().sjhip_debug_bounds_selftest() == 2
+ctx = sjhip.Context(0)
+for name in ('twitter', 'twitterescaped', 'parking-citations', 'canada'):
+    data, nd = fixtures.load(name), name == 'parking-citations'
+    for copy in (True, False):
+        ref = O.parse(data, ndjson=nd, copy_strings=copy)
+        ctx.parse(data, ndjson=nd, copy_strings=copy)
+        rc, want = O.marshal_json(ref.tape, ref.strings, data[ref.msg_off:ref.msg_off + ref.msg_len])
+        assert rc == 0 and bytes(ctx.marshal_json()) == bytes(want), (name, copy)
+        if copy:
+            for dedup in (False, True):
+                stream = ctx.serialize(dedup=dedup)
+                rc, tape2, strs2, msg2 = O.deserialize(stream)
+                assert rc == 0 and len(tape2) == len(ref.tape), (name, dedup)   # (test_gpu_serialize.py compares the contents)
 print('ok')
 """ % (PKG, HERE)
     env = dict(os.environ, SJHIP_LIB=lib)
