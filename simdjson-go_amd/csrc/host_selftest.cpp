@@ -746,7 +746,18 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
 extern "C" void sj_selftest_free(void *p) { free(p); }
 
 // number formatting of the tape -> JSON text path (sj_ftoa.h): appendFloat / AppendInt / AppendUint
-extern "C" unsigned sj_selftest_format_float(uint64_t bits, uint8_t *out32) { return format_float(bits, out32); }
+// the text of a float64; also checked here: exactly the bytes of the text are written (k_ms_tile formats straight into the
+// tile's window, where the next entry's text follows) and the length-only form agrees -- 0x80000000 is set otherwise
+extern "C" unsigned sj_selftest_format_float(uint64_t bits, uint8_t *out32) {
+    uint8_t tmp[40];
+    memset(tmp, 0xee, sizeof tmp);
+    const unsigned n = format_float(bits, tmp);
+    unsigned bad = n > 25 || float_text_len(bits) != n ? 0x80000000u : 0u;
+    for (unsigned k = n; k < sizeof tmp && n <= 25; k++)
+        if (tmp[k] != 0xee) bad = 0x80000000u;
+    memcpy(out32, tmp, 32);
+    return n | bad;
+}
 extern "C" unsigned sj_selftest_format_int(uint64_t raw, int is_unsigned, uint8_t *out24) {
     return is_unsigned ? format_uint(raw, out24) : format_int(raw, out24);
 }

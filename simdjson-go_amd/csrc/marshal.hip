@@ -391,8 +391,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     for (u32 j = (u32)tid; j < n_flt; j += TW_THREADS) {
         const u32 idx = s_qn[MS_QCAP - 1 - j] & 0x7ffu;
-        u8 tmp[32];
-        const u32 nl = format_float(p.tape[tb + idx + 1], tmp);
+        const u32 nl = float_text_len(p.tape[tb + idx + 1]);
         if (nl == 0) bad = true;  // Inf / NaN: "INF or NaN number found"
         s_len[idx] += nl;
     }
@@ -525,10 +524,8 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     for (u32 j = (u32)tid; j < n_flt; j += TW_THREADS) {
         const u32 e = s_qn[MS_QCAP - 1 - j], idx = e & 0x7ffu;
-        u8 tmp[32];  // format_float writes up to 32 bytes: not straight into the neighbours' text
-        const u32 nl = format_float(p.tape[tb + idx + 1], tmp);
         u8 *o = tbase + s_len[idx];
-        for (u32 q = 0; q < nl; q++) o[q] = tmp[q];
+        const u32 nl = format_float(p.tape[tb + idx + 1], o);  // (exactly the bytes of the text: straight into the tile's window)
         if ((e >> 11) & 1u) o[nl] = ',';
     }
     const u64 key_base = p.kf_tape ? 0 : p.cnt_s[tile];
@@ -617,12 +614,14 @@ template <int MODE>
 static void launch_ms_tile(const MsView &p, hipStream_t st) {
     const dim3 g(p.tiles), b(TW_THREADS);
     switch (ms_variant()) {
-        case 0: hipLaunchKernelGGL((k_ms_tile<MODE, 4, MS_WINDOW>), g, b, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW>), g, b, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 2>), g, b, 0, st, p); break;
+        // (the second template argument is the occupancy the LDS of that window leaves: asking for more only earns hipcc's
+        // "failed to meet occupancy target" -- the registers were never the limit, 80-91 VGPRs without scratch)
+        case 0:
+        case 1: hipLaunchKernelGGL((k_ms_tile<MODE, 3, MS_WINDOW>), g, b, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((k_ms_tile<MODE, 4, MS_WINDOW / 2>), g, b, 0, st, p); break;
         case 4: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
-        case 5: hipLaunchKernelGGL((k_ms_tile<MODE, 6, 19456u>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ms_tile<MODE, 6, 21504u>), g, b, 0, st, p); break;  // the largest window with four blocks per CU
+        case 5: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 19456u>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 21504u>), g, b, 0, st, p); break;  // the largest window with four blocks per CU
     }
 }
 }  // namespace

@@ -99,13 +99,12 @@ __device__ __forceinline__ bool ser_equal(const u8 *a, const u8 *b, u64 len) {
 __global__ __launch_bounds__(1024) void k_ser_scan_cnt(unsigned long long *cnt_a, unsigned long long *cnt_b,
                                                        unsigned long long *cnt_c, u32 tiles, unsigned long long *totals) {
     __shared__ long long s_w[16];
-    const long long ta = block1024_scan_array<false>((long long *)cnt_a, tiles, s_w, (int)threadIdx.x);
-    const long long tb = block1024_scan_array<false>((long long *)cnt_b, tiles, s_w, (int)threadIdx.x);
-    const long long tc = cnt_c ? block1024_scan_array<false>((long long *)cnt_c, tiles, s_w, (int)threadIdx.x) : 0;
-    if (threadIdx.x == 0) {
-        totals[0] = (unsigned long long)ta;
-        totals[1] = (unsigned long long)tb;
-        totals[2] = (unsigned long long)tc;
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {  // (one copy of the scan: three inlined ones spilled 84 bytes per lane under the 1024-thread bound)
+        unsigned long long *const cnt = k == 0 ? cnt_a : (k == 1 ? cnt_b : cnt_c);
+        const long long t = cnt ? block1024_scan_array<false>((long long *)cnt, tiles, s_w, (int)threadIdx.x) : 0;
+        if (threadIdx.x == 0) totals[k] = (unsigned long long)t;
+        __syncthreads();
     }
 }
 

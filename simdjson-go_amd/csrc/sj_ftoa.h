@@ -25,11 +25,6 @@ __device__ __constant__ static const u64 POW10_128[(POW10_MAX_Q - POW10_MIN_Q + 
 static const u64 POW10_128[(POW10_MAX_Q - POW10_MIN_Q + 1) * 2] = SJ_POW10_TABLE_INIT;
 #endif
 
-struct Digits {  // value = 0.d[0]d[1]...d[nd-1] * 10^dp, no trailing zeros (nd == 0: zero)
-    u8 d[24];
-    int nd, dp;
-};
-
 // ---- shortest round-trip digits ----------------------------------------------------------------------------------
 // Any correct shortest-digits routine prints the same digits as the reference's copy of Go's strconv (the shortest
 // decimal that reads back as the same float64, the closest such one, ties to even).  This one works on the rounding
@@ -88,42 +83,69 @@ SJ_HD void shortest_decimal(u64 c, int q, bool narrow, u64 *dec, int *k10) {
     *dec = s + (round_up ? 1u : 0u);
 }
 
-// eight decimal digits of x < 10^8, most significant first, without a loop (two four-digit halves, two two-digit quarters)
-SJ_HD void digits8(u32 x, u8 *out) {
+// The decimal digits live in REGISTERS (round 5: the byte buffers this file used to fill -- 17 digits, the trimmed window, the
+// caller's 32-byte text -- were 80 bytes of scratch per lane in k_ms_tile): eight digits of x < 10^8 as the bytes of one
+// 64-bit word, most significant digit in byte 0, values 0..9 (two four-digit halves, two two-digit quarters, no loop)
+SJ_HD u64 digits8(u32 x) {
     const u32 hi = x / 10000u, lo = x - hi * 10000u;
     const u32 a = hi / 100u, b = hi - a * 100u, c = lo / 100u, d = lo - c * 100u;
-    out[0] = (u8)('0' + a / 10u); out[1] = (u8)('0' + a % 10u);
-    out[2] = (u8)('0' + b / 10u); out[3] = (u8)('0' + b % 10u);
-    out[4] = (u8)('0' + c / 10u); out[5] = (u8)('0' + c % 10u);
-    out[6] = (u8)('0' + d / 10u); out[7] = (u8)('0' + d % 10u);
+    const u32 w0 = (a / 10u) | (a % 10u) << 8 | (b / 10u) << 16 | (b % 10u) << 24;
+    const u32 w1 = (c / 10u) | (c % 10u) << 8 | (d / 10u) << 16 | (d % 10u) << 24;
+    return (u64)w0 | ((u64)w1 << 32);
+}
+SJ_HD int low_byte_index(u64 v) {  // index of the lowest non-zero byte (v != 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(__ffsll((unsigned long long)v) - 1) >> 3;
+#else
+    return __builtin_ctzll(v) >> 3;
+#endif
+}
+SJ_HD int high_byte_index(u64 v) {  // index of the highest non-zero byte (v != 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (63 - __clzll((long long)v)) >> 3;
+#else
+    return (63 - __builtin_clzll(v)) >> 3;
+#endif
 }
 
+// value = 0.d(0)d(1)...d(nd-1) * 10^dp, no trailing zeros (nd == 0: zero); the 17 digits of dec < 10^17 are `top`, the
+// bytes of `a` (digits 1..8) and the bytes of `b` (digits 9..16), d(0) is digit `first`
+struct Digits {
+    u64 a, b;
+    u32 top;
+    int first, nd, dp;
+    SJ_HD u8 digit(int i) const {  // ASCII of d(i), 0 <= i < nd
+        const int k = first + i;
+        const u32 v = k == 0 ? top : (u32)((k < 9 ? a >> (8 * (k - 1)) : b >> (8 * (k - 9))) & 0xffu);
+        return (u8)('0' + v);
+    }
+};
+
 // the digits of mant * 2^exp2 (mant != 0 unless the value is zero; denormals come with their own exponent)
-SJ_HD void shortest_digits(Digits *d, u64 mant, int exp2, bool narrow) {
-    d->nd = 0;
-    d->dp = 0;
-    if (mant == 0) return;
+SJ_HD Digits shortest_digits(u64 mant, int exp2, bool narrow) {
+    Digits d{0, 0, 0, 0, 0, 0};
+    if (mant == 0) return d;
     u64 dec;
     int k10;
     shortest_decimal(mant, exp2, narrow, &dec, &k10);
-    // dec < 10^17: 1 + 8 + 8 digits into a fixed buffer, then the window between the first and the last non-zero digit
-    u8 buf[24];
+    // 0 < dec < 10^17: 1 + 8 + 8 digits, then the window between the first and the last non-zero digit
     const u64 top = dec / 100000000ull;           // < 10^9
     const u32 low8 = (u32)(dec - top * 100000000ull);
-    const u32 top1 = (u32)(top / 100000000ull);   // the 17th digit
-    buf[0] = (u8)('0' + top1);
-    digits8((u32)(top - (u64)top1 * 100000000ull), buf + 1);
-    digits8(low8, buf + 9);
-    int first = 0, last = 16;
-    while (first < 16 && buf[first] == '0') first++;
-    while (last > first && buf[last] == '0') last--;
-    d->nd = last - first + 1;
-    for (int i = 0; i < d->nd; i++) d->d[i] = buf[first + i];
-    d->dp = k10 + (17 - first);  // dec has 17 - first digits: value = 0.d... * 10^(k10 + digits)
+    d.top = (u32)(top / 100000000ull);            // the 17th digit
+    d.a = digits8((u32)(top - (u64)d.top * 100000000ull));
+    d.b = digits8(low8);
+    d.first = d.top ? 0 : (d.a ? 1 + low_byte_index(d.a) : 9 + low_byte_index(d.b));
+    const int last = d.b ? 9 + high_byte_index(d.b) : (d.a ? 1 + high_byte_index(d.a) : 0);
+    d.nd = last - d.first + 1;
+    d.dp = k10 + (17 - d.first);  // dec has 17 - first digits: value = 0.d... * 10^(k10 + digits)
+    return d;
 }
 
-// appendFloat (parsed_json.go:1250-1272): `out` needs 32 bytes; returns the length, 0 for Inf / NaN (an error there)
-SJ_HD u32 format_float(u64 bits, u8 *out) {
+// appendFloat (parsed_json.go:1250-1272): exactly the bytes of the text are written (at most 25: sign, 17 digits, '.',
+// "e-308"; %f prints at most 21 digits in front of the point or "0." and 5 zeros and 17 digits behind it); returns the
+// length, 0 for Inf / NaN (an error there).  WRITE = false: the length alone (the counting pass of k_ms_tile).
+template <bool WRITE>
+SJ_HD u32 format_float_t(u64 bits, u8 *out) {
     const bool neg = (bits >> 63) != 0;
     int exp = (int)((bits >> 52) & 0x7ff);
     u64 mant = bits & ((1ull << 52) - 1);
@@ -131,65 +153,59 @@ SJ_HD u32 format_float(u64 bits, u8 *out) {
     if (exp == 0) exp++;         // denormal
     else mant |= 1ull << 52;
     exp += -1023;
-    Digits d;
     // below a power of two the interval's lower half is narrower (not for the smallest normal exponent and denormals)
-    shortest_digits(&d, mant, exp - 52, (bits & ((1ull << 52) - 1)) == 0 && ((bits >> 52) & 0x7ff) > 1);
+    const Digits d = shortest_digits(mant, exp - 52, (bits & ((1ull << 52) - 1)) == 0 && ((bits >> 52) & 0x7ff) > 1);
     u32 n = 0;
-    if (neg) out[n++] = '-';
+    auto put = [&](u8 c) {
+        if (WRITE) out[n] = c;
+        n++;
+    };
+    if (neg) put('-');
     // abs >= 1e-6 && abs < 1e21, or zero  <=>  %f  (the comparisons are exact on the decimal exponent of the
     // shortest digits: abs < 1e21 <=> dp <= 21, abs >= 1e-6 <=> dp >= -5, because 1e21 and 1e-6 round-trip as "1")
     const u64 absbits = bits & 0x7fffffffffffffffull;
     const bool use_f = absbits == 0 || (absbits >= 0x3eb0c6f7a0b5ed8dull /* 1e-6 */ && absbits < 0x444b1ae4d6e2ef50ull /* 1e21 */);
     if (use_f) {  // fmtF with prec = max(nd - dp, 0) (appendfloat_f.go:43-84)
+        const int prec = d.nd - d.dp > 0 ? d.nd - d.dp : 0;
+        if (!WRITE) return n + (u32)(d.dp > 0 ? d.dp : 1) + (prec > 0 ? 1u + (u32)prec : 0u);
         if (d.dp > 0) {
             const int m = d.nd < d.dp ? d.nd : d.dp;
-            for (int k = 0; k < m; k++) out[n++] = d.d[k];
-            for (int k = m; k < d.dp; k++) out[n++] = '0';
+            for (int k = 0; k < m; k++) put(d.digit(k));
+            for (int k = m; k < d.dp; k++) put('0');
         } else {
-            out[n++] = '0';
+            put('0');
         }
-        const int prec = d.nd - d.dp > 0 ? d.nd - d.dp : 0;
         if (prec > 0) {
-            out[n++] = '.';
+            put('.');
             for (int i = 0; i < prec; i++) {
                 const int j = d.dp + i;
-                out[n++] = (0 <= j && j < d.nd) ? d.d[j] : (u8)'0';
+                put((0 <= j && j < d.nd) ? d.digit(j) : (u8)'0');
             }
         }
         return n;
     }
-    // strconv 'e' with the shortest precision (fmtE): first digit, '.', the rest, 'e', sign, >= 2 exponent digits
-    out[n++] = d.nd > 0 ? d.d[0] : (u8)'0';
-    if (d.nd > 1) {
-        out[n++] = '.';
-        for (int k = 1; k < d.nd; k++) out[n++] = d.d[k];
-    }
-    out[n++] = 'e';
+    // strconv 'e' with the shortest precision (fmtE): first digit, '.', the rest, 'e', sign, >= 2 exponent digits --
+    // but "e-09" is cleaned up to "e-9" (parsed_json.go:1265-1270: the text ends with 'e', '-', '0', digit exactly for the
+    // negative one-digit exponents; positive exponents start at 21 here)
     int e = d.nd == 0 ? 0 : d.dp - 1;
-    if (e < 0) {
-        out[n++] = '-';
-        e = -e;
-    } else {
-        out[n++] = '+';
+    const bool eneg = e < 0;
+    if (eneg) e = -e;
+    const u32 elen = e >= 100 ? 3u : ((e >= 10 || !eneg) ? 2u : 1u);
+    if (!WRITE) return n + 1u + (d.nd > 1 ? (u32)d.nd : 0u) + 2u + elen;
+    put(d.nd > 0 ? d.digit(0) : (u8)'0');
+    if (d.nd > 1) {
+        put('.');
+        for (int k = 1; k < d.nd; k++) put(d.digit(k));
     }
-    if (e < 10) {
-        out[n++] = '0';
-        out[n++] = (u8)('0' + e);
-    } else if (e < 100) {
-        out[n++] = (u8)('0' + e / 10);
-        out[n++] = (u8)('0' + e % 10);
-    } else {
-        out[n++] = (u8)('0' + e / 100);
-        out[n++] = (u8)('0' + (e / 10) % 10);
-        out[n++] = (u8)('0' + e % 10);
-    }
-    // clean up e-09 to e-9 (parsed_json.go:1265-1270)
-    if (n >= 4 && out[n - 4] == 'e' && out[n - 3] == '-' && out[n - 2] == '0') {
-        out[n - 2] = out[n - 1];
-        n--;
-    }
+    put('e');
+    put(eneg ? '-' : '+');
+    if (elen == 3) put((u8)('0' + e / 100));
+    if (elen >= 2) put((u8)('0' + (e / 10) % 10));
+    put((u8)('0' + e % 10));
     return n;
 }
+SJ_HD u32 format_float(u64 bits, u8 *out) { return format_float_t<true>(bits, out); }
+SJ_HD u32 float_text_len(u64 bits) { return format_float_t<false>(bits, nullptr); }
 
 // strconv.AppendUint / AppendInt, base 10: exactly the digits are written (`out` needs up to 20 bytes)
 SJ_HD u32 digit_count(u64 v) {

@@ -56,6 +56,7 @@ def go_format(x):
 def fmt(L, bits):
     buf = C.create_string_buffer(40)
     n = L.sj_selftest_format_float(bits, buf)
+    assert n < 0x80000000, hex(bits)   # (bytes behind the text were written, or the length-only form disagrees)
     return buf.raw[:n].decode()
 
 

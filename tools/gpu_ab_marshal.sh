@@ -5,6 +5,6 @@
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2; do
 for lib in $(ls build_ab/libsjhip_ms_*.so); do
-for w in parking twitter; do
+for w in ${MS_WORKLOADS:-parking twitter}; do
 echo -n "$lib "; SJHIP_LIB=$PWD/$lib timeout 200 python tools/marshal_loop.py $w 5 kf 2>&1 | grep marshal_json
 done; done; done

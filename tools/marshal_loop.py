@@ -1,5 +1,5 @@
 """Parse one BASELINE workload once, then MarshalJSON / Serialize / Deserialize of the resident result in a loop (for
-rocprofv3): python tools/marshal_loop.py twitter|parking [iters]"""
+rocprofv3): python tools/marshal_loop.py twitter|parking|canada [iters] [kf]"""
 import os
 import sys
 import time
@@ -15,6 +15,9 @@ which = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if which == "twitter":
     doc, nd = workloads.c2_twitter_array(426), False
+elif which == "canada":  # floats: 20 copies of canada.json in one array (45 MB)
+    import fixtures
+    doc, nd = b"[" + b",".join([fixtures.load("canada")] * 20) + b"]", False
 else:
     doc, nd = workloads.c5_parking_nd(1000).rstrip(b"\n"), True
 d = torch.empty(len(doc) + 256, dtype=torch.uint8, device="cuda:0")
