@@ -290,6 +290,26 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
         const u64 c = unit * 64 + lane;
         const u32 uh = p.sv.unit_h[unit], uhp = unit ? (u32)p.sv.unit_h[unit - 1] : 0u;
         const u32 h = uh & 1u;
+        if (SEL && !slow && !(uh & 2u)) {  // (uniform) no escape starter in the unit: nothing of it is copied unless a string that
+            // crosses one of its ends holds a starter elsewhere -- decided on the unit flags alone, no mask of this unit is read
+            // (parking-citations: every unit).  "Open at the start" = the state stage 1 left (a superset of the predicate
+            // below -- it also holds when byte 0 closes the string, where the answer changes nothing); "open at the end" = the
+            // state at the start of the next unit, the same bit the masks give.
+            const bool open_in = h != 0, open_out = unit + 1 < p.units && (p.sv.unit_h[unit + 1] & 1u) != 0;
+            bool giveup = false;
+            const u32 fin = open_in ? sel_unit_in(p, unit, lane, giveup) : 0u;
+            u32 tq = 0;
+            const u32 gout = open_out ? sel_unit_out(p, unit, lane, giveup, &tq) : 0u;
+            if (!fin && !gout) {
+                if (lane == 0) {
+                    p.unit_cnt[unit] = 0;
+                    p.unit_copy[unit] = 0;
+                    p.unit_tq[unit] = tq;
+                    if (giveup) atomicOr(&p.st->err, S2_ERR_SERIAL_STRINGS);
+                }
+                continue;
+            }
+        }
         const u64 qm = p.sv.qm[c], q = p.sv.q[c];
         const u64 st = (uh & 2u) ? p.sv.st[c] : 0ull;
         const u64 stp = (c && ((lane ? uh : uhp) & 2u)) ? p.sv.st[c - 1] >> 63 : 0ull;
