@@ -6,17 +6,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import __graft_entry__ as G  # noqa: E402
-
 CS = os.path.join(ROOT, "simdjson-go_amd", "csrc")
-srcs = sorted(f for f in os.listdir(CS) if f.endswith(".hip"))
-print("# %-14s %-86s %5s %8s %5s %7s" % ("file", "kernel", "VGPRs", "scratch", "occ", "LDS"))
-for f in srcs:
+
+
+def kernels_of(src, flags=()):
+    """[(kernel, VGPRs, scratch bytes per lane, waves per SIMD, LDS bytes per block)] of one .hip file"""
     out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
-                          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CS, f)],
+                          "-Rpass-analysis=kernel-resource-usage", *flags, "-o", os.devnull, os.path.join(CS, src)],
                          capture_output=True, text=True).stderr
-    cur = {}
+    rows, cur = [], {}
     for line in out.splitlines():
         m = re.search(r"remark: +(Function Name|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
         if not m:
@@ -29,4 +27,12 @@ for f in srcs:
             name = subprocess.run(["c++filt", cur["name"]], capture_output=True, text=True).stdout.strip()
             name = name.replace("(anonymous namespace)::", "").replace("sj::", "").replace("void ", "")
             name = re.sub(r"\((?!.*>).*$", "", name)  # drop the argument list (behind the last template bracket)
-            print("%-16s %-86s %5s %8s %5s %7s" % (f, name[:86], cur["VGPRs"], cur["ScratchSize"], cur["Occupancy"], cur["LDS"]))
+            rows.append((name, int(cur["VGPRs"]), int(cur["ScratchSize"]), int(cur["Occupancy"]), int(cur["LDS"])))
+    return rows
+
+
+if __name__ == "__main__":
+    print("# %-14s %-86s %5s %8s %5s %7s" % ("file", "kernel", "VGPRs", "scratch", "occ", "LDS"))
+    for f in sorted(f for f in os.listdir(CS) if f.endswith(".hip")):
+        for name, vgprs, scratch, occ, lds in kernels_of(f):
+            print("%-16s %-86s %5d %8d %5d %7d" % (f, name[:86], vgprs, scratch, occ, lds))
