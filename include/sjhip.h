@@ -177,7 +177,8 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
  *                          EXISTS; EQ_STRING (value = vlen bytes, compared after unescaping, Iter.StringBytes);
  *                          EQ_INT / EQ_UINT / EQ_FLOAT (value = an int64_t / uint64_t / double, vlen 8; the element is
  *                          converted the way Iter.Int / Uint / Float convert between the three number tags,
- *                          parsed_json.go:560-727); EQ_BOOL (value = one byte); IS_NULL.  8 bytes cross PCIe.
+ *                          parsed_json.go:560-727 -- with the amd64 results at the two edges the reference lets through:
+ *                          a float of exactly 2^63 is MinInt64 for EQ_INT, one of exactly 2^64 is 0 for EQ_UINT); EQ_BOOL (value = one byte); IS_NULL.  8 bytes cross PCIe.
  *   sjhip_project_keys     Object.ForEach(fn, onlyKeys) (parsed_object.go:142-196) on the root object of every record: the
  *                          members whose key is in the set, in document order, at most n_keys of them (the reference stops
  *                          after len(onlyKeys) deliveries).  out[r * n_keys + j] = key number << 56 | tape index of the
@@ -222,7 +223,8 @@ int sjhip_fetch_message(sjhip_ctx *ctx, uint8_t *dst);
  * The device-resident result of the last parse as compact JSON text, records separated by '\n' -- byte for byte what
  * pj.Iter().MarshalJSON() returns: escapeBytes for strings, strconv.AppendInt / AppendUint, appendFloat (the reference's
  * copy of Go's Ryu shortest formatting with its ES6-style %f / %e choice).  The text stays on the device until
- * sjhip_fetch_marshaled copies it into `dst` (>= text_len bytes). */
+ * sjhip_fetch_marshaled copies it into `dst` (>= text_len bytes).  SJHIP_ERR_TOOBIG for a document of 4 GiB or more that was
+ * parsed without SJHIP_FLAG_COPY_STRINGS (the strings that are not copied then lie at message offsets beyond 32 bits). */
 int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len);
 int sjhip_fetch_marshaled(sjhip_ctx *ctx, uint8_t *dst);
 

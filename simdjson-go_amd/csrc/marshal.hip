@@ -652,6 +652,12 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
         ctx_set_error(ctx, "no parse result on the device (sjhip_marshal_json follows a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;
     }
+    if (ctx->p_len >= (1ull << 32) && !(ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) {
+        // k_ms_tile keeps the offset of a string in 32 bits of its queue entry: with WithCopyStrings(false) the strings that are not
+        // copied lie at MESSAGE offsets, which pass 2^32 in a document of 4 GiB or more (Strings.B itself is checked to stay below)
+        ctx_set_error(ctx, "sjhip_marshal_json: a document of 4 GiB or more parsed without SJHIP_FLAG_COPY_STRINGS (message offsets beyond 32 bits)");
+        return SJHIP_ERR_TOOBIG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->ser_valid = 0;  // shares d_q with the serializer and the filter
     ctx->q_tape_len = ctx->q_strings_len = 0;

@@ -67,6 +67,7 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
 // the tape length in words, the length of Strings.B, the distance between two neighbouring tokens -- a document beyond one of
 // those is SJHIP_ERR_TOOBIG / a failed parse, as is a document beyond SINGLE_LIMIT.
 static constexpr size_t ND_LIMIT = 0xffffffc0ull - 64;
+static constexpr size_t TOKEN_LIMIT = 0xfffffff0ull;   // tokens (structural indexes) of one context's parse: 32-bit token indexes in stage 2
 static constexpr size_t SINGLE_LIMIT = (size_t)1 << 38;  // 256 GiB: the positions' workspace alone is 5 bytes per message byte
 static size_t env_bytes(const char *name, size_t dflt) {
     const char *e = getenv(name);
@@ -174,6 +175,10 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         if (rc) return rc;
     }
     if (!ok) return SJHIP_ERR_STAGE1;
+    if (n >= TOKEN_LIMIT) {  // (stage 1 counts in 40 bits; the token kernels index tokens with 32)
+        ctx_set_error(ctx, "document of %zu tokens: one context parses fewer than 2^32", n);
+        return SJHIP_ERR_TOOBIG;
+    }
     int rc = arena_reserve(ctx, ctx->d_s2, stage2_workspace_bytes(n));
     if (rc) return rc;
     rc = arena_reserve(ctx, ctx->d_tape, (2 * n + 2) * sizeof(uint64_t));
@@ -268,6 +273,10 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         rc = stage1_collect(ctx, ctx->p_len, ctx->p_last, ctx->p_have_last, &n, &ok);
         if (rc) return rc;
         if (!ok) return SJHIP_ERR_STAGE1;
+        if (n >= TOKEN_LIMIT) {
+            ctx_set_error(ctx, "document of %zu tokens: one context parses fewer than 2^32", n);
+            return SJHIP_ERR_TOOBIG;
+        }
         if (n > ctx->p_nlay) return PARSE_AGAIN_SYNCHRONOUS;  // denser than the layout assumed: nothing of this run counts
         ctx->p_n = n;  // (the arrays stay laid out for p_nlay)
     }
@@ -289,12 +298,18 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
         return SJHIP_ERR_HIP;
     }
     if (hs->err & 4u) {
-        ctx_set_error(ctx, "tape longer than 2^32 words, or Strings.B longer than 4 GiB");
+        ctx_set_error(ctx, "tape longer than 2^32 words, Strings.B longer than 4 GiB, or a 4096-token tile that spans 4 GiB of the message");
         return SJHIP_ERR_TOOBIG;
     }
     if (hs->err) return SJHIP_ERR_STAGE2;
     // the token density of this parse (tokens per KiB, rounded up): what the next large parse of the context is laid out for
-    if (ctx->p_len) ctx->p_density_q = (uint32_t)(((unsigned __int128)ctx->p_n * 1024 + ctx->p_len - 1) / ctx->p_len) + 1;
+    // (only LARGE parses leave one -- a small sparse document in between must not send the next large dense one through a
+    // layout that fails and a second run of both stages -- and a sparser large document lowers it only half way: the price of
+    // too large a layout is a few empty blocks per grid, the price of too small a one is the whole parse twice)
+    if (ctx->p_len > small_document_bytes()) {
+        const uint32_t dq = (uint32_t)(((unsigned __int128)ctx->p_n * 1024 + ctx->p_len - 1) / ctx->p_len) + 1;
+        ctx->p_density_q = dq >= ctx->p_density_q ? dq : (uint32_t)(((uint64_t)dq + ctx->p_density_q + 1) / 2);
+    }
     ctx->tape_len = (size_t)hs->tape_len;
     ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;

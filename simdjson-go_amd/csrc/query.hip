@@ -447,9 +447,14 @@ __device__ bool element_is(const QView &q, u64 v, int op, u64 want) {
         if (t == 'u') return raw == want;
         if (t == 'l') return (long long)raw >= 0 && raw == want;
         if (t == 'd') {
+            // Iter.Uint (parsed_json.go:679-692): an error only for v > math.MaxUint64 -- which as a float64 constant is 2^64 --
+            // and for v < 0; uint64(v) of exactly 2^64 is the amd64 conversion's result: (v - 2^63) converts to the integer
+            // indefinite 0x8000000000000000, XORed with the sign bit = 0 (the mirror image of EQ_INT's 2^63 edge above)
             const double d = __longlong_as_double((long long)raw);
-            if (!(d >= 0.0) || !(d < 18446744073709551616.0)) return false;
-            return (u64)d == want;
+            if (d != d) return want == 0x8000000000000000ull;  // NaN never reaches the tape (parse_number rejects it); amd64: indefinite
+            if (d < 0.0 || d > 18446744073709551616.0) return false;
+            const u64 uv = d >= 18446744073709551616.0 ? 0ull : (u64)d;
+            return uv == want;
         }
         return false;
     }

@@ -26,7 +26,8 @@ enum ArrId : uint32_t {
     A_LEV, A_TAPE, A_STRINGS, A_STR_OUT, A_REC, A_UNIT_CNT, A_SV_BASE, A_SV_QM, A_SV_Q, A_SV_ST, A_SV_UNIT_H, A_SV_UNIT_SLOW,
     A_SELFTEST, A_KEYFLAG,
     A_UNIT_COPY, A_S1_POS, A_S1_KIND, A_S1_QM, A_S1_Q, A_S1_ST, A_S1_UNIT_H, A_S1_UNIT_SLOW,  // stage 1's outputs (stage1.hip)
-    A_S1_REC, A_S1_UNIT_CNT, A_S1_UNIT_COPY, A_S1_UNIT_STR, A_UNIT_STR, A_SOFF
+    A_S1_REC, A_S1_UNIT_CNT, A_S1_UNIT_COPY, A_S1_UNIT_STR, A_UNIT_STR, A_SOFF,
+    A_S1_TILE_UNIT, A_TILE_UNIT, A_UNIT_TQ
 };
 
 #if defined(SJ_DEBUG_BOUNDS)

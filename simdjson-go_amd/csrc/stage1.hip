@@ -438,7 +438,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
-        if (AUX && aux.qm && unit_off < end && !SJ_S1EXP(aux, 8)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+        if (AUX && aux.qm && unit_off < end && !SJ_S1EXP(aux, 16)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.q[ci] = quote_bits;
@@ -452,7 +452,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             // the fast formula; units with a \u escape are counted again by k_measure) and opening quotes of the unit under
             // hypothesis 0, and under either hypothesis together (the two sets are disjoint: the other one is the difference)
             uint2 tot = make_uint2(0u, 0u);
-            if (aux.unit_str && unit_off < end) {  // (uniform)
+            if (aux.unit_str && unit_off < end && !SJ_S1EXP(aux, 18)) {  // (uniform)
                 const u64 nqst = ~quote_bits & ~starters;
                 const u32 cnt = wave_incl_scan((u32)popc64(qm & nqst) | ((u32)popc64(nqst) << 16));
                 const u32 opn = wave_incl_scan((u32)popc64(qm & quote_bits) | ((u32)popc64(quote_bits) << 16));
@@ -580,7 +580,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
                     const uint2 e2 = *reinterpret_cast<const uint2 *>(stage + i);
                     const u32 e0 = e2.x & 0xffffu, e1 = e2.x >> 16, e3 = e2.y >> 16, e2v = e2.y & 0xffffu;
                     *reinterpret_cast<uint4 *>(arr_at(out_pos, gd + i, 4)) = make_uint4(ubase + e0, ubase + e1, ubase + e2v, ubase + e3);
-                    *reinterpret_cast<u32 *>(arr_at(kind_out, gd + i, 4)) = kind_of(e0) | (kind_of(e1) << 8) | (kind_of(e2v) << 16) | (kind_of(e3) << 24);
+                    if (!SJ_S1EXP(aux, 17)) *reinterpret_cast<u32 *>(arr_at(kind_out, gd + i, 4)) = kind_of(e0) | (kind_of(e1) << 8) | (kind_of(e2v) << 16) | (kind_of(e3) << 24);
                 }
                 for (u32 i = c4 + (u32)lane; i < cnt; i += 64) {  // the last <= 3 (or, without room for all, everything)
                     if (fits || gd + i < pos_cap) {
@@ -1174,7 +1174,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
         aux.unit_cnt = SJ_ARR(a.unit_cnt, a.units, A_S1_UNIT_CNT);
         aux.unit_str = SJ_ARR(a.unit_str, a.units, A_S1_UNIT_STR);
-        aux.tile_unit = SJ_ARR(a.tile_unit, a.units + 1, A_S1_UNIT_STR);
+        aux.tile_unit = SJ_ARR(a.tile_unit, a.units + 1, A_S1_TILE_UNIT);
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \

@@ -1247,6 +1247,12 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
         tbase = (u64)p.tile_unit[blockIdx.x] * 4096u + (((u64)first + p.sv.lead) & 4095u) - p.sv.lead;
     }
     const u32 endpos = (u32)(p.len - tbase);
+    if (MASKS && WIDE && tid == 0) {  // the tile's offsets are 32-bit differences from its first token: a tile that spans 4 GiB or more cannot be rebuilt
+        const u64 nb = (u64)t0 + S2_TILE < n
+                           ? (u64)p.tile_unit[blockIdx.x + 1] * 4096u + (((u64)p.pos[t0 + S2_TILE] + p.sv.lead) & 4095u) - p.sv.lead
+                           : p.len;
+        if (nb - tbase >= (1ull << 32)) atomicOr(&p.st->err, 4u);
+    }
     {
         const u32 base = t0 + (u32)tid * ITEMS;
         u32 pp[ITEMS];
@@ -1321,7 +1327,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     bool bad = lane16_illegal(m);  // a token that is legal in no context at all
     const u32 SB = MASKS ? S + 1u : S, SC = SB + B + D;
     const bool y_staged = SC + S <= (u32)S2_TILE + 8u;  // (block-uniform)
-    if (MASKS) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
+    if (MASKS && !SJ_EXPBIT(p, 9)) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
         for (u32 j = (u32)tid; j <= S; j += BLK) {
             const bool in = tp.s + j < p.soff_cap;
             if (MODE == 2) {
@@ -1382,7 +1388,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
                 w0 = string_word(false, 0, p.msg_base + tbase + s_pos[(u32)tid * ITEMS + j] + 1);
                 w1 = (u64)(y_staged ? s_q[SC + ks] : (tp.s + ks < p.soff_cap ? p.sinfo[tp.s + ks].y : 0u));
             }
-            *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
+            if (!SJ_EXPBIT(p, 8)) *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
             if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((m.keystr >> j) & 1u);
         }
     }
@@ -1408,9 +1414,9 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     // here (sj_number.h parse_int_fast); only the others -- floats, long integers -- move to the global queue (k_numbers; the
     // order does not matter): a wave draws the slots of its queued numbers with one atomic (round 4 queued every number and
     // marked the parsed ones: 10 MB of entries on configs[1] that k_numbers read only to skip them)
-    for (u32 j = (u32)tid; j < D; j += BLK) {
+    for (u32 j = (u32)tid; j < (SJ_EXPBIT(p, 10) ? 0u : D); j += BLK) {
         const u32 v = s_q[SB + B + j], idx = v & 0xfffu, o = T0 + ((v >> 12) & 0x1fffu);
-        const u64 at = tbase + s_pos[idx];
+        const u64 at = SJ_EXPBIT(p, 11) ? (u64)(tid & 7) * 8u : tbase + s_pos[idx];
         const u8 ak = (u8)(8u + ((v >> 26) & 3u));
         bool slow = false;
         if (ak == K_NUM) {
@@ -1439,7 +1445,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     // device-wide form).  One rule for every bracket: the container of the gap in front of it -- the partner of a close, the
     // parent of an open -- is the bracket behind the last one in front with depth <= (depth in front - 1).  Depths here are
     // relative to the tile's start; a question that no bracket of the tile answers stays for k_br_match.
-    {
+    if (!SJ_EXPBIT(p, 12)) {
         const u32 G = (B + 63u) / 64u;
         for (u32 g = (u32)wave; g < G; g += WAVES) {  // the minimum depth of every group of 64
             const u32 c = g * 64u + (u32)lane;
@@ -1531,6 +1537,7 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
             // the compact bracket view of the whole message: every bracket keeps its depth (the matcher's questions pass
             // over it), only the live ones ask and write there
             const u32 cg = tp.bc + c;
+            if (SJ_EXPBIT(p, 13)) continue;
             p.br_depth[cg] = tp.d + drel;
             p.br_off[cg] = oc;
             p.br_info[cg] = (u8)(kd | (gap << 4) | (done ? BR_DONE : 0u));
@@ -1975,13 +1982,13 @@ static S2Dev stage2_view(const S2Args &a) {
         // the strings of the message are numbered, their Strings.B offsets go where the per-string fallback keeps its lengths
         // (dlen and str_off are adjacent: 2 x align_up(4n, 256) >= 4 (n + 2) bytes)
         p.unit_str = SJ_ARR(x.unit_str, x.units, A_UNIT_STR);
-        p.tile_unit = SJ_ARR((const u32 *)x.tile_unit, x.units + 1, A_UNIT_STR);
+        p.tile_unit = SJ_ARR((const u32 *)x.tile_unit, x.units + 1, A_TILE_UNIT);
         p.soff_cap = (u32)(n + 2 < 0xffffffffull ? n + 2 : 0xffffffffull);
         p.soff = SJ_ARR(arr_raw(p.dlen), p.soff_cap, A_SOFF);
         if (!p.copy_strings) {  // the states at the units' ends (k_measure), the closing quotes
             p.unit_copy = SJ_ARR(x.unit_copy, x.units, A_UNIT_COPY);
             p.sinfo = SJ_ARR(reinterpret_cast<uint2 *>(scq_mem), p.soff_cap, A_STRQ);  // (8 n + 128 bytes)
-            p.unit_tq = SJ_ARR(x.unit_tq, x.units, A_UNIT_STR);
+            p.unit_tq = SJ_ARR(x.unit_tq, x.units, A_UNIT_TQ);
         }
         p.units = (p.sv.end + 4095) / 4096;  // units that hold message bytes (stage 1 wrote their masks)
     }

@@ -455,6 +455,8 @@ func ParseNDStream(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 // Stream.Value's Tape, Strings.B and Message alias memory of the stream until the consumer hands the value back on
 // `reuse` -- which it MUST do for every value, before the next one is delivered (the blocks behind it keep being read
 // and parsed meanwhile).  `reuse` must not be nil.  The value handed back is only a token: nothing of it is recycled.
+// CLOSING `reuse` ends the stream and INVALIDATES every value it delivered (their slices alias pinned memory that is freed
+// with the stream): copy what must outlive the stream before closing.
 func ParseNDStreamInPlace(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson) {
 	if reuse == nil {
 		go func() {
@@ -616,10 +618,17 @@ func parseNDStreamHip(r io.Reader, res chan<- Stream, reuse <-chan *ParsedJson, 
 				}
 				res <- Stream{Value: v}
 				if _, ok := <-reuse; !ok {
-					// the consumer closed `reuse` (legal with ParseNDStream): that is NOT a hand-back -- the value it
-					// still holds aliases this block, so the block must not be recycled under it.  Stop here.
+					// the consumer closed `reuse` (legal with ParseNDStream): that is NOT a hand-back.  In-place mode has no
+					// copy to fall back on: the value delivered last aliases pinned memory of the stream, which is torn down
+					// when this goroutine returns -- CLOSING `reuse` THEREFORE INVALIDATES EVERY VALUE THIS STREAM DELIVERED
+					// (documented on ParseNDStreamInPlace; a consumer that wants to keep a value copies it before closing).
+					// The error is offered without blocking: a consumer that has stopped reading `res` must not pin this
+					// goroutine and the stream forever.
 					close(stop)
-					res <- Stream{Error: errors.New("ParseNDStreamInPlace: reuse channel closed while a delivered value aliases the stream's memory")}
+					select {
+					case res <- Stream{Error: errors.New("ParseNDStreamInPlace: reuse channel closed; values delivered by this stream are no longer valid")}:
+					default:
+					}
 					return
 				}
 				C.sjhip_stream_release(st)

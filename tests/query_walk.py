@@ -112,8 +112,12 @@ class Walk:
             if tag == "l":
                 return as_i() >= 0 and raw == want
             if tag == "d":
+                # `if v > math.MaxUint64` -- the constant converts to the float64 2^64, so exactly 2^64 passes and uint64(v)
+                # is the amd64 conversion's result for it: 0 (parsed_json.go:685-692)
                 d = as_f()
-                return 0.0 <= d < 2.0 ** 64 and int(d) == want
+                if d != d or d < 0.0 or d > 2.0 ** 64:
+                    return False
+                return (0 if d >= 2.0 ** 64 else int(d)) == want
             return False
         if op == OP_EQ_FLOAT:  # Iter.Float
             if tag == "d":

@@ -272,3 +272,8 @@ def test_paths_on_fixtures(ctx):
     assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_INT, 100) == 1
     assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_FLOAT, 100.0) == 1
     assert ctx.count_where_path((b"search_metadata", b"count"), ctx.OP_EQ_UINT, 99) == 0
+    # floats at the edges of Iter.Int / Iter.Uint (exactly 2^63 / 2^64 pass the reference's range checks: amd64 conversion results)
+    ctx.parse(b'{"a":9223372036854775808.0,"b":18446744073709551616.0,"c":18446744073709555000.0}')
+    assert ctx.count_where_path((b"a",), ctx.OP_EQ_INT, -(2 ** 63)) == 1 and ctx.count_where_path((b"a",), ctx.OP_EQ_UINT, 2 ** 63) == 1
+    assert ctx.count_where_path((b"b",), ctx.OP_EQ_UINT, 0) == 1 and ctx.count_where_path((b"b",), ctx.OP_EQ_INT, 0) == 0
+    assert ctx.count_where_path((b"c",), ctx.OP_EQ_UINT, 0) == 0

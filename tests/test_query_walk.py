@@ -135,3 +135,11 @@ def test_typed_comparisons_follow_the_iter_conversions():
     assert w.element_is(at(b"t"), Q.OP_EQ_BOOL, True) and not w.element_is(at(b"t"), Q.OP_EQ_BOOL, False)
     assert w.element_is(at(b"n"), Q.OP_IS_NULL) and not w.element_is(at(b"t"), Q.OP_IS_NULL)
     assert w.element_is(at(b"big"), Q.OP_EQ_UINT, 2 ** 63) and not w.element_is(at(b"big"), Q.OP_EQ_INT, 2 ** 63 - 1)
+    # the two float edges the reference's range checks let through (`v > math.MaxInt64` / `v > math.MaxUint64` compare with the
+    # float64 constants 2^63 / 2^64): int64(2^63) and uint64(2^64) are the amd64 conversions' results, MinInt64 and 0
+    ref = O.parse(b'{"a":9223372036854775808.0,"b":18446744073709551616.0,"c":18446744073709555000.0}', copy_strings=True)
+    w = Q.Walk(ref.tape, ref.strings, b"")
+    (root,) = w.records()
+    assert w.element_is(w.find_path(root, [b"a"]), Q.OP_EQ_INT, -(2 ** 63)) and w.element_is(w.find_path(root, [b"a"]), Q.OP_EQ_UINT, 2 ** 63)
+    assert w.element_is(w.find_path(root, [b"b"]), Q.OP_EQ_UINT, 0) and not w.element_is(w.find_path(root, [b"b"]), Q.OP_EQ_INT, 0)
+    assert not w.element_is(w.find_path(root, [b"c"]), Q.OP_EQ_UINT, 0)

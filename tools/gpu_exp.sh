@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 export SJHIP_LIB=$REPO/build_ab/libsjhip_exp.so
 : > $OUT/exp.txt
 for w in twitter parking; do
-for bits in 0 1 2 4 8 512 15 16 32 64 112 128 256 384; do
+for bits in 0 256 512 1024 2048 4096 8192 65536 131072 262144 458752 32 64 0; do
   rm -rf $OUT/t
   SJHIP_EXP=$bits timeout 120 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/parse_loop_noexc.py $w 3 > $OUT/log 2>&1
   echo "== $w exp=$bits" >> $OUT/exp.txt
