@@ -19,7 +19,9 @@ Objects on the same line (all measured live in this run unless they say "committ
                 algorithmic bytes of SURVEY.md 8d = (N + 4S) + (4S + N + 8T + B_str), per-kernel times from the
                 committed rocprofv3 kernel trace.
   ndjson        configs[4]: parking-citations x1000 ParseND, sharded over the ranks at record boundaries (sizes and
-                return codes exchanged with all_gather), with its roofline object; strong scaling.
+                return codes exchanged through a shared-memory mailbox between the ranks of the node, RCCL all_gather as the
+                fallback), with its roofline object; strong scaling.  At N = 1 also shard_1of8: what one of eight ranks will
+                do, and the 8-GPU efficiency that projects.  ndjson_x8000: the same protocol on a 2.98 GB document.
   stream        ParseNDStream through the library (sjhip_stream_*): host memory -> tapes in host memory, 10 MiB blocks.
   query         sjhip_count_where("Make", "HOND") on the device-resident tape of configs[4]: only 8 bytes cross PCIe.
   serialize / marshal_json   Serializer.Serialize (CompressNone) and Iter.MarshalJSON of the same tape on the device.
@@ -391,13 +393,26 @@ def main():
             ctx._check(L.sjhip_parse_shard_finish(ctx._h, tape_base, strings_base, msg_base))
             return None, None  # the tape / Strings.B stay in HBM (the bench measures the parse, not the fetch)
 
-        def nd_gather(vals):  # the only exchange of the data path: 8 bytes per value and rank (RCCL all_gather)
+        def nd_gather_rccl(vals):  # 8 bytes per value and rank through RCCL: a tensor, the collective, a synchronisation
             if not distributed:
                 return [tuple(vals)]
             mine = torch.tensor(list(vals), dtype=torch.int64, device=dev)
             got = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(got, mine)
             return [tuple(int(x) for x in g) for g in got]
+
+        # The only exchange of the data path is 24 bytes per rank, twice per parse.  Between the ranks of one node it goes
+        # through a shared-memory mailbox (sjhip.ndshard.ShmMailbox: a store and a poll, ~3 us) -- no collective launch and no
+        # device synchronisation in the middle of a 100-us shard parse; RCCL is the fallback and is timed beside it.
+        mailbox = ndshard.open_mailbox(rank, world, barrier=(dist.barrier if distributed else None),
+                                       tag="bench%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+        if distributed:  # every rank must use the same exchange
+            okbox = torch.tensor([1 if mailbox is not None else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(okbox, op=dist.ReduceOp.MIN)
+            if int(okbox.item()) == 0 and mailbox is not None:
+                mailbox.close()
+                mailbox = None
+        nd_gather = mailbox.gather if mailbox is not None else nd_gather_rccl
 
         def ndp():
             nonlocal tl, sl
@@ -432,8 +447,9 @@ def main():
         s_shard = 77 * s_nd + (s_nd - 1)
         algo_nd = (len(shard) + 4 * s_shard) + (4 * s_shard + len(shard) + 8 * tl + sl)
         extra["ndjson"] = {"workload": f"configs[4]: parking-citations.json x1000 ParseND, {world} shard(s) cut at record "
-                                       f"boundaries, sizes + return codes exchanged by all_gather", "bytes_total": total_bytes,
+                                       f"boundaries, sizes + return codes exchanged between the phases", "bytes_total": total_bytes,
                            "GBps": round(total_bytes / t_nd / 1e9, 2), "ms": round(t_nd * 1e3, 3),
+                           "exchange": "shared-memory mailbox (sjhip.ndshard.ShmMailbox)" if mailbox is not None else "RCCL all_gather",
                            "scaling": "strong", "tape_words_rank0": tl, "strings_bytes_rank0": sl,
                            "roofline": {"bound": "hbm", "algorithmic_bytes_rank0": algo_nd,
                                         "achieved": round(algo_nd / t_nd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -441,6 +457,88 @@ def main():
                                         "bytes_per_input_byte": round(algo_nd / max(len(shard), 1), 3),
                                         "kernels_us_committed_profile": (kprof or {}).get("parking_x1000_nd"),
                                         "note": "per rank; same byte model as full_parse"}}
+        if distributed and mailbox is not None:  # the same sharded parse with the RCCL exchange, for comparison
+            nd_gather_used, nd_gather = nd_gather, nd_gather_rccl
+            dist.barrier()
+            t_rccl = timed(ndp, reps)
+            tm = torch.tensor([t_rccl], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            extra["ndjson"]["ms_with_rccl_all_gather"] = round(float(tm.item()) * 1e3, 3)
+            nd_gather = nd_gather_used
+        if not distributed:
+            # ---- what one of EIGHT ranks will do: the first of 8 record-cut shards of configs[4] (46.6 MB) through the same
+            # two-phase protocol (begin -> exchange -> finish -> exchange).  8 x its time against the whole parse on one GPU is
+            # the strong-scaling efficiency an 8-GPU node can reach at best (the ranks also wait for the slowest of them).
+            a8, b8 = ndshard.record_cuts(nd_all, 8)[0]
+            shard8 = nd_all[a8:b8].rstrip(b"\n")
+            d_s8 = device_doc(shard8)
+
+            def s8_begin():
+                t_, s_ = C.c_size_t(0), C.c_size_t(0)
+                ctx._check(L.sjhip_parse_shard_begin(ctx._h, C.c_void_p(d_s8.data_ptr()), len(shard8), 3, C.byref(t_), C.byref(s_)))
+                return t_.value, s_.value
+
+            def s8_run(gather):
+                ndshard.run_shard(0, 1, False, s8_begin, nd_finish, gather, 0)
+            t_s8 = timed(lambda: s8_run(nd_gather), 20)
+            t_s8_plain = timed(lambda: ctx.parse_device(d_s8.data_ptr(), len(shard8), ndjson=True, copy_strings=True), 20)
+            extra["ndjson"]["shard_1of8"] = {
+                "workload": f"the first of 8 record-cut shards of configs[4] ({len(shard8)} B) through sjhip_parse_shard_begin -> exchange "
+                            f"-> sjhip_parse_shard_finish -> exchange on this GPU (what each rank of an 8-GPU run does)",
+                "ms": round(t_s8 * 1e3, 4), "ms_plain_parse_of_the_shard": round(t_s8_plain * 1e3, 4),
+                "exchange": extra["ndjson"]["exchange"],
+                "projected_8gpu_ms": round(t_s8 * 1e3, 4), "projected_8gpu_GBps": round(total_bytes / t_s8 / 1e9, 1),
+                "projected_8gpu_efficiency": round(t_nd / (8 * t_s8), 3),
+                "note": "efficiency = (whole parse on one GPU) / (8 x this): an upper bound -- the ranks of a real run also wait for "
+                        "the slowest of them at the exchange"}
+            del d_s8
+        # ---- a second ND workload, sized for eight GPUs: parking-citations x8000 (2.98 GB), strong scaling -- every rank parses
+        # its 1/N of it (N = 1: the whole document on one GPU), same protocol
+        if os.environ.get("SJHIP_BENCH_ND_BIG", "1") != "0":
+            del d_nd
+            torch.cuda.empty_cache()
+            nd_big = workloads.c5_parking_nd(8000)
+            ab, bb = ndshard.record_cuts(nd_big, world)[rank]
+            shard_b = nd_big[ab:bb].rstrip(b"\n")
+            big_total = len(nd_big) - 1
+            del nd_big
+            d_b = device_doc(shard_b)
+            recs_b = shard_b.count(b"\n") + 1
+            nb_len = len(shard_b)
+            del shard_b
+            tlb8 = slb8 = 0
+
+            def b_begin():
+                nonlocal tlb8, slb8
+                t_, s_ = C.c_size_t(0), C.c_size_t(0)
+                ctx._check(L.sjhip_parse_shard_begin(ctx._h, C.c_void_p(d_b.data_ptr()), nb_len, 3, C.byref(t_), C.byref(s_)))
+                tlb8, slb8 = t_.value, s_.value
+                return tlb8, slb8
+
+            def b_run():
+                ndshard.run_shard(rank, world, nb_len == 0, b_begin, nd_finish, nd_gather, ab)
+            if distributed:
+                dist.barrier()
+            t_b = timed(b_run, 5)
+            szb = torch.tensor([tlb8, slb8, recs_b], dtype=torch.int64, device=dev)
+            if distributed:
+                tm = torch.tensor([t_b], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                t_b = float(tm.item())
+                dist.all_reduce(szb)
+            assert tuple(int(x) for x in szb) == (80000 * 8000, 256664 * 8000, 8000 * 1000), tuple(int(x) for x in szb)
+            extra["ndjson_x8000"] = {"workload": f"parking-citations.json x8000 ParseND ({big_total} B), {world} shard(s) cut at record "
+                                                 f"boundaries, two-phase protocol on every rank", "bytes_total": big_total,
+                                     "ms": round(t_b * 1e3, 3), "GBps": round(big_total / t_b / 1e9, 2), "scaling": "strong",
+                                     "exchange": extra["ndjson"]["exchange"], "tape_words_total": int(szb[0]),
+                                     "strings_bytes_total": int(szb[1])}
+            del d_b
+            torch.cuda.empty_cache()
+            ctx.trim()
+            if rank == 0 and not distributed:
+                d_nd = device_doc(shard)
+        if mailbox is not None:
+            mailbox.close()
         if rank == 0 and not distributed:
             # ---- N2: a query on the device-resident tape instead of fetching 640 MB of it
             ctx.parse_device(d_nd.data_ptr(), len(shard), ndjson=True, copy_strings=True)
@@ -554,6 +652,9 @@ def main():
             "canada_device_us": (sd.get("parse_c2_canada") or {}).get("device_us"),
             "twitterescaped_h2h_us": (sd.get("parse_c3_twitterescaped") or {}).get("host_to_host_us"),
             "twitterescaped_device_us": (sd.get("parse_c3_twitterescaped") or {}).get("device_us"),
+            "ndjson_shard_1of8_ms": ((nd.get("shard_1of8") or {}).get("ms")),
+            "ndjson_projected_8gpu_efficiency": ((nd.get("shard_1of8") or {}).get("projected_8gpu_efficiency")),
+            "ndjson_x8000_ms": (extra.get("ndjson_x8000") or {}).get("ms"), "ndjson_x8000_GBps": (extra.get("ndjson_x8000") or {}).get("GBps"),
             "marshal_json_ms": (extra.get("marshal_json") or {}).get("ms"),
             "stream_GBps": (extra.get("stream") or {}).get("GBps"),
         }

@@ -153,6 +153,11 @@ void sjhip_trim_space(const uint8_t *msg, size_t len, size_t *off, size_t *out_l
 /* ---- queries on the device-resident result (no reference counterpart in the parser: they replace what callers do with
  * Iter / Object.FindKey on the host, ndjson_test.go:421-471, parsed_object.go:97-138, README.md:226-269) ------------
  * Both work on the result of the last successful sjhip_parse / sjhip_parse_device of `ctx` (still on the device).
+ * Results larger than one context (round 6): after an ND message beyond 4 GiB -- parsed shard by shard, every shard resident on
+ * its own context -- sjhip_count_where, the path / key-set queries below and sjhip_marshal_json run shard by shard and return
+ * what they return on the merged ParsedJson (counts added up, per-record answers in document order holding indexes of the MERGED
+ * tape, texts joined with the newline between two records), like the reference's Iter on any ParsedJson (parsed_json.go:96,125,833);
+ * sjhip_filter_where and sjhip_serialize need the result of one context and say so (SJHIP_ERR_ARG).
  * A record matches when its root value is an object whose FIRST member with key == `key` (top level only, like
  * Object.FindKey) has a string value == `value` (compared after unescaping) -- the reference's countWhere.
  *   count_where : number of matching records; 8 bytes cross PCIe.

@@ -196,7 +196,7 @@ static int stage1_verdict(const Stage1State &st, size_t len, uint8_t last_byte) 
 // copy, the positions with the token kinds behind them: queries, the serializer and MarshalJSON must not run on what
 // is left (they return SJHIP_ERR_ARG until the next parse).
 static void invalidate_result(sjhip_ctx *ctx) {
-    ctx->q_valid = ctx->ser_valid = ctx->ms_valid = 0;
+    ctx->q_valid = ctx->r_valid = ctx->ser_valid = ctx->ms_valid = 0;
     ctx->pending = 0;
     ctx->q_tape_len = ctx->q_strings_len = 0;
     ctx->f_valid = 0;

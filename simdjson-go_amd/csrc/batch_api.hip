@@ -244,7 +244,7 @@ int sjhip_parse_batch_device(sjhip_ctx *ctx, const void *d_buf, const size_t *of
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return SJHIP_ERR_HIP;  // (a parse that failed early may not have waited)
     if (*bad) {  // a document that Parse() rejects in stage 1: that code wins (parse_json_amd64.go:97-105,123-126)
         ctx->tape_len = ctx->strings_len = 0;
-        ctx->q_valid = ctx->pack_valid = 0;
+        ctx->q_valid = ctx->r_valid = ctx->pack_valid = 0;
         if (tape_len) *tape_len = 0;
         if (strings_len) *strings_len = 0;
         return SJHIP_ERR_STAGE1;

@@ -54,6 +54,9 @@ struct MsView {
     const u8 *kf_tape;           // null, or the flags the parser left (SJHIP_FLAG_KEY_FLAGS): [tape index of the entry >> 1]
     u32 *slen;                   // [tiles][1024] escaped length of the tile's k-th string (counting pass -> writing pass)
     const u8 *strings_end, *msg_end;  // ends of the buffers the strings live in (8-byte loads stop there)
+    // a shard of a sharded ParseND (an ND message beyond one context's reach) stores its indices in the merged index space: what
+    // a root word points at, where a string lies in Strings.B / the message (0 for an unsharded result)
+    u64 tape_base, strings_base, msg_base;
     u8 *text;
     // the single-pass form (k_ms_tile<2>): one descriptor per tile (0: nothing yet, MS_DESC_AGG | size, MS_DESC_PREFIX | size of
     // everything up to and including the tile), the ticket counter that numbers the tiles, the capacity of `text`
@@ -83,10 +86,6 @@ __device__ __forceinline__ const u8 *ms_string(const MsView &p, bool inbuf, u64 
     (void)len;
 #endif
     return (inbuf ? p.strings : p.msg) + off;
-}
-__device__ __forceinline__ const u8 *entry_string(const MsView &p, u64 word) {
-    const u64 v = word & TW_PAYLOAD;
-    return (v & STRINGBUFBIT) ? p.strings + (v & (STRINGBUFBIT - 1)) : p.msg + v;
 }
 
 // e: queue entry of a string (its ordinal inside the tile in bits 11..20), at: its tape index
@@ -351,10 +350,11 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             if (t == '"') {
                 const bool lng = w[k + 1] >= MS_LONG;
                 const u32 slot = lng ? MS_QCAP - 1 - atomicAdd(&s_cnt[1], 1u) : atomicAdd(&s_cnt[0], 1u);
-                const u64 v = w[k] & TW_PAYLOAD;
-                const u64 inbuf = (v & STRINGBUFBIT) ? 1u : 0u;
+                const u64 vr = w[k] & TW_PAYLOAD;
+                const u64 inbuf = (vr & STRINGBUFBIT) ? 1u : 0u;
+                const u64 v = inbuf ? (vr & ~STRINGBUFBIT) - p.strings_base : vr - p.msg_base;  // (inside this context's buffers)
                 s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) |
-                             ((inbuf ? (v & (STRINGBUFBIT - 1)) : v) << 32);
+                             (v << 32);
                 l = 2 + sep + (MODE == 1 ? p.slen[slen_base + ord] : 0u);
                 ord++;
             } else if (t == 'l' || t == 'u') {
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             } else if (t == '}' || t == ']') {
                 l = 1 + sep;
             } else if (t == 'r') {
-                const bool is_open = (w[k] & TW_PAYLOAD) > base + k;  // isOpenRoot (:441)
+                const bool is_open = (w[k] & TW_PAYLOAD) > p.tape_base + base + k;  // isOpenRoot (:441)
                 l = (!is_open && base + k + 1 < p.n) ? 1u : 0u;       // '\n' between records
             } else {
                 bad = true;
@@ -644,43 +644,46 @@ static int marshal_bounds_check(sjhip_ctx *ctx) {
     return SJHIP_OK;
 }
 
-int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
-    if (!ctx) return SJHIP_ERR_ARG;
-    ctx->ms_len = 0;
-    ctx->ms_valid = 0;
-    if (!ctx->q_valid || ctx->tape_len == 0) {
+// Iter.MarshalJSON of the result `part` holds (ctx itself, or one shard of ctx's sharded ND result); errors are left in ctx
+static int marshal_part(sjhip_ctx *ctx, sjhip_ctx *part, size_t *text_len) {
+    part->ms_len = 0;
+    part->ms_valid = 0;
+    if (!part->r_valid || part->tape_len == 0) {
         ctx_set_error(ctx, "no parse result on the device (sjhip_marshal_json follows a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;
     }
-    if (ctx->p_len >= (1ull << 32) && !(ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) {
+    if (part->p_len >= (1ull << 32) && !(part->p_flags & SJHIP_FLAG_COPY_STRINGS)) {
         // k_ms_tile keeps the offset of a string in 32 bits of its queue entry: with WithCopyStrings(false) the strings that are not
         // copied lie at MESSAGE offsets, which pass 2^32 in a document of 4 GiB or more (Strings.B itself is checked to stay below)
         ctx_set_error(ctx, "sjhip_marshal_json: a document of 4 GiB or more parsed without SJHIP_FLAG_COPY_STRINGS (message offsets beyond 32 bits)");
         return SJHIP_ERR_TOOBIG;
     }
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    ctx->ser_valid = 0;  // shares d_q with the serializer and the filter
-    ctx->q_tape_len = ctx->q_strings_len = 0;
-    ctx->f_valid = 0;
+    HIPCHK(hipSetDevice(part->device), "hipSetDevice");
+    part->ser_valid = 0;  // shares d_q with the serializer and the filter
+    part->q_tape_len = part->q_strings_len = 0;
+    part->f_valid = 0;
     MsView p;
-    p.tape = (const u64 *)ctx->d_tape.p;
-    p.n = ctx->tape_len;
+    p.tape = (const u64 *)part->d_tape.p;
+    p.n = part->tape_len;
     p.tiles = (u32)((p.n + TW_TILE - 1) / TW_TILE);
-    p.strings = (const u8 *)ctx->d_strings.p;
-    p.msg = (const u8 *)ctx->p_msg;
-    p.strings_len = ctx->strings_len;
-    p.msg_len = ctx->p_msg ? ctx->p_len : 0;
-    p.strings_end = p.strings + ctx->strings_len;
-    p.msg_end = p.msg ? p.msg + ctx->p_len : nullptr;
+    p.tape_base = part->r_tape_base;
+    p.strings_base = part->r_strings_base;
+    p.msg_base = part->r_msg_base;
+    p.strings = (const u8 *)part->d_strings.p;
+    p.msg = (const u8 *)part->p_msg;
+    p.strings_len = part->strings_len;
+    p.msg_len = part->p_msg ? part->p_len : 0;
+    p.strings_end = p.strings + part->strings_len;
+    p.msg_end = p.msg ? p.msg + part->p_len : nullptr;
     KeyView kv;
-    kv.kind = ctx->p_kind;
-    kv.n = (u32)ctx->p_n;
+    kv.kind = part->p_kind;
+    kv.n = (u32)part->p_n;
     kv.tiles = (kv.n + 4095u) / 4096u;
     const size_t per = ((size_t)p.tiles * 8 + 255) / 256 * 256, perk = ((size_t)kv.tiles * 8 + 255) / 256 * 256;
     const size_t flags = ((size_t)kv.n + 255) / 256 * 256;
-    int rc = arena_reserve(ctx, ctx->d_q, 256 + per * 4 + 256 + perk + flags + (size_t)p.tiles * MS_QCAP * 4 + 256);
+    int rc = arena_reserve(part, part->d_q, 256 + per * 4 + 256 + perk + flags + (size_t)p.tiles * MS_QCAP * 4 + 256);
     if (rc) return rc;
-    char *w = (char *)ctx->d_q.p;
+    char *w = (char *)part->d_q.p;
     p.totals = (unsigned long long *)w;
     w += 256;
     p.tile_last = (long long *)w;
@@ -701,17 +704,17 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     p.slen = (u32 *)w;
     p.text = nullptr;
     p.text_cap = 0;
-    HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
+    HIPCHK(hipMemsetAsync(p.totals, 0, 256, part->stream), "marshal memset");
     // keys: the flags the parser left (SJHIP_FLAG_KEY_FLAGS), or from the token array of the parse (three launches)
-    p.kf_tape = (ctx->kf_valid && ctx->q_valid) ? (const u8 *)ctx->d_keyflag.p : nullptr;
+    p.kf_tape = (part->kf_valid) ? (const u8 *)part->d_keyflag.p : nullptr;
     if (!p.kf_tape) {
-        hipLaunchKernelGGL(k_ms_keys<false>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
-        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, kv.cnt, (unsigned long long *)nullptr, kv.tiles,
+        hipLaunchKernelGGL(k_ms_keys<false>, dim3(kv.tiles), dim3(256), 0, part->stream, kv);
+        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, part->stream, kv.cnt, (unsigned long long *)nullptr, kv.tiles,
                            (unsigned long long *)nullptr);
-        hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, ctx->stream, kv);
+        hipLaunchKernelGGL(k_ms_keys<true>, dim3(kv.tiles), dim3(256), 0, part->stream, kv);
     }
     long long *const tile_last = p.tile_last;
-    unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
+    unsigned long long *h = (unsigned long long *)(part->h_scratch + 512);
     // With the key flags at hand, ONE pass over the tape (k_ms_tile<2>): the text buffer is sized by a bound instead of by a
     // counting pass.  The text of an entry is never longer than its source, except a number's: "1e20" prints as 21
     // digits (appendFloat leaves exponent form only from 1e21 on), 17 bytes more -- strings come out as they went in or
@@ -720,7 +723,7 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
     // would write past the bound (it cannot) or that finds no anchor raises a flag and the two-pass form below runs.
     bool no_local_anchor = false;
     bool one_pass = p.kf_tape && ms_onepass();
-    size_t bound = ctx->p_len + 20 * (p.n / 2 + 1) + 64;
+    size_t bound = part->p_len + 20 * (p.n / 2 + 1) + 64;
     if (one_pass) {
         // The bound is ~10 bytes per tape word above the real text: for a tape of several hundred million words that is
         // gigabytes of a grow-only arena.  Beyond SJHIP_MS_BOUND_LIMIT (default 8 GiB), or when the device cannot give
@@ -728,20 +731,20 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
         static const size_t limit = getenv("SJHIP_MS_BOUND_LIMIT") ? (size_t)strtoull(getenv("SJHIP_MS_BOUND_LIMIT"), nullptr, 0) : (size_t)8 << 30;
         if (const char *e = getenv("SJHIP_MS_TEST_BOUND")) bound = (size_t)strtoull(e, nullptr, 0);  // tests: make the bound fail
         if (bound > limit) one_pass = false;
-        else if (arena_reserve(ctx, ctx->d_qtape, bound + 64) != SJHIP_OK) {
+        else if (arena_reserve(part, part->d_qtape, bound + 64) != SJHIP_OK) {
             (void)hipGetLastError();
             one_pass = false;
         }
     }
     if (one_pass) {
         p.tile_last = nullptr;
-        p.text = (u8 *)ctx->d_qtape.p;
+        p.text = (u8 *)part->d_qtape.p;
         p.text_cap = bound;
-        HIPCHK(hipMemsetAsync(p.desc, 0, per + 256, ctx->stream), "marshal memset (descriptors)");  // (and the ticket behind them)
-        launch_ms_tile<2>(p, ctx->stream);
+        HIPCHK(hipMemsetAsync(p.desc, 0, per + 256, part->stream), "marshal memset (descriptors)");  // (and the ticket behind them)
+        launch_ms_tile<2>(p, part->stream);
         HIPCHK(hipGetLastError(), "marshal launch (one pass)");
-        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
-        HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
+        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, part->stream), "D2H totals");
+        HIPCHK(hipStreamSynchronize(part->stream), "marshal sync");
         if (h[2] & 16ull) {
             ctx_set_error(ctx, "MarshalJSON: look-back aborted (internal synchronisation timeout)");
             return SJHIP_ERR_HIP;
@@ -755,13 +758,13 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
                 ctx_set_error(ctx, "MarshalJSON: 2048 consecutive tape words produce more than 4 GiB of text");
                 return SJHIP_ERR_TOOBIG;
             }
-            ctx->ms_len = (size_t)h[0];
-            ctx->ms_valid = 1;
-            if (text_len) *text_len = ctx->ms_len;
+            part->ms_len = (size_t)h[0];
+            part->ms_valid = 1;
+            if (text_len) *text_len = part->ms_len;
             return marshal_bounds_check(ctx);
         }
         no_local_anchor = (h[2] & 4ull) != 0;  // (the counting pass below starts with the global anchors right away)
-        HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
+        HIPCHK(hipMemsetAsync(p.totals, 0, 256, part->stream), "marshal memset");
         p.text = nullptr;
     }
     // lengths and positions; the tag / raw anchors of the tiles are found locally unless a tile reports that it cannot
@@ -770,17 +773,17 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
             p.tile_last = nullptr;
         } else {
             p.tile_last = tile_last;
-            HIPCHK(hipMemsetAsync(p.totals, 0, 256, ctx->stream), "marshal memset");
-            hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, ctx->stream, p.tape, p.n, p.tile_last);
-            hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, ctx->stream, p.tile_last, p.tiles);
+            HIPCHK(hipMemsetAsync(p.totals, 0, 256, part->stream), "marshal memset");
+            hipLaunchKernelGGL(k_tw_last, dim3(p.tiles), dim3(TW_THREADS), 0, part->stream, p.tape, p.n, p.tile_last);
+            hipLaunchKernelGGL(k_tw_scan_last, dim3(1), dim3(1024), 0, part->stream, p.tile_last, p.tiles);
         }
-        launch_ms_tile<0>(p, ctx->stream);
+        launch_ms_tile<0>(p, part->stream);
         // (the prefix of the string counts is only needed to index the recovered key flags)
-        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, ctx->stream, p.cnt_b, p.kf_tape ? (unsigned long long *)nullptr : p.cnt_s,
+        hipLaunchKernelGGL(k_ms_scan, dim3(1), dim3(1024), 0, part->stream, p.cnt_b, p.kf_tape ? (unsigned long long *)nullptr : p.cnt_s,
                            p.tiles, p.totals);
         HIPCHK(hipGetLastError(), "marshal launch");
-        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, ctx->stream), "D2H totals");
-        HIPCHK(hipStreamSynchronize(ctx->stream), "marshal sync");
+        HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, part->stream), "D2H totals");
+        HIPCHK(hipStreamSynchronize(part->stream), "marshal sync");
         if (!(h[2] & 4ull)) break;
     }
     if (h[2] & 1ull) {
@@ -791,19 +794,69 @@ int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
         ctx_set_error(ctx, "MarshalJSON: 2048 consecutive tape words produce more than 4 GiB of text");
         return SJHIP_ERR_TOOBIG;
     }
-    rc = arena_reserve(ctx, ctx->d_qtape, (size_t)h[0] + 64);
+    rc = arena_reserve(part, part->d_qtape, (size_t)h[0] + 64);
     if (rc) return rc;
-    p.text = (u8 *)ctx->d_qtape.p;
-    launch_ms_tile<1>(p, ctx->stream);
+    p.text = (u8 *)part->d_qtape.p;
+    launch_ms_tile<1>(p, part->stream);
     HIPCHK(hipGetLastError(), "marshal emit launch");
-    ctx->ms_len = (size_t)h[0];
+    part->ms_len = (size_t)h[0];
+    part->ms_valid = 1;
+    if (text_len) *text_len = part->ms_len;
+    return SJHIP_OK;
+}
+
+// The device-resident result of the last parse as text.  A sharded ND result (parse_nd_big) is marshaled shard by shard -- a shard
+// ends at a record boundary, so the text of the whole result is the shards' texts joined with the '\n' that separates two records
+// (parsed_json.go:401-556 writes one between records and none behind the last).
+int sjhip_marshal_json(sjhip_ctx *ctx, size_t *text_len) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    ctx->ms_len = 0;
+    ctx->ms_valid = 0;
+    if (!ctx->big_valid) return marshal_part(ctx, ctx, text_len);
+    size_t total = 0;
+    int np = 0;
+    for (int k = 0; k < nd_big_shards(ctx); k++) {
+        sjhip_ctx *part = nd_big_shard(ctx, k);
+        if (!part) continue;
+        size_t len = 0;
+        const int rc = marshal_part(ctx, part, &len);
+        if (rc) {
+            if (part->err[0] && !ctx->err[0]) ctx_set_error(ctx, "%s", part->err);
+            (void)hipSetDevice(ctx->device);
+            return rc;
+        }
+        total += len + (np ? 1 : 0);
+        np++;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (np == 0) {
+        ctx_set_error(ctx, "no parse result on the device (sjhip_marshal_json follows a successful sjhip_parse / sjhip_parse_device)");
+        return SJHIP_ERR_ARG;
+    }
+    ctx->ms_len = total;
     ctx->ms_valid = 1;
-    if (text_len) *text_len = ctx->ms_len;
+    if (text_len) *text_len = total;
     return SJHIP_OK;
 }
 
 int sjhip_fetch_marshaled(sjhip_ctx *ctx, uint8_t *dst) {
     if (!ctx || !ctx->ms_valid) return SJHIP_ERR_ARG;
+    if (ctx->big_valid) {  // the shards' texts, joined with the newline between two records
+        size_t at = 0;
+        int np = 0;
+        for (int k = 0; k < nd_big_shards(ctx); k++) {
+            sjhip_ctx *part = nd_big_shard(ctx, k);
+            if (!part || !part->ms_valid) continue;
+            if (np++ && dst) dst[at++] = '\n';
+            HIPCHK(hipSetDevice(part->device), "hipSetDevice");
+            if (part->ms_len && dst)
+                HIPCHK(hipMemcpyAsync(dst + at, part->d_qtape.p, part->ms_len, hipMemcpyDeviceToHost, part->stream), "D2H JSON text");
+            HIPCHK(hipStreamSynchronize(part->stream), "fetch sync");
+            at += part->ms_len;
+        }
+        HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+        return at == ctx->ms_len ? marshal_bounds_check(ctx) : SJHIP_ERR_ARG;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (ctx->ms_len && dst)
         HIPCHK(hipMemcpyAsync(dst, ctx->d_qtape.p, ctx->ms_len, hipMemcpyDeviceToHost, ctx->stream), "D2H JSON text");

@@ -321,6 +321,13 @@ size_t sj::nd_big_device_bytes(const sjhip_ctx *ctx) {
     return total;
 }
 
+int sj::nd_big_shards(const sjhip_ctx *ctx) { return ctx->big && ctx->big_valid ? (int)ctx->big->shards.size() : 0; }
+sjhip_ctx *sj::nd_big_shard(const sjhip_ctx *ctx, int k) {
+    if (!ctx->big || k < 0 || (size_t)k >= ctx->big->shards.size()) return nullptr;
+    const Shard &s = ctx->big->shards[(size_t)k];
+    return s.len ? s.ctx : nullptr;
+}
+
 void sj::release_nd_big(sjhip_ctx *ctx) {
     if (ctx->big) sjhip_multi_destroy(ctx->big);
     ctx->big = nullptr;

@@ -44,6 +44,8 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.n = ctx->p_nlay;
     a.n_dev = ctx->p_deferred ? (const unsigned long long *)((const char *)ctx->d_ws.p + offsetof(Stage1State, total)) : nullptr;
     a.flags = ctx->p_flags;
+    // (stage 1 of this parse ran in the context's stage-1 workspace, whose first line is its state)
+    a.s1_has_starter = ctx->p_aux ? (const uint32_t *)((const char *)ctx->d_ws.p + offsetof(Stage1State, has_starter)) : nullptr;
     a.ws_zero = ctx->d_s2z.p;
     a.ws = ctx->d_s2.p;
     a.d_tape = (uint64_t *)ctx->d_tape.p;
@@ -90,6 +92,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     ctx->pending = 0;
     ctx->pack_valid = 0;
     ctx->q_valid = 0;
+    ctx->r_valid = 0;
     ctx->kf_valid = 0;
     ctx->ser_valid = 0;
     ctx->ms_valid = 0;
@@ -133,7 +136,9 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         // (same box): the host round trip between stage 1 and stage 2 and the launch gap behind it.
         const bool small = len <= small_document_bytes();
         const bool known = ctx->p_density_q != 0 && small_document_bytes() != 0;
-        ctx->p_deferred = !(tape_len || strings_len) && (small || known) && !ctx->p_no_defer;
+        // (round 6: a shard's phase 1 as well -- its sizes need one synchronisation, not a second one in front for stage 1's count)
+        ctx->p_deferred = (small || known) && !ctx->p_no_defer;
+        ctx->p_collected = 0;
         if (ctx->p_deferred && !small) {
             rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
@@ -201,6 +206,26 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         S2State *hs = (S2State *)(ctx->h_scratch + 512);
         HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 sizes");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sizes sync");
+        if (ctx->p_deferred) {  // stage 1's verdict and count arrived with the same synchronisation (its last block wrote them to pinned memory)
+            size_t n1 = 0;
+            int ok1 = 0;
+            rc = stage1_collect(ctx, len, last_byte, have_last, &n1, &ok1);
+            if (rc) return rc;
+            if (!ok1) return SJHIP_ERR_STAGE1;  // (first, as in parseMessage)
+            if (n1 >= TOKEN_LIMIT) {
+                ctx_set_error(ctx, "document of %zu tokens: one context parses fewer than 2^32", n1);
+                return SJHIP_ERR_TOOBIG;
+            }
+            if (n1 > ctx->p_nlay) {  // denser than the layout assumed: nothing of this run counts -- again, the synchronous way
+                ctx->p_no_defer = 1;
+                if (len <= small_document_bytes()) ctx->p_dense = 1;
+                rc = parse_begin(ctx, d_msg, len, flags, last_byte, have_last, tape_len, strings_len);
+                ctx->p_no_defer = 0;
+                return rc;
+            }
+            ctx->p_n = n1;
+            ctx->p_collected = 1;
+        }
         if (hs->err & S2_ERR_SERIAL_STRINGS) {  // pathological surrogate run: measure again with the per-string walks
             if (len > ND_LIMIT) {
                 ctx_set_error(ctx, "the per-string path (a surrogate run or a string beyond the byte-parallel path) works on documents of up to 4 GiB");
@@ -267,7 +292,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
             return SJHIP_ERR_HIP;
         }
     }
-    if (ctx->p_deferred) {  // stage 1's verdict first, as in parseMessage (parse_json_amd64.go:97-105,123-126)
+    if (ctx->p_deferred && !ctx->p_collected) {  // stage 1's verdict first, as in parseMessage (parse_json_amd64.go:97-105,123-126)
         size_t n = 0;
         int ok = 0;
         rc = stage1_collect(ctx, ctx->p_len, ctx->p_last, ctx->p_have_last, &n, &ok);
@@ -313,8 +338,12 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
     ctx->tape_len = (size_t)hs->tape_len;
     ctx->strings_len = ctx->p_aux ? (size_t)hs->strings_len_masks : (size_t)hs->strings_len;
     ctx->q_records = hs->records;
-    ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // query.hip works on unsharded results
-    ctx->kf_valid = ctx->q_valid && (ctx->p_flags & SJHIP_FLAG_KEY_FLAGS) && ctx->d_keyflag.p;
+    ctx->q_valid = tape_base == 0 && strings_base == 0 && msg_base == 0;  // filter / serializer / MarshalJSON work on unsharded results
+    ctx->r_valid = 1;  // the path / count queries also on a shard (in the merged index space)
+    ctx->r_tape_base = tape_base;
+    ctx->r_strings_base = strings_base;
+    ctx->r_msg_base = msg_base;
+    ctx->kf_valid = (ctx->p_flags & SJHIP_FLAG_KEY_FLAGS) && ctx->d_keyflag.p;  // (indexed by the context's own tape offsets: a shard's as well)
     if (tape_len) *tape_len = ctx->tape_len;
     if (strings_len) *strings_len = ctx->strings_len;
     return SJHIP_OK;
@@ -362,7 +391,7 @@ int sjhip_parse_device(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     if (!ctx) return SJHIP_ERR_ARG;
     if (nd_too_big(len, flags)) {  // shards on this device, each parsing its window of the message in place
         ctx->tape_len = ctx->strings_len = 0;
-        ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
+        ctx->q_valid = ctx->r_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
         HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
         HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync");  // (the shards run on streams of their own)
         return parse_nd_big(ctx, (const uint8_t *)d_msg, len, flags, true, nd_shard_bytes(), tape_len, strings_len, nullptr, nullptr);
@@ -383,7 +412,7 @@ int sjhip_parse(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags, 
     ctx->big_valid = 0;
     if (mlen == 0) return SJHIP_ERR_STAGE1;
     if (nd_too_big(mlen, flags)) {  // shards of the host message, H2D straight from the caller's buffer
-        ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
+        ctx->q_valid = ctx->r_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->pack_valid = ctx->pending = 0;
         return parse_nd_big(ctx, msg, len, flags, false, nd_shard_bytes(), tape_len, strings_len, nullptr, nullptr);
     }
     if (mlen > SINGLE_LIMIT) {  // before anything is copied to the device

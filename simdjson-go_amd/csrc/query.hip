@@ -44,14 +44,19 @@ struct QView {
     u64 strings_len;
     Arr<const u8> msg; // device copy of the message (strings that were not copied point into it)
     u64 msg_len;
-    Arr<const u32> nl_off; // tape offset of the close root of record r (r < R)
+    Arr<const u32> nl_off; // tape offset (inside this context's tape) of the close root of record r (r < R)
     u32 R;             // record-separating newline runs: R + 1 records
+    // A shard of a sharded ParseND (parse_nd_big: an ND message beyond one context's reach) stores its indices in the MERGED index
+    // space: tape indices + tape_base, Strings.B offsets + the shard's Strings.B base, message offsets + its message base.  The view
+    // of such a shard holds `tape`, `strings` and `msg` as pointers moved DOWN by those bases, so that every index a tape word holds
+    // -- and every index the path queries hand out -- is used as it stands; only the record bounds (nl_off: local) add tape_base.
+    u64 tape_base;     // 0 for an unsharded result; tape_len: END of this context's stretch in the merged index space
     u8 key[QMAX], val[QMAX];
     u32 klen, vlen;
 };
 
-__device__ __forceinline__ u32 rec_open(const QView &q, u32 r) { return r == 0 ? 0u : q.nl_off[r - 1] + 1u; }
-__device__ __forceinline__ u32 rec_close(const QView &q, u32 r) { return r == q.R ? (u32)q.tape_len - 1u : q.nl_off[r]; }
+__device__ __forceinline__ u64 rec_open(const QView &q, u32 r) { return q.tape_base + (r == 0 ? 0u : q.nl_off[r - 1] + 1u); }
+__device__ __forceinline__ u64 rec_close(const QView &q, u32 r) { return r == q.R ? q.tape_len - 1u : q.tape_base + q.nl_off[r]; }
 
 __device__ __forceinline__ const u8 *str_bytes(const QView &q, u64 word, u64 len) {
     const u64 p = word & PAYLOAD;
@@ -67,7 +72,7 @@ __device__ __forceinline__ bool str_equals(const QView &q, u64 word, u64 len, co
 
 // FindKey(key) on the root object of record r + the string compare of countWhere
 __device__ bool record_matches(const QView &q, u32 r) {
-    const u32 o = rec_open(q, r);
+    const u64 o = rec_open(q, r);
     const u64 w = q.tape[o + 1];
     if ((w >> 56) != '{') return false;
     const u64 end = (w & PAYLOAD) - 1;  // index of the closing '}'
@@ -397,7 +402,7 @@ __device__ __forceinline__ u64 skip_value(const QView &q, u64 v) {  // index beh
 // level.  Returns the tape index of the element's value, SJHIP_PATH_NOT_FOUND (ErrPathNotFound) or SJHIP_PATH_NOT_OBJECT
 // ("type ... found before object was found" / "value of key ... is not an object").
 __device__ u64 record_find_path(const QView &q, const QPath &pth, u32 r) {
-    const u32 o = rec_open(q, r);
+    const u64 o = rec_open(q, r);
     const u64 w = q.tape[o + 1];
     if ((w >> 56) != '{') return SJHIP_PATH_NOT_OBJECT;
     u64 end = (w & PAYLOAD) - 1;  // index of the closing '}'
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256) void k_q_project(QView q, QPath set, u64 *out)
     if (r > q.R) return;
     u64 *dst = out + (u64)r * set.n;
     u32 n = 0;
-    const u32 o = rec_open(q, r);
+    const u64 o = rec_open(q, r);
     const u64 w = q.tape[o + 1];
     if ((w >> 56) == '{') {
         const u64 end = (w & PAYLOAD) - 1;
@@ -532,54 +537,101 @@ static int query_bounds_check(sjhip_ctx *ctx) {
     return SJHIP_OK;
 }
 
-static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q,
+// The contexts whose device-resident results make up the last parse of `ctx`, in document order: the context itself, or --
+// after an ND message beyond one context's reach (parse_nd_big) -- the contexts of its shards.  Iter / ForEach / FindElement of
+// the reference work on any ParsedJson (parsed_json.go:96,125,833); here the count and path queries run shard by shard in the
+// merged index space (QView) and the host adds the counts up / lays the per-record answers end to end.
+static int result_parts(sjhip_ctx *ctx, sjhip_ctx **parts, int cap) {
+    if (!ctx->big_valid) {
+        parts[0] = ctx;
+        return 1;
+    }
+    int n = 0;
+    for (int k = 0; k < nd_big_shards(ctx) && n < cap; k++)
+        if (sjhip_ctx *c = nd_big_shard(ctx, k)) parts[n++] = c;
+    return n;
+}
+static constexpr int MAX_PARTS = 4096;  // (parse_nd_big's own limit)
+
+// view of the result held by `part` (ctx itself, or one shard context of ctx's sharded result); errors are left in ctx
+static int make_view(sjhip_ctx *ctx, sjhip_ctx *part, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q,
                      uint32_t *records) {
     if (!ctx || !key || !val) return SJHIP_ERR_ARG;
     if (klen > QMAX || vlen > QMAX) {
         ctx_set_error(ctx, "query key / value longer than %d bytes", QMAX);
         return SJHIP_ERR_ARG;
     }
-    if (!ctx->q_valid || ctx->tape_len == 0) {
+    if (!part || !part->r_valid || part->tape_len == 0) {
         ctx_set_error(ctx, "no parse result on the device (queries follow a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;
     }
     const uint32_t *nl = nullptr;
-    stage2_records_view(ctx->d_s2.p, ctx->p_nlay, &nl);
-    q->tape = SJ_ARR((const u64 *)ctx->d_tape.p, ctx->tape_len, A_TAPE);
-    q->tape_len = ctx->tape_len;
-    q->strings = SJ_ARR((const u8 *)ctx->d_strings.p, ctx->strings_len, A_STRINGS);
-    q->strings_len = ctx->strings_len;
-    q->msg = SJ_ARR((const u8 *)ctx->p_msg, ctx->p_len, A_MSG);
-    q->msg_len = ctx->p_len;
-    q->nl_off = SJ_ARR(nl, ctx->q_records, A_NL_OFF);
-    q->R = ctx->q_records;
+    stage2_records_view(part->d_s2.p, part->p_nlay, &nl);
+    // (pointers moved down by the shard's bases: see QView; all zero for an unsharded result)
+    q->tape_base = part->r_tape_base;
+    q->tape = SJ_ARR((const u64 *)part->d_tape.p - part->r_tape_base, part->r_tape_base + part->tape_len, A_TAPE);
+    q->tape_len = part->r_tape_base + part->tape_len;
+    q->strings = SJ_ARR((const u8 *)part->d_strings.p - part->r_strings_base, part->r_strings_base + part->strings_len, A_STRINGS);
+    q->strings_len = part->strings_len;
+    q->msg = SJ_ARR((const u8 *)part->p_msg - part->r_msg_base, part->r_msg_base + part->p_len, A_MSG);
+    q->msg_len = part->p_len;
+    q->nl_off = SJ_ARR(nl, part->q_records, A_NL_OFF);
+    q->R = part->q_records;
     memset(q->key, 0, QMAX);
     memset(q->val, 0, QMAX);
     memcpy(q->key, key, klen);
     memcpy(q->val, val, vlen);
     q->klen = (u32)klen;
     q->vlen = (u32)vlen;
-    *records = ctx->q_records + 1u;
+    *records = part->q_records + 1u;
     return SJHIP_OK;
+}
+// the unsharded result of ctx itself (filter / what needs q_valid)
+static int make_view(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, QView *q, uint32_t *records) {
+    if (ctx && !ctx->q_valid) {
+        if (ctx->big_valid) ctx_set_error(ctx, "sjhip_filter_where works on the result of one context; this ND result was parsed shard by shard");
+        else ctx_set_error(ctx, "no parse result on the device (queries follow a successful sjhip_parse / sjhip_parse_device)");
+        return SJHIP_ERR_ARG;
+    }
+    return make_view(ctx, ctx, key, klen, val, vlen, q, records);
+}
+// Runs `launch(part, q, n, d_count)` on every part of ctx's result and adds the 8-byte counts up.
+template <typename F>
+static int count_over_parts(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *val, size_t vlen, uint64_t *count, F launch) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    static thread_local sjhip_ctx *parts[MAX_PARTS];
+    const int np = result_parts(ctx, parts, MAX_PARTS);
+    if (np == 0) return make_view(ctx, nullptr, key, klen, val, vlen, nullptr, nullptr);  // (the error text)
+    uint64_t total = 0;
+    for (int k = 0; k < np; k++) {  // every part is queued on its own stream (its own device) before any is waited for
+        sjhip_ctx *part = parts[k];
+        QView q;
+        uint32_t n = 0;
+        int rc = make_view(ctx, part, key, klen, val, vlen, &q, &n);
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(part->device), "hipSetDevice");
+        rc = arena_reserve(part, part->d_kat, 64);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(part->d_kat.p, 0, 8, part->stream), "count memset");
+        launch(part, q, n, (unsigned long long *)part->d_kat.p);
+        HIPCHK(hipGetLastError(), "count launch");
+        HIPCHK(hipMemcpyAsync(part->h_scratch + 512, part->d_kat.p, 8, hipMemcpyDeviceToHost, part->stream), "D2H count");
+    }
+    for (int k = 0; k < np; k++) {
+        HIPCHK(hipSetDevice(parts[k]->device), "hipSetDevice");
+        HIPCHK(hipStreamSynchronize(parts[k]->stream), "count sync");
+        total += *(const unsigned long long *)(parts[k]->h_scratch + 512);
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    *count = total;
+    return query_bounds_check(ctx);
 }
 
 int sjhip_count_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen, uint64_t *count) {
     if (!count) return SJHIP_ERR_ARG;
-    QView q;
-    uint32_t n = 0;
-    int rc = make_view(ctx, key, klen, value, vlen, &q, &n);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    rc = arena_reserve(ctx, ctx->d_kat, 64);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, 8, ctx->stream), "count memset");
-    hipLaunchKernelGGL(k_q_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, (unsigned long long *)ctx->d_kat.p);
-    HIPCHK(hipGetLastError(), "count launch");
-    unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
-    HIPCHK(hipMemcpyAsync(h, ctx->d_kat.p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H count");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "count sync");
-    *count = *h;
-    return query_bounds_check(ctx);
+    return count_over_parts(ctx, key, klen, value, vlen, count, [](sjhip_ctx *part, const QView &q, uint32_t n, unsigned long long *d) {
+        hipLaunchKernelGGL(k_q_count, dim3((n + 255) / 256), dim3(256), 0, part->stream, q, d);
+    });
 }
 
 int sjhip_filter_where(sjhip_ctx *ctx, const uint8_t *key, size_t klen, const uint8_t *value, size_t vlen,
@@ -666,8 +718,8 @@ int sjhip_fetch_filtered(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_ds
 }
 
 // ---- paths, typed values, key sets ------------------------------------------------------------------------------------------
-static int make_path_view(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, const uint8_t *val,
-                          size_t vlen, QView *q, QPath *pth, uint32_t *records) {
+// the keys of a path / key set: where each one ends in the concatenation (QView::key holds the bytes)
+static int make_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, QPath *pth, size_t *total_out) {
     if (!ctx || !keys || !key_lens || n_keys == 0) return SJHIP_ERR_ARG;
     if (n_keys > (uint32_t)QPATH_MAX) {
         ctx_set_error(ctx, "a path / key set holds at most %d keys", QPATH_MAX);
@@ -684,31 +736,62 @@ static int make_path_view(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *k
     }
     for (uint32_t j = n_keys; j < (uint32_t)QPATH_MAX; j++) pth->end[j] = (u32)total;
     pth->n = n_keys;
+    *total_out = total;
+    return SJHIP_OK;
+}
+
+// Per-record answers (`per` 8-byte words for every record) of every part of ctx's result, laid end to end in `out` in document
+// order: launch(part, q, n, d_out) fills n * per words on the part's device.  cap_records: room in `out`; *records: records of
+// the whole result.
+template <typename F>
+static int records_over_parts(sjhip_ctx *ctx, const uint8_t *keys, size_t klen, uint32_t per, uint64_t *out, size_t cap_records,
+                              size_t *records, const char *who, F launch) {
     static const uint8_t none = 0;
-    return make_view(ctx, keys, total, val ? val : &none, val ? vlen : 0, q, records);
+    static thread_local sjhip_ctx *parts[MAX_PARTS];
+    const int np = result_parts(ctx, parts, MAX_PARTS);
+    if (np == 0) return make_view(ctx, nullptr, keys, klen, &none, 0, nullptr, nullptr);
+    size_t total = 0;
+    for (int k = 0; k < np; k++) total += (size_t)parts[k]->q_records + 1u;
+    *records = total;
+    if (cap_records < total) {
+        ctx_set_error(ctx, "%s: room for %zu records, the result holds %zu", who, cap_records, total);
+        return SJHIP_ERR_ARG;
+    }
+    size_t at = 0;
+    for (int k = 0; k < np; k++) {
+        sjhip_ctx *part = parts[k];
+        QView q;
+        uint32_t n = 0;
+        int rc = make_view(ctx, part, keys, klen, &none, 0, &q, &n);
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(part->device), "hipSetDevice");
+        const size_t bytes = (size_t)n * per * 8;
+        rc = arena_reserve(part, part->d_kat, bytes + 64);
+        if (rc) return rc;
+        launch(part, q, n, (u64 *)part->d_kat.p);
+        HIPCHK(hipGetLastError(), "query launch");
+        HIPCHK(hipMemcpyAsync(out + at * per, part->d_kat.p, bytes, hipMemcpyDeviceToHost, part->stream), "D2H per-record answers");
+        at += n;
+    }
+    for (int k = 0; k < np; k++) {
+        HIPCHK(hipSetDevice(parts[k]->device), "hipSetDevice");
+        HIPCHK(hipStreamSynchronize(parts[k]->stream), "query sync");
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    return query_bounds_check(ctx);
 }
 
 int sjhip_find_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *index_out,
                     size_t cap, size_t *records) {
     if (!index_out || !records) return SJHIP_ERR_ARG;
-    QView q;
     QPath pth;
-    uint32_t n = 0;
-    int rc = make_path_view(ctx, keys, key_lens, n_keys, nullptr, 0, &q, &pth, &n);
+    size_t klen = 0;
+    const int rc = make_path(ctx, keys, key_lens, n_keys, &pth, &klen);
     if (rc) return rc;
-    *records = n;
-    if (cap < n) {
-        ctx_set_error(ctx, "sjhip_find_path: room for %zu records, the result holds %u", cap, n);
-        return SJHIP_ERR_ARG;
-    }
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    rc = arena_reserve(ctx, ctx->d_kat, (size_t)n * 8 + 64);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_q_find_path, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, pth, (u64 *)ctx->d_kat.p);
-    HIPCHK(hipGetLastError(), "find_path launch");
-    HIPCHK(hipMemcpyAsync(index_out, ctx->d_kat.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H path indexes");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "find_path sync");
-    return query_bounds_check(ctx);
+    return records_over_parts(ctx, keys, klen, 1, index_out, cap, records, "sjhip_find_path",
+                              [&](sjhip_ctx *part, const QView &q, uint32_t n, u64 *d) {
+                                  hipLaunchKernelGGL(k_q_find_path, dim3((n + 255) / 256), dim3(256), 0, part->stream, q, pth, d);
+                              });
 }
 
 int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, int op,
@@ -725,31 +808,23 @@ int sjhip_count_where_path(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *
     } else if (is_str && !value && vlen) {
         return SJHIP_ERR_ARG;
     }
-    QView q;
     QPath pth;
-    uint32_t n = 0;
-    int rc = make_path_view(ctx, keys, key_lens, n_keys, is_str ? (const uint8_t *)value : nullptr, is_str ? vlen : 0, &q, &pth, &n);
+    size_t klen = 0;
+    const int rc = make_path(ctx, keys, key_lens, n_keys, &pth, &klen);
     if (rc) return rc;
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    rc = arena_reserve(ctx, ctx->d_kat, 64);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, 8, ctx->stream), "count memset");
-    hipLaunchKernelGGL(k_q_count_path, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, pth, op, want, (unsigned long long *)ctx->d_kat.p);
-    HIPCHK(hipGetLastError(), "count_where_path launch");
-    unsigned long long *h = (unsigned long long *)(ctx->h_scratch + 512);
-    HIPCHK(hipMemcpyAsync(h, ctx->d_kat.p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H count");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "count sync");
-    *count = *h;
-    return query_bounds_check(ctx);
+    static const uint8_t none = 0;
+    return count_over_parts(ctx, keys, klen, is_str && value ? (const uint8_t *)value : &none, is_str ? vlen : 0, count,
+                            [&](sjhip_ctx *part, const QView &q, uint32_t n, unsigned long long *d) {
+                                hipLaunchKernelGGL(k_q_count_path, dim3((n + 255) / 256), dim3(256), 0, part->stream, q, pth, op, want, d);
+                            });
 }
 
 int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_lens, uint32_t n_keys, uint64_t *out,
                        size_t cap_records, size_t *records) {
     if (!out || !records) return SJHIP_ERR_ARG;
-    QView q;
     QPath set;
-    uint32_t n = 0;
-    int rc = make_path_view(ctx, keys, key_lens, n_keys, nullptr, 0, &q, &set, &n);
+    size_t klen = 0;
+    const int rc = make_path(ctx, keys, key_lens, n_keys, &set, &klen);
     if (rc) return rc;
     for (uint32_t a = 0; a < n_keys; a++)  // a set: the reference's onlyKeys is a map
         for (uint32_t b = a + 1; b < n_keys; b++) {
@@ -759,18 +834,8 @@ int sjhip_project_keys(sjhip_ctx *ctx, const uint8_t *keys, const uint32_t *key_
                 return SJHIP_ERR_ARG;
             }
         }
-    *records = n;
-    if (cap_records < n) {
-        ctx_set_error(ctx, "sjhip_project_keys: room for %zu records, the result holds %u", cap_records, n);
-        return SJHIP_ERR_ARG;
-    }
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    const size_t bytes = (size_t)n * n_keys * 8;
-    rc = arena_reserve(ctx, ctx->d_kat, bytes + 64);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_q_project, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q, set, (u64 *)ctx->d_kat.p);
-    HIPCHK(hipGetLastError(), "project_keys launch");
-    HIPCHK(hipMemcpyAsync(out, ctx->d_kat.p, bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H projected members");
-    HIPCHK(hipStreamSynchronize(ctx->stream), "project_keys sync");
-    return query_bounds_check(ctx);
+    return records_over_parts(ctx, keys, klen, n_keys, out, cap_records, records, "sjhip_project_keys",
+                              [&](sjhip_ctx *part, const QView &q, uint32_t n, u64 *d) {
+                                  hipLaunchKernelGGL(k_q_project, dim3((n + 255) / 256), dim3(256), 0, part->stream, q, set, d);
+                              });
 }

@@ -270,7 +270,8 @@ int sjhip_serialize_ex(sjhip_ctx *ctx, uint32_t flags, size_t *tags_len, size_t 
     ctx->ser_valid = 0;
     ctx->ms_valid = 0;
     if (!ctx->q_valid || ctx->tape_len == 0) {
-        ctx_set_error(ctx, "no parse result on the device (sjhip_serialize follows a successful sjhip_parse / sjhip_parse_device)");
+        if (ctx->big_valid) ctx_set_error(ctx, "sjhip_serialize works on the result of one context; this ND result was parsed shard by shard");
+        else ctx_set_error(ctx, "no parse result on the device (sjhip_serialize follows a successful sjhip_parse / sjhip_parse_device)");
         return SJHIP_ERR_ARG;
     }
     if (!(ctx->p_flags & SJHIP_FLAG_COPY_STRINGS)) {
@@ -582,7 +583,7 @@ bool get_block(const uint8_t *src, size_t len, size_t *o, uint64_t *size, size_t
 
 int sjhip_deserialize(sjhip_ctx *ctx, const uint8_t *stream, size_t len, size_t *tape_len, size_t *strings_len, size_t *message_len) {
     if (!ctx || !stream) return SJHIP_ERR_ARG;
-    ctx->q_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->kf_valid = 0;
+    ctx->q_valid = ctx->r_valid = ctx->ser_valid = ctx->ms_valid = ctx->f_valid = ctx->kf_valid = 0;
     ctx->pending = 0;
     ctx->pack_valid = 0;
     ctx->tape_len = ctx->strings_len = 0;

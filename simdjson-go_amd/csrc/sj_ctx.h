@@ -39,6 +39,8 @@ struct sjhip_ctx {
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;
     int q_valid = 0;              // the device holds the whole result of an unsharded parse: queries are possible
+    int r_valid = 0;              // the device holds the result of a parse -- whole, or one shard of a sharded ParseND whose stored
+    uint64_t r_tape_base = 0, r_strings_base = 0, r_msg_base = 0;  // indices carry these bases (query.hip works in the merged index space)
     uint32_t q_records = 0;       // record-separating newline runs of that parse (records - 1)
     size_t q_tape_len = 0, q_strings_len = 0;  // last sjhip_filter_where
     int f_valid = 0;              // a filtered result is resident (sjhip_fetch_filtered)
@@ -51,6 +53,7 @@ struct sjhip_ctx {
     // a parse between its two phases (sjhip_parse_shard_begin / _finish)
     int pending = 0;
     int p_deferred = 0;   // stage 1's result has not been collected yet (small documents: one synchronisation per parse)
+    int p_collected = 0;  // ... but a shard's phase 1 has: its sizes and stage 1's verdict arrive with one synchronisation (parse_begin)
     int p_no_defer = 0;   // the deferred run met more tokens than its layout holds: this parse takes the synchronous path
     uint32_t p_density_q = 0;  // tokens per KiB of the context's last successful parse (+1), 0: none yet -- a large document is
                                // then parsed without the host round trip between the stages, laid out for that density + 1/16 (or what the arenas hold)
@@ -86,6 +89,9 @@ int parse_nd_big(sjhip_ctx *ctx, const uint8_t *msg, size_t len, uint32_t flags,
 int fetch_nd_big(sjhip_ctx *ctx, uint64_t *tape_dst, uint8_t *strings_dst);
 void release_nd_big(sjhip_ctx *ctx);
 size_t nd_big_device_bytes(const sjhip_ctx *ctx);  // arenas of the shard contexts of a sharded ND parse
+// the shards of the merged result of parse_nd_big, in document order (empty shards have no context to look at: null)
+int nd_big_shards(const sjhip_ctx *ctx);
+sjhip_ctx *nd_big_shard(const sjhip_ctx *ctx, int k);
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                    uint8_t *d_kind, void *zero2, size_t zero2_bytes);
 int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);

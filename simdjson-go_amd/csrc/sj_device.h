@@ -15,7 +15,9 @@ struct Stage1State {
     uint32_t ends_in_quote;  // reference prev_iter_inside_quote != 0 at the end
     uint32_t done;           // blocks that have finished: the last one copies this record to pinned host memory
     uint32_t last_byte;      // msg[len - 1] (host copy only: the end-of-document verdict needs it)
-    uint32_t pad[9];
+    uint32_t has_starter;    // whole parse: some unit holds a backslash that starts an escape (stage 2 reads it on the device:
+                             // WithCopyStrings(false) of a message without one copies nothing and measures nothing)
+    uint32_t pad[8];
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
 // the packed result word the last block of stage 1 stores to pinned host memory
@@ -53,6 +55,7 @@ struct S2Args {
     const uint8_t *d_kind;  // the token kinds stage 1 wrote next to the positions
     size_t n;               // tokens; with n_dev an upper bound (the arrays and grids are sized for it)
     const unsigned long long *n_dev;  // null, or Stage1State::total on the device: the host did not wait for stage 1
+    const uint32_t *s1_has_starter;   // Stage1State::has_starter on the device (null: unknown, assume there are escapes)
     uint32_t flags;
     void *ws_zero;          // stage2_zero_bytes(): zero before the measure phase (stage 1's preparation kernel does it)
     void *ws;               // stage2_workspace_bytes(n)

@@ -338,7 +338,7 @@ template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
                                         const S1Aux &aux, const u8 *__restrict__ edge, u64 (&kp)[CH][4], uint2 *s_ucnt,
-                                        bool TOP = false) {
+                                        u32 &seen_st, bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
 #if defined(SJ_S1_ROLL)
@@ -470,6 +470,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         const u32 tot = lane63(incl);
         // (whole parse, bit 28: the unit holds an escape starter -- k_str_emit does not read the st masks of the others)
         const u32 has_st = AUX && __ballot(((u32)starters | (u32)(starters >> 32)) != 0) != 0 ? 1u : 0u;
+        seen_st |= has_st;  // (wave-uniform)
         // (bit 29: the unit holds an unescaped quote -- the walks of the selective copy pass over units without one 64 at a time)
         const u32 has_q = AUX && par_ballot_any(quote_bits) ? 1u : 0u;
         if (lane == 0)
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     u32 t_prev = 0;                         // T(j-1): the tile that is flattened in iteration j
     u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // its aggregates; meaningful in wave 0 only
     bool err = false;
+    u32 seen_st = 0;                        // whole parse: a unit of this wave held an escape starter
     for (u32 j = 0;; j++) {
         const bool first = j == 0;
         const u32 t_a = uniform(s_ticket[j & 3u]);                               // phase A runs on T(j)
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
-                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, s_ucnt[AUX ? ua : 0], wave == 0 && !first);
+                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, s_ucnt[AUX ? ua : 0], seen_st, wave == 0 && !first);
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
         }
         u32 *res = s_res2[j & 1u];
@@ -796,6 +798,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         t_prev = t_a;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+    if (AUX && seen_st && lane == 0) atomicOr(&st->has_starter, 1u);  // (at most one per wave and launch)
     block_done(st, aux, base + lead, len);
 }
 
@@ -868,8 +871,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         s_tkn = 3;
     }
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
+    u32 seen_st_nb = 0;  // (this kernel never runs the whole parse: unused)
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge, kp, nullptr);
+                                    aux, edge, kp, nullptr, seen_st_nb);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();
     {
@@ -965,7 +969,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
-                                            s_unit[ua], aux, edge, kp, nullptr, wave == 0);
+                                            s_unit[ua], aux, edge, kp, nullptr, seen_st_nb, wave == 0);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             u32 arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -72,6 +72,7 @@ struct S2Dev {
     const unsigned long long *n_dev;  // null, or the token count on the device (Stage1State::total): the host has not
                                       // waited for stage 1 (small documents: one synchronisation per parse)
     u32 ndjson, copy_strings;
+    const u32 *s1_has_starter;  // Stage1State::has_starter on the device, or null (see no_escapes below)
     Arr<const u8> kind;  // [n] token kinds (stage 1 writes them next to the positions)
     Arr<u32> dlen;     // [n] selective copy only: unescaped length | DLEN_COPY, or DLEN_INVALID
     Arr<u32> str_off;  // [n] selective copy only: Strings.B offset of a copied string
@@ -130,6 +131,17 @@ __device__ __forceinline__ u32 token_count(const S2Dev &p) {
     return n < p.n ? (u32)n : p.n;
 }
 
+// WithCopyStrings(false) of a message that holds no escape starter at all (round 6; parking-citations, most machine-written
+// NDJSON): parseString copies a string only if unescaping changed it (parse_string_amd64.go:33-42), so NOTHING is copied, Strings.B
+// is empty, every string word points into the message -- and the raw length of a string equals its unescaped length, i.e. the
+// difference of two offsets of the full compaction (what copy mode computes from stage 1's unit counts without touching the
+// message).  The selective machinery is skipped: no string half in k_measure (it visited every unit: 90 us on configs[4]),
+// k_str_emit<true> only numbers the strings (soff[], 4 bytes each, no message read, no compaction), the emit pass reads 4 instead
+// of 8 bytes per string.  The flag is stage 1's (one atomic per wave that saw a starter); stage 2 is queued before the host
+// knows it, so every kernel asks on the device (grid-uniform).
+__device__ __forceinline__ bool no_escapes(const S2Dev &p) {
+    return !p.copy_strings && p.s1_has_starter != nullptr && *p.s1_has_starter == 0u;
+}
 // inclusive sum over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU instructions, no LDS crossbar)
 __device__ __forceinline__ u32 wave_incl_sum(u32 v) {
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
@@ -519,7 +531,8 @@ __device__ __forceinline__ void str_scan_body(const S2Dev &p, int seg) {
             if (seg == p.unit_segs - 1) {
                 if (STR) p.st->n_strings = (u32)(before.s + tot);
                 else {
-                    p.st->strings_len_masks = before.s + tot;
+                    // (no_escapes: the counts are the full compaction's -- they only measure the strings; nothing is copied)
+                    p.st->strings_len_masks = no_escapes(p) ? 0ull : before.s + tot;
                     if (before.s + tot > 0xfffffff0ull) atomicOr(&p.st->err, 4u);  // (Strings.B offsets are 32 bits wide)
                 }
             }
@@ -629,6 +642,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
     if (threadIdx.x < 16) s_sel[threadIdx.x] = c_sel.v[threadIdx.x];
     s_esc[threadIdx.x] = c_esc.v[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the unit's scalars stay in SGPRs)
+    const bool NE = SEL && no_escapes(p);  // nothing is copied: the strings are only numbered (offsets of the full compaction in soff[])
     const u64 nwaves = (u64)gridDim.x * 4;
     u64 unit = (u64)blockIdx.x * 4 + wave;
     struct Raw {   // what is requested two units ahead
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         c.flags = ((sw != 0 || (sp >> 63) != 0) ? 1u : 0u) | (uh & 2u) | ((uhp & 2u) << 1) | ((uh & 1u) << 3);
         c.sb = p.unit_str[u];
         c.g = p.unit_cnt[u];
-        if (SEL) {
+        if (SEL && !NE) {  // (k_measure's: not written when the message holds no escape)
             c.uf = p.unit_copy[u];
             c.tq = p.unit_tq[u];
         }
@@ -717,7 +731,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             flags = f.esc != 0 ? CHUNK_SLOW : 0u;
         }
         u64 cq = 0;
-        if (SEL) {  // only the bytes of strings that hold an escape starter
+        if (SEL && !NE) {  // only the bytes of strings that hold an escape starter
             u64 sel = 0;
             if ((x.h & 2u) || x.uf)  // (uniform)
                 sel = sel_wave_mask(chunk_sel(x.qm, x.q, x.st, h), (x.uf & USEL_IN) ? 1u : 0u, (x.uf & USEL_OUT) ? 1u : 0u, lane);
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         if ((stotal != 0 || x.last) && x.live) {  // (uniform)
             const bool staged = stotal <= SO_CAP;  // (uniform)
             u32 far = 0;  // SEL: aligned offset of the first closing quote behind this chunk
-            if (SEL) {
+            if (SEL && !NE) {
                 const u64 cqb = __ballot(cq != 0);
                 const u64 above = lane < 63 ? cqb >> (lane + 1) : 0ull;
                 const int L = above ? lane + 1 + (int)ctz64(above) : lane;  // the next chunk of the unit with a closing quote
@@ -750,7 +764,10 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             for (u64 r = f.oq; r != 0; r &= r - 1, i++) {
                 const u32 b = (u32)ctz64(r);
                 const u32 val = x.g + pre + (u32)popc64(v.em & ((1ull << b) - 1ull));
-                if (SEL) {
+                if (SEL && NE) {
+                    if (staged) s_so[i] = val;
+                    else if (x.sb + i < p.soff_cap) p.soff[x.sb + i] = val;
+                } else if (SEL) {
                     const u64 cqa = b < 63 ? cq & (~0ull << (b + 1)) : 0ull;  // closing quotes of the chunk behind the opening one
                     const u32 open_at = (u32)((u * 64 + (u64)lane) * 64) + b;
                     const u32 raw = (cqa ? (u32)((u * 64 + (u64)lane) * 64) + (u32)ctz64(cqa) : far) - open_at - 1u;
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
                 __builtin_amdgcn_wave_barrier();
                 for (u32 j = (u32)lane; j < stotal; j += 64) {
                     if (x.sb + j >= p.soff_cap) continue;
-                    if (SEL) p.sinfo[x.sb + j] = s_so2[j];
+                    if (SEL && !NE) p.sinfo[x.sb + j] = s_so2[j];
                     else p.soff[x.sb + j] = s_so[j];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -774,9 +791,14 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
             // (behind the last string: the end of Strings.B, so that every length is a difference)
             if (x.last && lane == 63 && x.sb + stotal < p.soff_cap) {
-                if (SEL) p.sinfo[x.sb + stotal] = make_uint2(x.g + (tot & 0xffffu), 0u);
+                if (SEL && !NE) p.sinfo[x.sb + stotal] = make_uint2(x.g + (tot & 0xffffu), 0u);
                 else p.soff[x.sb + stotal] = x.g + (tot & 0xffffu);
             }
+        }
+        if (NE) {  // the unit's bytes stay where they are: nothing to load, patch, compact or store
+            v.em = 0;
+            v.esc = 0;
+            v.pre_raw = 0;
         }
         return v;
     };
@@ -1200,7 +1222,7 @@ __global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
     if (blockIdx.x < mblocks) {
         if (p.copy_strings) str_masks_body<false>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
-        else str_masks_body<true>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
+        else if (!no_escapes(p)) str_masks_body<true>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
     }
     else s2_reduce_planes(p, blockIdx.x - mblocks);
 }
@@ -1326,11 +1348,14 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     const u32 lane_w = ex.x & 0x3fffu, lane_bc = ex.x >> 14, lane_open = ex.y & 0x1fffu, lane_nb = ex.y >> 13;
     bool bad = lane16_illegal(m);  // a token that is legal in no context at all
     const u32 SB = MASKS ? S + 1u : S, SC = SB + B + D;
-    const bool y_staged = SC + S <= (u32)S2_TILE + 8u;  // (block-uniform)
+    // MODE 2 on a message without an escape starter (no_escapes): no string is copied, k_str_emit left the offsets of the FULL
+    // compaction in soff[] -- a string's length is the difference of two of them, as in MODE 1 -- and no raw lengths
+    const bool NE = MODE == 2 && no_escapes(p);        // (grid-uniform)
+    const bool y_staged = !NE && SC + S <= (u32)S2_TILE + 8u;  // (block-uniform)
     if (MASKS && !SJ_EXPBIT(p, 9)) {  // the tile's first string is string number tp.s of the message (k_measure counted them through the scan)
         for (u32 j = (u32)tid; j <= S; j += BLK) {
             const bool in = tp.s + j < p.soff_cap;
-            if (MODE == 2) {
+            if (MODE == 2 && !NE) {
                 const uint2 e = in ? p.sinfo[tp.s + j] : make_uint2(0u, 0u);
                 s_q[j] = e.x;
                 if (y_staged && j < S) s_q[SC + j] = e.y;
@@ -1384,9 +1409,9 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
             const u32 j = (u32)__builtin_ctz(r), lo = lane_w + lane16_words_before(m, j);
             const u32 so = s_q[ks], se = s_q[ks + 1];
             u64 w0 = string_word(true, p.strings_base + so, 0), w1 = (u64)(se - so);
-            if (MODE == 2 && se == so) {
+            if (MODE == 2 && (NE || se == so)) {
                 w0 = string_word(false, 0, p.msg_base + tbase + s_pos[(u32)tid * ITEMS + j] + 1);
-                w1 = (u64)(y_staged ? s_q[SC + ks] : (tp.s + ks < p.soff_cap ? p.sinfo[tp.s + ks].y : 0u));
+                if (!NE) w1 = (u64)(y_staged ? s_q[SC + ks] : (tp.s + ks < p.soff_cap ? p.sinfo[tp.s + ks].y : 0u));
             }
             if (!SJ_EXPBIT(p, 8)) *reinterpret_cast<uint4 *>(arr_at(p.tape, T0 + lo, 2)) = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32));
             if (p.keyflag) p.keyflag[(T0 + lo) >> 1] = (u8)((m.keystr >> j) & 1u);
@@ -1905,6 +1930,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.n_dev = a.n_dev;
     p.ndjson = a.flags & 1u;
     p.copy_strings = (a.flags >> 1) & 1u;
+    p.s1_has_starter = a.s1_has_starter;
     p.kind = SJ_ARR(a.d_kind, n, A_KIND);
     p.br_info = SJ_ARR(reinterpret_cast<u8 *>(carve(n + 16)), n + 16, A_BR_INFO);
     p.dlen = SJ_ARR(reinterpret_cast<u32 *>(carve(n * 4)), n, A_DLEN);

@@ -119,6 +119,99 @@ def run_shard(rank: int, world: int, empty: bool, begin: Callable, finish: Calla
     return tape, strings, tape_base, strings_base
 
 
+class ShmMailbox:
+    """The exchange of a sharded ParseND between the ranks of ONE node without a collective launch: a POSIX shared-memory
+    segment with one 128-byte slot per rank and exchange parity (two buffers: a rank can be at most one exchange ahead of a
+    rank that is still reading, see gather()).  gather(vals) has the signature parse_shard / run_shard expect of all_gather.
+
+    Why: the data the ranks exchange is 24 bytes per rank; through torch.distributed it costs a tensor, two launches and a
+    synchronisation per call (RCCL) or a TCP round (gloo) -- tens of microseconds next to a shard parse of ~150 us.  Here a
+    rank stores its values and then its sequence number (x86 total store order; the readers poll the sequence numbers), about a
+    microsecond when the ranks arrive together.  RCCL / gloo stay the fallback (across nodes, or where /dev/shm is not shared)
+    and bench.py reports which one it used.  A rank that does not arrive within `timeout` seconds fails the exchange with a
+    ShardError(-1) on the ranks that waited (nobody spins forever)."""
+    SLOT_WORDS = 16  # 128 bytes: [0] sequence number, [1] count, [2 ..] values
+    MAX_VALS = SLOT_WORDS - 2
+
+    def __init__(self, name: str, rank: int, world: int, create: bool, timeout: float = 30.0):
+        from multiprocessing import shared_memory
+        self.rank, self.world, self.timeout, self.name = rank, world, timeout, name
+        size = 2 * world * self.SLOT_WORDS * 8
+        if create:
+            try:  # a segment a crashed run left behind
+                old = shared_memory.SharedMemory(name=name)
+                old.close()
+                old.unlink()
+            except FileNotFoundError:
+                pass
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+            self.shm.buf[:size] = bytes(size)
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.owner = create
+        self.words = self.shm.buf.cast("Q")  # (a flat view of 64-bit words: plain Python indexing, ~50 ns per access)
+        self.seq = 0
+
+    def gather(self, vals):
+        """all_gather of a short tuple of ints (each below 2^63, may be negative: stored as two's complement)."""
+        import time
+        vals = [int(v) & 0xFFFFFFFFFFFFFFFF for v in vals]
+        assert len(vals) <= self.MAX_VALS
+        self.seq += 1
+        seq, par = self.seq, self.seq & 1
+        # Two buffers are enough: a rank enters exchange k+2 (which reuses the buffer of exchange k) only after it has seen
+        # EVERY rank's sequence number k+1, and a rank publishes k+1 only after it has finished reading exchange k.
+        w, sw = self.words, self.SLOT_WORDS
+        base = (par * self.world + self.rank) * sw
+        w[base + 1] = len(vals)
+        for k, v in enumerate(vals):
+            w[base + 2 + k] = v
+        w[base] = seq  # published last
+        out = [None] * self.world
+        t0 = None
+        for r in range(self.world):
+            b = (par * self.world + r) * sw
+            spins = 0
+            while w[b] != seq:
+                spins += 1
+                if spins & 0x3FF == 0:
+                    now = time.perf_counter()
+                    t0 = t0 or now
+                    if now - t0 > self.timeout:
+                        raise ShardError(-1, [r])
+            out[r] = tuple(v - (1 << 64) if v >= 1 << 63 else v for v in w[b + 2:b + 2 + w[b + 1]])
+        return out
+
+    def close(self):
+        try:
+            self.words.release()
+            self.words = None
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def open_mailbox(rank: int, world: int, barrier: Callable = None, tag: str = None, timeout: float = 30.0):
+    """One ShmMailbox per job: rank 0 creates the segment, `barrier()` (any collective of the job, called once at set-up),
+    the others attach.  The name is derived from the rendezvous (MASTER_PORT) so that every rank of a torchrun job computes
+    the same one.  Returns None where shared memory is not available (the caller keeps its all_gather)."""
+    import os
+    name = "sjhip_mb_%s_%d" % (tag or os.environ.get("MASTER_PORT", "0"), world)
+    try:
+        mb = ShmMailbox(name, rank, world, create=True, timeout=timeout) if rank == 0 else None
+        if barrier:
+            barrier()
+        if rank != 0:
+            mb = ShmMailbox(name, rank, world, create=False, timeout=timeout)
+        if barrier:
+            barrier()
+        return mb
+    except Exception:  # noqa: BLE001 -- no /dev/shm, name clash, ...: the collective is the fallback
+        return None
+
+
 def device_callbacks(ctx, copy_strings=True):
     """begin / finish / trim bound to a sjhip.Context (the shard is uploaded with torch)."""
     import ctypes as C

@@ -81,7 +81,7 @@ def _bad_docs():
     yield b'{"a":tru}\n' + good * 2 + b'"unterminated', 1     # stage 2 on rank 0 and stage 1 on rank 1: stage 1 wins
 
 
-def _worker(rank, world, port, copy_strings, q):
+def _worker(rank, world, port, copy_strings, q, exchange="gloo"):
     import torch.distributed as dist
     from sjhip import ndshard
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -93,6 +93,12 @@ def _worker(rank, world, port, copy_strings, q):
         box = [None] * world
         dist.all_gather_object(box, tuple(int(x) for x in vals))
         return box
+
+    mb = None
+    if exchange == "shm":  # the node-local mailbox (ndshard.ShmMailbox) in place of the collective: same control flow, same results
+        mb = ndshard.open_mailbox(rank, world, barrier=dist.barrier, tag=str(port))
+        assert mb is not None
+        gather = mb.gather  # noqa: F811
 
     # an invalid shard on one rank: every rank raises the same ShardError, nobody stays behind in a collective
     for doc, want in _bad_docs():
@@ -112,11 +118,13 @@ def _worker(rank, world, port, copy_strings, q):
     if rank == 0:
         q.put(out)
     dist.barrier()
+    if mb:
+        mb.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("copy_strings", [True, False])
-def test_two_rank_gloo_merge_equals_oracle(copy_strings):
+@pytest.mark.parametrize("copy_strings,exchange", [(True, "gloo"), (False, "gloo"), (True, "shm")])
+def test_two_rank_gloo_merge_equals_oracle(copy_strings, exchange):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -124,7 +132,7 @@ def test_two_rank_gloo_merge_equals_oracle(copy_strings):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, copy_strings, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, copy_strings, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = q.get(timeout=180)
@@ -149,3 +157,31 @@ def test_record_cuts():
         for a, b in cuts[:-1]:
             assert b == len(doc) or doc[b - 1:b] == b"\n"           # every cut follows a newline
     assert ndshard.bases_from_sizes([(5, 2), (0, 0), (7, 1)]) == [(0, 0), (5, 2), (5, 2)]
+
+
+def test_mailbox_exchange_order_and_timeout():
+    """ShmMailbox alone: values (negative ones too) arrive in rank order over many exchanges of alternating parity, a rank that
+    never arrives fails the waiting rank with a ShardError instead of a hang, and a stale segment of the same name is replaced."""
+    import threading
+    from sjhip import ndshard
+    tag = "t%d" % os.getpid()
+    a = ndshard.ShmMailbox("sjhip_mb_%s_2" % tag, 0, 2, create=True, timeout=20.0)
+    b = ndshard.ShmMailbox("sjhip_mb_%s_2" % tag, 1, 2, create=False, timeout=20.0)
+    got = {}
+
+    def run(mb, r):
+        got[r] = [mb.gather((r * 100 + k, -k, 1 << 40)) for k in range(200)]
+    ts = [threading.Thread(target=run, args=(m, r)) for r, m in enumerate((a, b))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r in (0, 1):
+        assert got[r] == [[(k, -k, 1 << 40), (100 + k, -k, 1 << 40)] for k in range(200)]
+    a.timeout = 0.2
+    with pytest.raises(ndshard.ShardError):
+        a.gather((1,))  # rank 1 does not come
+    b.close()
+    a.close()
+    c = ndshard.ShmMailbox("sjhip_mb_%s_2" % tag, 0, 2, create=True)  # (the name is free again / a leftover is replaced)
+    c.close()

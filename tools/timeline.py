@@ -1,19 +1,19 @@
-"""Timeline of the last parses in a rocprofv3 rocpd database: kernel name, start relative to the first kernel of the parse,
-duration, gap to the previous kernel: python tools/timeline.py <db> [parses]"""
+"""Kernel timeline of the LAST `reps` repetitions of a launch chain from a rocprofv3 rocpd database: per kernel the start relative to
+the chain's first kernel, the duration and the gap to the kernel in front (microseconds): python tools/timeline.py <db> [chains]"""
 import sqlite3
 import sys
 
 con = sqlite3.connect(sys.argv[1])
+want = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-# a parse starts with k_s1_prepare
+# a chain begins with the preparation kernel of stage 1
 starts = [i for i, r in enumerate(rows) if "k_s1_prepare" in r[0]]
-want = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-for s in starts[-want:]:
-    e = next((x for x in starts if x > s), len(rows))
-    t0 = rows[s][1]
+for ci in starts[-want:]:
+    nxt = [s for s in starts if s > ci]
+    chain = rows[ci:(nxt[0] if nxt else len(rows))]
+    t0 = chain[0][1]
     prev_end = t0
-    print("-- parse")
-    for name, a, b in rows[s:e]:
-        print(f"  {name.split('(')[0][:44]:44s} start {(a - t0) / 1000:8.1f} us  dur {(b - a) / 1000:7.1f} us  gap {(a - prev_end) / 1000:6.1f} us")
-        prev_end = b
-    print(f"  total {(rows[e - 1][2] - t0) / 1000:.1f} us")
+    print(f"-- chain of {len(chain)} launches, {(chain[-1][2] - t0) / 1e3:.1f} us from first start to last end")
+    for name, s, e in chain:
+        print(f"  {name.split('(')[0][:44]:44s} start {(s - t0) / 1e3:7.1f}  dur {(e - s) / 1e3:6.1f}  gap {(s - prev_end) / 1e3:5.1f}")
+        prev_end = e
