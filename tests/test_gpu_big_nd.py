@@ -314,12 +314,17 @@ def test_single_document_beyond_4GiB_second_shape():
             if not np.array_equal(tape[b], want):
                 d = np.nonzero(tape[b] != want)[0]
                 raise AssertionError((copy, b, d[:5], [hex(int(x)) for x in tape[b][d[:3]]], [hex(int(x)) for x in want[d[:3]]]))
-        # Strings.B: the blocks' bytes, then the tail's
-        s_tail = len(r2.strings) - 2 * sb
-        assert len(pj.Strings) == copies * sb + s_tail
-        if sb:
-            assert (pj.Strings[:copies * sb].reshape(copies, sb) == r2.strings[None, :sb]).all()
-        assert bytes(pj.Strings[copies * sb:]) == bytes(r2.strings[2 * sb:])
+        # Strings.B: the strings in front of the array (the keys of the nesting, where they are copied), the blocks' bytes, the tail's
+        s_rest = len(r2.strings) - 2 * sb
+        assert len(pj.Strings) == copies * sb + s_rest
+        s_head = 0
+        if sb:  # the first string of block 0 that lies in Strings.B (bit 55 of its payload) lies at the end of the head's bytes
+            is_str = ((b0 >> TAG) == ord('"')) & (((b0 >> np.uint64(55)) & np.uint64(1)) == 1)
+            is_str[1:] &= ~(((b0[:-1] >> TAG) == ord('"')))      # (not the length word behind a string word)
+            s_head = int(b0[np.nonzero(is_str)[0][0]] & np.uint64((1 << 55) - 1))
+            assert (pj.Strings[s_head:s_head + copies * sb].reshape(copies, sb) == r2.strings[None, s_head:s_head + sb]).all()
+        assert bytes(pj.Strings[:s_head]) == bytes(r2.strings[:s_head])
+        assert bytes(pj.Strings[s_head + copies * sb:]) == bytes(r2.strings[s_head + 2 * sb:])
         # consumers on the resident result: the members behind the array, through five levels of nesting
         (v,) = ctx.find_path(*(path + [b"n"]))
         assert int(v) == len(pj.Tape) - ntail + int(np.nonzero((r2.tape[-ntail:] >> TAG) == ord("d"))[0][0])
