@@ -275,7 +275,7 @@ int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjso
                         size_t *n, int *ok) {
     if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
     invalidate_result(ctx);
-    return stage1_run_device(ctx, d_msg, len, ndjson, d_pos, pos_cap, 0, 0, n, ok);
+    return stage1_run_device(ctx, d_msg, len, ndjson != 0, d_pos, pos_cap, 0, 0, n, ok);
 }
 
 int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t pos_cap,
@@ -292,7 +292,7 @@ int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uin
     rc = arena_reserve(ctx, ctx->d_pos, (pos_cap + 16) * sizeof(uint32_t));
     if (rc) return rc;
     if (len) HIPCHK(hipMemcpyAsync(ctx->d_msg.p, msg, len, hipMemcpyHostToDevice, ctx->stream), "H2D msg");
-    rc = stage1_run_device(ctx, ctx->d_msg.p, len, ndjson, ctx->d_pos.p, pos_cap, len ? msg[len - 1] : 0, 1, n, ok);
+    rc = stage1_run_device(ctx, ctx->d_msg.p, len, ndjson != 0, ctx->d_pos.p, pos_cap, len ? msg[len - 1] : 0, 1, n, ok);
     if (rc) return rc;
     const size_t ncopy = *n < pos_cap ? *n : pos_cap;
     if (ncopy && pos_out) {
@@ -318,7 +318,7 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
         (void)a;
         HIPCHK(stage1_prepare(d_msg, len, ctx->d_ws.p, ctx->stream), "stage1 prepare");
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream), "event");
-        HIPCHK(stage1_launch_prepared(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream),
+        HIPCHK(stage1_launch_prepared(d_msg, len, ndjson != 0, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream),
                "stage1 launch");
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream), "event");
         HIPCHK(hipEventSynchronize(ctx->ev1), "event sync");

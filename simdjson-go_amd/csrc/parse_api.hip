@@ -109,6 +109,8 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
     const size_t pos_cap = (len + 63) / 64 * 64 + 64;
     size_t n = 0;
     int ok = 0;
+    // (WithCopyStrings(false): stage 1 also says whether the message holds an escape starter at all, stage2.hip no_escapes)
+    const int s1_mode = ((flags & SJHIP_FLAG_NDJSON) ? 1 : 0) | ((flags & SJHIP_FLAG_COPY_STRINGS) ? 0 : S1_WANT_STARTER_FLAG);
     // stage 1 leaves its string masks for the byte-parallel unescape.  Every string copied (the reference's default):
     // Strings.B is the compaction of all string bytes; WithCopyStrings(false): the compaction of the bytes of the strings
     // that hold an escape (stage2.hip k_str_emit) -- in both modes written once, in place
@@ -140,7 +142,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
         ctx->p_deferred = (small || known) && !ctx->p_no_defer;
         ctx->p_collected = 0;
         if (ctx->p_deferred && !small) {
-            rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
+            rc = stage1_enqueue(ctx, d_msg, len, s1_mode, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
             // tokens per KiB, + 1/16 -- and, where the context's arenas already hold more (the same document again: exactly its
             // count), as much as they hold: a layout that needs no allocation and fails for as few documents as possible
@@ -163,7 +165,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             ctx->p_last = last_byte;
             ctx->p_have_last = have_last;
         } else if (ctx->p_deferred) {
-            rc = stage1_enqueue(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
+            rc = stage1_enqueue(ctx, d_msg, len, s1_mode, ctx->d_pos.p, pos_cap, aux, ctx->p_kind,
                                 ctx->d_s2z.p, stage2_zero_bytes());
             // The stage-2 arrays are laid out for one token per four bytes (the densest fixture, marine_ik, has 0.22):
             // ~14 B of arena per message byte instead of 57.  The kernels clamp the device-side count to this layout
@@ -174,7 +176,7 @@ static int parse_begin(sjhip_ctx *ctx, const void *d_msg, size_t len, uint32_t f
             ctx->p_last = last_byte;
             ctx->p_have_last = have_last;
         } else {
-            rc = stage1_run_device(ctx, d_msg, len, (flags & SJHIP_FLAG_NDJSON) != 0, ctx->d_pos.p, pos_cap, last_byte,
+            rc = stage1_run_device(ctx, d_msg, len, s1_mode, ctx->d_pos.p, pos_cap, last_byte,
                                    have_last, &n, &ok, aux, ctx->p_kind, ctx->d_s2z.p, stage2_zero_bytes());
         }
         if (rc) return rc;

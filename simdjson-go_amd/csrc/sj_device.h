@@ -129,6 +129,9 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
     return a;
 }
 inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).bytes + 256; }
+// `ndjson` of the launch functions: bit 0 NDJSON | S1_WANT_STARTER_FLAG (whole parse with WithCopyStrings(false): the kernel also
+// leaves Stage1State::has_starter -- one look and at most one store per block; nobody else pays for it)
+static constexpr int S1_WANT_STARTER_FLAG = 0x100;
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,

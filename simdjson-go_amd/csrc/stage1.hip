@@ -55,6 +55,7 @@ struct S1Aux {
                          // more than 4 GiB -- the token kernels rebuild a tile's positions from the unit its first token lies in
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
+    bool want_flag;    // leave Stage1State::has_starter (WithCopyStrings(false): stage2.hip no_escapes)
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
 };
 #if defined(SJ_DEBUG_BOUNDS)
@@ -798,7 +799,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         t_prev = t_a;
     }
     if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-    if (AUX && seen_st && lane == 0) atomicOr(&st->has_starter, 1u);  // (at most one per wave and launch)
+    if (AUX && aux.want_flag) {  // (uniform over the grid)
+        // one look and at most one atomic per BLOCK (an atomicOr per wave -- 4096 of them on one word as the kernel ends -- cost
+        // configs[1] 31 us: a word takes ~88 atomics per microsecond)
+        const int any_st = __syncthreads_or((int)seen_st);
+        if (any_st && tid == 0 && __hip_atomic_load(&st->has_starter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            __hip_atomic_store(&st->has_starter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     block_done(st, aux, base + lead, len);
 }
 
@@ -1160,12 +1167,13 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     u64 *desc = reinterpret_cast<u64 *>(const_cast<u8 *>(edge) + S1_EDGE_BYTES);
     if (tiles == 0) return hipSuccess;
     const S1Variant v = s1_variant();
-    const u32 nd = (u32)(ndjson != 0);
+    const u32 nd = (u32)((ndjson & 1) != 0);
     S1Aux aux = {};
     aux.kind = nullptr;
     if (d_kind) aux.kind = SJ_ARR(d_kind, pos_cap, A_S1_KIND);
     aux.trace = reinterpret_cast<u64 *>(d_trace);
     aux.host = h_state;
+    aux.want_flag = (ndjson & S1_WANT_STARTER_FLAG) != 0;
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) aux.exp = (u32)strtoul(e, nullptr, 0);
 #endif

@@ -842,11 +842,17 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
         const u64 g = (u64)cur.g;  // exclusive prefix: Strings.B offset of the unit
         if (total != 0) {  // wave-uniform
             const bool mine = em != 0 && patched;
-            if (mine) {
+            // A unit whose escapes are all simple ones (\" \\ \/ \b \f \n \r \t: twitter.json's URLs) is not parked any more
+            // (round 6): an escaped character is ONE byte in, one byte out, so it is translated where the compaction put it, in
+            // the output window below -- the 16 + 16 LDS instructions that parked a chunk and took it back, issued by the whole
+            // wave if a single lane had an escape, and two waits, are gone for those units.  Only a unit with a \u (or invalid)
+            // escape, whose translated bytes differ in number and may fall into the neighbour chunk, takes the parked form.
+            const bool any_general = __ballot(mine && general) != 0;  // (wave-uniform)
+            if (mine && any_general) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) in32[q * 64 + lane] = w[q];
             }
-            if (__ballot(mine && general) != 0) {  // (wave-uniform)
+            if (any_general) {
                 // The general patch of a unit, escape by escape (see GenUnit / k_measure): the emitted escaped characters
                 // of the unit's general chunks -- simple escapes and the 'u' of \u escapes that emit bytes -- are listed
                 // and the lanes take them round robin; the translated bytes go into the parked copy of the chunk they
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            if (mine) {
+            if (mine && any_general) {
                 if (!general) {  // simple escapes only: translated in place, nothing is read from the message
                     for (u64 r = cur.esc; r != 0; r &= r - 1) {
                         const u32 ix = byte_ix((u32)ctz64(r));
@@ -878,8 +884,10 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) w[q] = in32[q * 64 + lane];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();  // every lane has its chunk in registers: the window turns into the output
+            if (any_general) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // every lane has its chunk in registers: the window turns into the output
+            }
             // The window is cleared and the lanes OR their bytes in at their byte offsets with ALIGNED 8-byte LDS atomics:
             // eight message bytes at a time are squeezed together (two v_perm_b32), shifted to where they belong inside an
             // aligned 8-byte slot and its successor, and ds_or_b64 merges them with what the neighbour lanes put there.
@@ -912,6 +920,21 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if (!any_general && __ballot(mine) != 0) {  // (wave-uniform) simple escapes: the escaped character where it landed
+                if (mine) {
+                    // of the eight simple escapes only b f n r t change the byte (\" \\ \/ stand for themselves -- every URL of
+                    // twitter.json): one LDS read per escape, the test and the translation in registers (a 4-bit table in a
+                    // constant: (c - 'b') / 2 -> 8, 12, 10, 13, 9), a write only where something changes
+                    for (u64 r = cur.esc; r != 0; r &= r - 1) {
+                        const u32 b = (u32)ctz64(r);
+                        u8 *at = &s_io[wave][pre + (u32)popc64(em & ((1ull << b) - 1ull))];
+                        const u32 d = (u32)*at - (u32)'b';
+                        if (d < 19u && ((0x51011u >> d) & 1u)) *at = (u8)((0x9D0A000C08ull >> ((d >> 1) * 4u)) & 15u);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
             if (g + total <= p.strings_cap && !SJ_EXPBIT(p, 6)) {
                 u8 *dst = arr_at(p.str_out, g, total);
                 const u32 q16 = total >> 4;

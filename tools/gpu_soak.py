@@ -2,7 +2,9 @@
     python tools/gpu_soak.py [seconds] [seed]
 Generated records (tests/test_gpu_parse._random_value: nested containers, every escape form, numbers of all shapes) as
 single documents, arrays and NDJSON, plus byte mutations of them (flipped, deleted, duplicated bytes: mostly invalid
-documents -- the verdict must match) -- each through Parse / ParseND in both copy modes, the in-place view, the key flags,
+documents -- the verdict must match), and every eighth round a document of 4-7 MB of a random token density (large documents are
+laid out for the density the context has learned: the path depends on the order) -- each through Parse / ParseND in both copy
+modes, the in-place view, the key flags,
 MarshalJSON (one pass and two) and the serializer stream, compared with oracle/ bit for bit.  Prints a summary line;
 exit code 1 and the offending document (hex) on the first difference."""
 import os
@@ -90,8 +92,45 @@ def mutate(doc):
     return bytes(b)
 
 
+def large_document():
+    """A document beyond SJHIP_SMALL_BYTES (4 MiB): it is parsed without a host round trip between the stages, laid out for the
+    token density the context learned from its earlier LARGE parses (parse_api.hip) -- so which path a document takes depends on
+    the documents before it.  Densities from 0.002 to 1 token per byte, in random order on the one context of this run."""
+    kind = rnd.randrange(5)
+    target = rnd.randrange(4200 << 10, 7 << 20)
+    if kind == 0:    # long strings: ~0.002 tokens per byte
+        item, sep, nd = '"%s"' % ("s" * rnd.randrange(500, 1500)), ",", False
+    elif kind == 1:  # one token per byte
+        item, sep, nd = rnd.choice(["1", "[]", "0"]), ",", False
+    elif kind == 2:  # generated records as NDJSON
+        item, sep, nd = None, "\n", True
+    elif kind == 3:  # generated values in one array
+        item, sep, nd = None, ",", False
+    else:            # escape-free records (WithCopyStrings(false) copies nothing: its own path, stage2.hip no_escapes)
+        item, sep, nd = '{"k":"plain value %d","n":[1,2.5,true,null],"o":{"p":"q"}}' % rnd.randrange(1000), "\n", True
+    parts, size = [], 0
+    while size < target:
+        v = item
+        if v is None:
+            v = _random_value(rnd, 0)
+            if v[0] not in "[{":
+                v = "[" + v + "]"
+        parts.append(v)
+        size += len(v) + 1
+    body = sep.join(parts)
+    return (body if nd else "[" + body + "]").encode("utf-8"), nd
+
+
+stats["large"] = 0
 t_end = time.time() + budget
+rounds = 0
 while time.time() < t_end:
+    rounds += 1
+    if rounds % 8 == 0:
+        doc, nd = large_document()
+        check(doc, nd)
+        stats["large"] += 1
+        continue
     n = rnd.choice([1, 1, 3, 20, 200, 3000])
     vals = []
     for _ in range(n):
