@@ -334,7 +334,7 @@ def main():
             tl, sl = ctx.parse_device(d_msg.data_ptr(), n_bytes, ndjson=False, copy_strings=True)
         t_full = timed(full, reps)
         algo_full = (n_bytes + 4 * s_expect) + (4 * s_expect + n_bytes + 8 * tl + sl)
-        kprof = _profile("r05_parse_kernels.json")
+        kprof = _profile("r06_parse_kernels.json")
         extra["full_parse"] = {
             "workload": f"configs[1] document, stage1+stage2 (tape + Strings.B left in HBM), {n_bytes} B",
             "GBps": round(n_bytes / t_full / 1e9, 2), "ms": round(t_full * 1e3, 3), "tape_words": tl, "strings_bytes": sl,
@@ -343,7 +343,7 @@ def main():
                          "bytes_per_input_byte": round(algo_full / n_bytes, 3),
                          "kernels_us_committed_profile": (kprof or {}).get("twitter_x426"),
                          "note": "algorithmic bytes = (N + 4S) + (4S + N + 8T + B_str), SURVEY.md 8d; time = wall time of "
-                                 "sjhip_parse_device (two host syncs included); per-kernel averages: profiles/r05_parse_kernels.json"}}
+                                 "sjhip_parse_device (two host syncs included); per-kernel averages: profiles/r06_parse_kernels.json"}}
         if rank == 0:  # WithCopyStrings(false): the reference publishes copy / nocopy pairs (README.md:517-557)
             tln = sln = 0
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r02_parse_kernels.json (per-kernel average microseconds of the whole parse, per workload) and
 profiles/stage2_pmc.json (HBM bytes per launch of every kernel: 2*FETCH_SIZE + WRITE_SIZE KiB, MI355X_MICROARCH.md)
-from a tools/profile_r4.sh summary: python tools/make_parse_json.py <summary.txt> <kernels.json> <pmc.json>"""
+from a tools/profile_r6.sh summary: python tools/make_parse_json.py <summary.txt> <kernels.json> <pmc.json>"""
 import json
 import re
 import sys
@@ -49,7 +49,7 @@ def main(summary, out_k, out_p):
         for k, v in pmc[wl].items():
             if "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
                 v["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024)
-    kern["source"] = "rocprofv3 --kernel-trace --stats -- python tools/parse_loop.py <workload> (tools/profile_r5.sh)"
+    kern["source"] = "rocprofv3 --kernel-trace --stats -- python tools/parse_loop.py <workload> (tools/profile_r6.sh)"
     pmc["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2"
     json.dump(kern, open(out_k, "w"), indent=1)
     json.dump(pmc, open(out_p, "w"), indent=1)
