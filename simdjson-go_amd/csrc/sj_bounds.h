@@ -102,3 +102,21 @@ SJ_HD T *arr_raw(T *a) { return a; }
 #endif
 
 }  // namespace sj
+
+// ---- streaming stores ------------------------------------------------------------------------------------------------
+// Output that nobody reads again soon (stage 1's positions, the tape, Strings.B) leaves with the nt bit: it does not displace the
+// lines the following kernels -- or the next pass over the same message -- find in the L2 / Infinity Cache (round 6, measured).
+#if defined(__HIPCC__)
+namespace sj {
+template <typename T>
+__device__ __forceinline__ void nt_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store4(void *p, uint4 v) {  // (merged into one global_store_dwordx4 ... nt)
+    unsigned int *d = reinterpret_cast<unsigned int *>(p);
+    __builtin_nontemporal_store(v.x, d);
+    __builtin_nontemporal_store(v.y, d + 1);
+    __builtin_nontemporal_store(v.z, d + 2);
+    __builtin_nontemporal_store(v.w, d + 3);
+}
+}  // namespace sj
+#endif
+

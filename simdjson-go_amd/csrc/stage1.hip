@@ -594,8 +594,15 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
             } else if (fits) {
                 // 16 bytes per lane (the positions are only 4-byte aligned in memory: fine on gfx950), then the rest
                 const u32 c4 = cnt & ~3u;
-                for (u32 i = (u32)lane * 4u; i < c4; i += 256u)
+                for (u32 i = (u32)lane * 4u; i < c4; i += 256u) {
+#if defined(SJ_S1_PLAIN_STORE)  // (A/B)
                     *reinterpret_cast<uint4 *>(arr_at(out_pos, gd + i, 4)) = *reinterpret_cast<const uint4 *>(stage + i);
+#else
+                    // streaming stores: the positions are not read again by this kernel, and without them in the way the next
+                    // pass over a cache-sized message finds more of it in the Infinity Cache (configs[1]: 0.1035 -> 0.094 ms)
+                    nt_store4(arr_at(out_pos, gd + i, 4), *reinterpret_cast<const uint4 *>(stage + i));
+#endif
+                }
                 if (c4 + (u32)lane < cnt) out_pos[gd + c4 + lane] = (u32)stage[c4 + lane];
             } else {
                 for (u32 i = lane; i < cnt; i += 64)

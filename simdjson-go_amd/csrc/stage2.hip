@@ -938,8 +938,9 @@ __global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
             if (g + total <= p.strings_cap && !SJ_EXPBIT(p, 6)) {
                 u8 *dst = arr_at(p.str_out, g, total);
                 const u32 q16 = total >> 4;
-                for (u32 i = lane; i < q16; i += 64)  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
+                for (u32 i = lane; i < q16; i += 64) {  // 16 bytes per lane; Strings.B offsets are byte-granular: unaligned stores are fine on gfx950
                     *reinterpret_cast<uint4 *>(dst + 16 * i) = *reinterpret_cast<const uint4 *>(&s_io[wave][16 * i]);
+                }
                 const u32 tail = q16 * 16 + lane;
                 if (tail < total) dst[tail] = s_io[wave][tail];
             }
