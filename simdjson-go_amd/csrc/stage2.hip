@@ -630,8 +630,13 @@ __constant__ EscapeLut c_esc = make_escape_lut();
 // that is not copied needs its raw length: the wave also leaves the position of every CLOSING quote under the number of
 // its string (scq[]).  (Rounds 3-4 compacted every string into a scratch buffer, measured every string token with two record
 // gathers and copied the changed strings out of the scratch: k_str_measure + k_emit_strings, 165 us on configs[1].)
+#if defined(SJ_STR_LB4)
+#define SJ_STR_LB __launch_bounds__(256, 4)
+#else
+#define SJ_STR_LB __launch_bounds__(256)
+#endif
 template <bool SEL>
-__global__ __launch_bounds__(256) void k_str_emit(S2Dev p) {
+__global__ SJ_STR_LB void k_str_emit(S2Dev p) {
     // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
     // unit's unescaped bytes.

@@ -1,7 +1,7 @@
 """The tape walkers stay off scratch (round 5: the float formatter of MarshalJSON kept its digits in byte buffers -- 36-132 B of
 scratch per lane in every k_ms_tile variant -- and k_ser_scan_cnt spilled; sj_ftoa.h now keeps the digits in registers).
 Compile-only: hipcc's resource remarks for marshal.hip and serialize.hip (tools/kernel_resources.py; the whole library:
-profiles/r05_kernel_resources.txt)."""
+profiles/r06_kernel_resources.txt)."""
 import os
 import sys
 
