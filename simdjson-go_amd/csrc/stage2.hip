@@ -630,13 +630,8 @@ __constant__ EscapeLut c_esc = make_escape_lut();
 // that is not copied needs its raw length: the wave also leaves the position of every CLOSING quote under the number of
 // its string (scq[]).  (Rounds 3-4 compacted every string into a scratch buffer, measured every string token with two record
 // gathers and copied the changed strings out of the scratch: k_str_measure + k_emit_strings, 165 us on configs[1].)
-#if defined(SJ_STR_LB4)
-#define SJ_STR_LB __launch_bounds__(256, 4)
-#else
-#define SJ_STR_LB __launch_bounds__(256)
-#endif
 template <bool SEL>
-__global__ SJ_STR_LB void k_str_emit(S2Dev p) {
+__device__ __forceinline__ void str_emit_body(const S2Dev &p) {
     // One LDS window per wave, used twice: chunks with escapes park their dwords there (dword-major: bank = lane)
     // to patch bytes, and once every lane has its (patched) chunk back in registers the window receives the
     // unit's unescaped bytes.
@@ -961,6 +956,16 @@ __global__ SJ_STR_LB void k_str_emit(S2Dev p) {
         for (int q = 0; q < 16; q++) w[q] = w_n[q];
     }
 }
+
+// (two kernels for the two modes: WithCopyStrings(false) is compiled for four waves per SIMD -- 128 registers, 16 bytes of
+// scratch -- where the compiler's own choice was 145 registers and three: 139 -> 121-125 us on configs[4], 151-164 -> 137 us on
+// configs[1]; the same bound on the copy-mode kernel, which sits at 125 registers anyway, measured 1-4 % slower)
+template <bool SEL>
+__global__ void k_str_emit(S2Dev p);
+template <>
+__global__ __launch_bounds__(256) void k_str_emit<false>(S2Dev p) { str_emit_body<false>(p); }
+template <>
+__global__ __launch_bounds__(256, 4) void k_str_emit<true>(S2Dev p) { str_emit_body<true>(p); }
 
 // ---- the token scan ----------------------------------------------------------------------------------------
 // Inside a tile the scan runs on the packed form PAgg (sj_stage2.h); wave scans use DPP row shifts / broadcasts
