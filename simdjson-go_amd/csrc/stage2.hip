@@ -41,6 +41,9 @@ namespace sj {
 
 static constexpr int S2_TILE = 4096;  // tokens per tile (the packed scan form PAgg is sized for it)
 static constexpr int RD_BLOCK = 256;  // k_measure
+#if !defined(SJ_MEASURE_WAVES)
+#define SJ_MEASURE_WAVES 7  // (72 registers, no scratch; 6: 77 registers; 8: 64 + 28 B of scratch -- measured: 7 is 4-6 % faster than 6, 8 no faster)
+#endif
 static constexpr u32 DLEN_INVALID = 0xffffffffu;
 static constexpr u32 DLEN_COPY = 0x80000000u;
 
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ PAgg pagg_block_exclusive(const PAgg &mine, PAgg *s_w
 // `mblocks` turn the string masks of stage 1 into emit masks and unit counts, the others reduce the token kinds of a tile
 // to its scan aggregate.
 __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block);
-__global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks);
+__global__ __launch_bounds__(RD_BLOCK, SJ_MEASURE_WAVES) void k_measure(S2Dev p, u32 mblocks);
 
 // ---- pass 2: exclusive scan over the tile aggregates (in place) + totals: SCAN_SEGS blocks ---------------------
 // Inside a segment every thread owns K consecutive tiles (K <= 32 per round), so a block scans once per round
@@ -1252,7 +1255,7 @@ __device__ __forceinline__ void s2_reduce_planes(const S2Dev &p, u32 block) {
     }
 }
 
-__global__ __launch_bounds__(RD_BLOCK, 6) void k_measure(S2Dev p, u32 mblocks) {
+__global__ __launch_bounds__(RD_BLOCK, SJ_MEASURE_WAVES) void k_measure(S2Dev p, u32 mblocks) {
     __shared__ GenUnit s_gu[RD_BLOCK / 64];
     if (blockIdx.x < mblocks) {
         if (p.copy_strings) str_masks_body<false>(p, blockIdx.x, mblocks, &s_gu[threadIdx.x >> 6]);
