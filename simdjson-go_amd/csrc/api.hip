@@ -55,6 +55,7 @@ int sj::arena_reserve(sjhip_ctx *ctx, DevBuf &b, size_t bytes) {
         return SJHIP_ERR_HIP;
     }
     b.cap = want;
+    b.gen++;
     return SJHIP_OK;
 }
 
@@ -107,6 +108,7 @@ int sjhip_ctx_trim(sjhip_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
         b->cap = 0;
+        b->gen++;
     }
     ctx->p_kind = nullptr;
     ctx->p_aux = nullptr;
@@ -208,6 +210,16 @@ static void invalidate_result(sjhip_ctx *ctx) {
 // stream has been synchronised, collect (the reference's end-of-document verdict).  (Polling the word instead of
 // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
 // would hand positions to other streams before they are visible there.)
+// Stage 1 runs without a preparation kernel: a launch leaves the state's control words and the tile descriptors it used
+// zeroed for the next one (stage1.hip block_done).  A workspace that has just been allocated is zeroed here, once.
+static int stage1_workspace_clean(sjhip_ctx *ctx) {
+    if (ctx->d_ws.p && ctx->ws_clean_gen != ctx->d_ws.gen) {
+        HIPCHK(hipMemsetAsync(ctx->d_ws.p, 0, ctx->d_ws.cap, ctx->stream), "stage-1 workspace memset");
+        ctx->ws_clean_gen = ctx->d_ws.gen;
+    }
+    return SJHIP_OK;
+}
+
 int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
                        uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
     // (plain stage 1 hands out 32-bit positions: up to 4 GiB - 64; the whole parse -- str_aux -- lets them wrap, parse_api.hip)
@@ -217,6 +229,8 @@ int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
+    if (rc) return rc;
+    rc = stage1_workspace_clean(ctx);
     if (rc) return rc;
     if (len > 0) {
         *(volatile unsigned long long *)ctx->h_scratch = 0;

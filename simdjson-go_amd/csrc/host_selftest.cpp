@@ -211,8 +211,19 @@ static int selftest_parse(const uint8_t *msg0, size_t len0, uint32_t flags, uint
     static constexpr ElementLut ELUT = make_element_lut();
     u32 bad = 0;
     // k_str_masks / k_str_scan (every string copied)
-    const StrView sv{msg, 0, len, v_qm.data(), v_q.data(), v_st.data(), v_h.data(), v_slow.data()};
+    // the device form of the in-string mask: relative to the start of its 4 KiB unit, with the unit's state in unit_h (the
+    // replay above keeps the absolute mask in v_qm)
+    std::vector<u64> v_qrel(chunks, 0);
+    for (size_t u = 0; u < units; u++) {
+        const u8 h = u ? (u8)(v_qm[u * 64 - 1] >> 63) : (u8)0;
+        v_h[u] = h;
+        for (size_t c = u * 64; c < (u + 1) * 64; c++) v_qrel[c] = h ? ~v_qm[c] : v_qm[c];
+    }
+    const StrView sv{msg, 0, len, v_qrel.data(), v_st.data(), v_h.data(), v_slow.data()};
     const size_t used_units = (len + 4095) / 4096;
+    // the device does not store the unescaped quotes: they are where the unit-relative in-string mask changes (StrView::quotes)
+    for (size_t c = 0; c < used_units * 64; c++)
+        if (sv.quotes(c) != v_q[c]) return 97;
     u64 masks_total = 0;
     if (masks) {
         for (size_t c = 0; c < used_units * 64; c++)

@@ -10,6 +10,7 @@ namespace sj {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    unsigned gen = 0;  // counts the allocations behind p (arena_reserve, sjhip_ctx_trim): "is this still the memory I prepared?"
 };
 }  // namespace sj
 
@@ -35,6 +36,7 @@ struct sjhip_ctx {
     int kf_valid = 0;                  // ... and they belong to the resident result
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
+    unsigned ws_clean_gen = 0;         // d_ws.gen of the allocation that has been zeroed for stage 1 (0: none; stage1_enqueue)
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;

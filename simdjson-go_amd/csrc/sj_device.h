@@ -6,8 +6,10 @@
 
 namespace sj {
 
-// Lives at the start of the stage-1 workspace; zeroed (with the tile descriptors that
-// follow it) by a hipMemsetAsync node before every launch.
+// Lives at the start of the stage-1 workspace, the tile descriptors behind it.  Round 6: no preparation kernel in front of
+// every launch any more -- the control words (tile_counter, done, err_acc, starter_acc) and the descriptors a launch used are
+// zero again when it ends (its last block cleans up: stage1.hip block_done), the result words (error, total, ends_in_quote,
+// has_starter) are overwritten by every launch and stay for whoever reads them behind it.  A fresh workspace is zeroed once.
 struct Stage1State {
     uint32_t tile_counter;   // dynamic tile id dispenser
     uint32_t error;          // OR of (control char inside string)   -> reference error_mask != 0
@@ -17,7 +19,9 @@ struct Stage1State {
     uint32_t last_byte;      // msg[len - 1] (host copy only: the end-of-document verdict needs it)
     uint32_t has_starter;    // whole parse: some unit holds a backslash that starts an escape (stage 2 reads it on the device:
                              // WithCopyStrings(false) of a message without one copies nothing and measures nothing)
-    uint32_t pad[8];
+    uint32_t err_acc;        // control: the blocks OR their error bits here; the last block moves them to `error`
+    uint32_t starter_acc;    // control: ... and the starter flag to `has_starter`
+    uint32_t pad[6];
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
 // the packed result word the last block of stage 1 stores to pinned host memory
@@ -87,14 +91,16 @@ int stage1_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index,
 int stage2_debug_bounds_selftest();
 
 size_t stage1_workspace_bytes(size_t len);
-// zero2 / zero2_bytes: a second region to zero in the same kernel (the stage-2 state) or null
+// Zeroes the state and the descriptors of a workspace whose contents are unknown (a parse does not need it: every launch
+// leaves the workspace clean, and whoever allocates one zeroes it once).  zero2 / zero2_bytes: a second region to zero in
+// the same kernel, or null
 hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2 = nullptr, size_t zero2_bytes = 0);
-// String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / q / st / unit_h, the string
+// String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / st / unit_h, the string
 // kernels of stage 2 add one 16-byte record per chunk (sj_strings.h ChunkRec) and unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
 // base of the message); everything is sized in whole 4 KiB units.
 struct StrAux {
     size_t units, chunks, bytes;
-    uint64_t *qm, *q, *st;
+    uint64_t *qm, *st;
     void *rec;  // ChunkRec[chunks]
     uint32_t *unit_cnt;
     uint32_t *tile_unit;  // [units + 1] the unit that holds token 4096 T (stage1.hip; positions wrap beyond 4 GiB)
@@ -115,7 +121,6 @@ inline StrAux str_aux_layout(void *buf, size_t span) {
         return r;
     };
     a.qm = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
-    a.q = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
     a.st = reinterpret_cast<uint64_t *>(carve(a.chunks * 8));
     a.rec = carve(a.chunks * 16);
     a.unit_cnt = reinterpret_cast<uint32_t *>(carve(a.units * 4));
@@ -135,7 +140,8 @@ static constexpr int S1_WANT_STARTER_FLAG = 0x100;
 // aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
                                   void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr);
+                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr,
+                                  void *zero2 = nullptr, size_t zero2_bytes = 0);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);

@@ -6,8 +6,10 @@
 // order, so the destination of a string byte is simply the number of emitted bytes in front of it.
 //
 // Stage 1 leaves, per 64-byte chunk (bit j = byte j; chunks count from the 64-byte aligned base of the
-// message), qm = in-string mask relative to the start of the 4 KiB unit, q = unescaped quotes,
-// st = escape starters (backslashes that are not themselves escaped), and per unit the resolved state h.
+// message), qm = in-string mask relative to the start of the 4 KiB unit, st = escape starters (backslashes that are not
+// themselves escaped), and per unit the resolved state h.  The unescaped quotes q are NOT stored (round 6: 8 of the 24 bytes
+// per chunk that stage 1 wrote and the string kernels read back): qm is the running parity of the quotes inside the unit, so
+// a quote sits exactly where qm changes -- q = qm ^ (qm << 1 | last bit of the chunk in front; 0 at the start of a unit).
 //   SM  = (h ? ~qm : qm) & ~q        bytes strictly inside strings
 //   esc = st << 1 (with carry)       escaped characters
 //   EM  = emit mask: one bit per byte of Strings.B.  Plain content and simple escapes emit at their own
@@ -31,7 +33,7 @@ namespace sj {
 struct StrView {
     Arr<const u8> base;  // 64-byte aligned base of the message (Arr: sj_bounds.h, a plain pointer in the product build)
     u64 lead, end;   // the message occupies [lead, end) of it
-    Arr<const u64> qm, q, st;
+    Arr<const u64> qm, st;
     Arr<const u8> unit_h;  // per unit: bit 0 = state at its start (1: inside a string), bit 1 = it holds an escape starter, bit 2 = an unescaped quote
     Arr<const u64> unit_slow;  // per unit: chunks that hold an escaped character other than " \\ / b f n r t (stage 1)
     SJ_HD u8 at(u64 a) const { return (a >= lead && a < end) ? base[a] : (u8)0; }  // zero padding like MsgView
@@ -49,9 +51,12 @@ struct StrView {
             }
         }
     }
+    // unescaped quotes of chunk c: where the in-string mask changes (its value in front of a unit's first byte is 0)
+    SJ_HD static u64 quotes_of(u64 m, u64 m_prev) { return m ^ ((m << 1) | (m_prev >> 63)); }
+    SJ_HD u64 quotes(u64 c) const { return quotes_of(qm[c], (c & 63) ? qm[c - 1] : 0ull); }
     SJ_HD u64 sm(u64 c) const {
         const u64 m = qm[c];
-        return ((unit_h[c >> 6] & 1u) ? ~m : m) & ~q[c];  // (bit 1 of unit_h: the unit holds an escape starter)
+        return ((unit_h[c >> 6] & 1u) ? ~m : m) & ~quotes_of(m, (c & 63) ? qm[c - 1] : 0ull);  // (bit 1 of unit_h: the unit holds an escape starter)
     }
     // escaped characters of chunk c (characters that follow a starter)
     SJ_HD u64 esc(u64 c) const { return (st[c] << 1) | (c ? st[c - 1] >> 63 : 0); }

@@ -38,7 +38,8 @@ namespace sj {
 // relative to the unit start, the unescaped quotes and the escape starters; per 4 KiB unit the resolved state
 struct S1Aux {
     // (Arr: sj_bounds.h -- plain pointers in the product build, bounds-checked views under -DSJ_DEBUG_BOUNDS)
-    Arr<u64> qm, q, st;  // null unless every string is copied (byte-parallel unescape)
+    Arr<u64> qm, st;     // null unless the strings are handled byte-parallel (stage2.hip); the unescaped quotes are not written:
+                         // they are where qm changes (sj_strings.h StrView::quotes)
     Arr<u8> unit_h;
     Arr<u64> unit_slow;  // per unit: chunks with an escaped character that no simple escape names (sj_strings.h)
     Arr<u8> kind;        // [pos_cap] kind of every structural (sj_stage2.h), written next to its position
@@ -56,6 +57,8 @@ struct S1Aux {
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
     unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
     bool want_flag;    // leave Stage1State::has_starter (WithCopyStrings(false): stage2.hip no_escapes)
+    uint4 *zero2;      // null, or a second region the launch's last block zeroes: the stage-2 state and scan slots of THIS parse
+    u64 zero2_quads;   // (every stage-2 kernel of the previous parse is through when this launch runs, none of this one has begun)
     u32 exp;           // SJ_EXP builds only: parts to leave out (A/B timing; results are wrong)
 };
 #if defined(SJ_DEBUG_BOUNDS)
@@ -69,24 +72,47 @@ struct S1Aux {
 #define SJ_S1EXP(a, b) false
 #endif
 // End of a block (after a block barrier: every wave has issued its last update of *st).  The block that finds all the
-// others finished publishes the state -- and the last message byte -- to the host record.
-__device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len) {
-    if (!aux.host) return;
-    // every update of *st is an agent-scope atomic (performed at the memory side, like the tile descriptors): once
-    // this wave's are acknowledged and the block has met, one counter tells which block is the last.  The counter is
-    // an acquire-release operation at agent scope -- one per block, not a hot path -- so that the last block's loads
-    // of *st are ordered behind every other block's updates by the memory model, not only by how gfx950 executes
-    // sc1 atomics.
+// others finished (a) cleans up -- round 6: there is no preparation kernel in front of a launch any more (it cost 3-4 us
+// and a kernel boundary on every parse, and the host of a device-resident small message had not enqueued stage 1 yet when
+// it was through): the tile descriptors this launch used and the control words of the state are zeroed for the NEXT launch
+// on this workspace, the stage-2 state of THIS parse (aux.zero2) for the kernels behind -- (b) moves the error bits and
+// the starter flag the blocks accumulated into the result words, and (c) publishes the state -- and the last message
+// byte -- to the host record.
+__device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len, u64 *__restrict__ desc,
+                                           u32 num_tiles) {
+    __shared__ u32 s_last;
+    // every update of *st is an agent-scope atomic (write-through: performed at the memory side, like the tile descriptors):
+    // once this wave's are acknowledged (the drained store counter) and the block has met, one counter tells which block is
+    // the last -- the guide's hand-off form "sc1 payload -> vmcnt(0) -> sc1 flag", the one the look-back and the scan slots
+    // of stage 2 use.  (Rounds 4-5 made the counter an acquire-release operation: a write-back of the XCD's L2 and an
+    // invalidate per block, at the very end of the kernel where nothing hides them -- 6-8 us per launch, measured when the
+    // timing entry point began to run this epilogue too: 256 MiB 0.093 -> 0.101 ms.  Nothing here needs them: the last
+    // block reads state words that were written through, its own stores leave with the kernel's end like everybody's
+    // positions, and every look-back load of the descriptors it zeroes has returned before its block counted itself.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == gridDim.x - 1) {
+        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = d == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;  // (uniform)
+    for (u32 i = threadIdx.x; i < num_tiles; i += blockDim.x) desc[i] = 0;
+    for (u64 i = threadIdx.x; i < aux.zero2_quads; i += blockDim.x) aux.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) {
+        const u32 err = __hip_atomic_load(&st->err_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 hs = __hip_atomic_load(&st->starter_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 eiq = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st->error = err;
+        st->has_starter = hs;
+        st->err_acc = 0;
+        st->starter_acc = 0;
+        st->tile_counter = 0;
+        st->done = 0;
+        if (aux.host) {
             // the whole result in ONE 8-byte store (several stores would need a system-scope release, i.e. an L2
             // write-back, to be ordered among themselves): S1_HOST_* in sj_device.h
-            const u32 err = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 eiq = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u64 word = S1_HOST_VALID | ((err & 0x80000000u) ? S1_HOST_INTERNAL : 0) | ((err & 1u) ? S1_HOST_ERROR : 0) |
                              (eiq ? S1_HOST_IN_QUOTE : 0) | ((u64)(len ? msg[len - 1] : 0u) << S1_HOST_LAST_SHIFT) |
                              (total & S1_HOST_TOTAL_MASK);
@@ -202,15 +228,30 @@ __device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base,
 }
 
 // ---- chunk load ------------------------------------------------------------------------
-// `base` is 64-byte aligned; the message occupies [lead, lead+len) of it.  A wave unit is 64
-// consecutive chunks (4 KiB, one per lane): one scalar base + lane * 64.  The first and the last unit of a
-// message are not read from the message: k_s1_prepare leaves a copy of each in the workspace in which the bytes
-// outside the message are 0x20, exactly like the reference's space-masked tail
+// `base` is 64-byte aligned; the message occupies [lead, lead+len) = [lead, end) of it.  A wave unit is 64
+// consecutive chunks (4 KiB, one per lane): one scalar base + lane * 64.  In the first and the last unit of a
+// message the bytes outside the message count as 0x20, exactly like the reference's space-masked tail
 // (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as well, which leaves the initial
-// pseudo_pred (=1) semantics untouched.  So the tile loop has one load path and never reads outside the message.
-static constexpr size_t S1_EDGE_BYTES = 2 * 4096;
-__device__ __forceinline__ const u8 *unit_src(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu) {
-    return unit == 0 ? edge : (unit + 1 == nu ? edge + 4096 : base + unit * 4096);  // wave-uniform
+// pseudo_pred (=1) semantics untouched.  (Rounds 1-5: a preparation kernel left blank-padded copies of the two units
+// in the workspace.  Round 6: the units are read where they lie -- a chunk that begins behind the message is not
+// read (its lane reads the message's last chunk instead), one that holds its first or last byte is read whole: its 64-byte
+// line is the message's own -- and phase A blanks the bytes outside [lead, end) of those two units, edge_blank.)
+// the chunk at byte offset c0 (from base) of the first or the last unit: bytes outside [lead, end) count as blanks.  Done on the
+// CLASS masks, not on the bytes (a dozen 64-bit operations; blanking the sixteen dwords was 3.6 KB of code in every copy of
+// phase A): outside the message every class is empty except whitespace -- everything behind classify() reads only the masks.
+__device__ __forceinline__ void edge_blank(Classes &c, u64 c0, u64 lead, u64 end) {
+    const u32 lo = c0 < lead ? (u32)(lead - c0) : 0u;                            // (lead < 64: only chunk 0 has lo > 0)
+    const u32 hi = end > c0 ? (end - c0 < 64 ? (u32)(end - c0) : 64u) : 0u;      // bytes [lo, hi) of the chunk are message bytes
+    const u64 valid = (hi >= 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+    c.bs &= valid;
+    c.quote &= valid;
+    c.structs &= valid;
+    c.ctrl &= valid;
+    c.nl &= valid;
+    c.esc1 &= valid;
+    c.ws |= ~valid;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.kp[i] &= valid;
 }
 // a unit in flight: this lane's chunk and (every lane the same) the 8 message bytes in front of the unit, which the
 // carries into its first chunk come from -- fetched with the chunk so that nothing waits for a scalar load later
@@ -220,34 +261,27 @@ struct UnitRegs {
     uint4 v[4];
     u64 prev8;
 };
-__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, const u8 *__restrict__ edge, u64 unit, u32 nu, int lane,
-                                           UnitRegs &r) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(unit_src(base, edge, unit, nu)) + lane * 4;
+__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, u64 end, u64 unit, int lane, UnitRegs &r) {
+    // (only chunks of the last unit can lie behind the message: those lanes read the message's last chunk instead -- an address
+    // clamp, not a predicated load: every lane's registers are defined by the load, so the compiler stays free to keep the unit
+    // in flight in registers of its own -- and phase A blanks what they hold)
+    const u64 last = (end - 1) & ~63ull;  // (uniform; len > 0)
+    u64 off = unit * 4096 + (u64)lane * 64;
+    off = off < last ? off : last;
+    const uint4 *p = reinterpret_cast<const uint4 *>(base + off);
 #pragma unroll
     for (int q = 0; q < 4; q++) r.v[q] = p[q];
     // (unit 0 has nothing in front of it: its own first bytes are read instead and not used)
     r.prev8 = *reinterpret_cast<const u64 *>(base + (unit ? unit * 4096 - 8 : 0));
 }
-// Zeroes the Stage1State and the tile descriptors (must precede every launch) and builds the two edge units.
-__global__ __launch_bounds__(256) void k_s1_prepare(const u8 *__restrict__ base, u64 lead, u64 end, u32 nu, u8 *__restrict__ edge,
-                                                    u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words,
+// Zeroes the Stage1State and the tile descriptors.  Not part of a parse any more (block_done): the timing / tracing entry
+// points and a workspace whose state is unknown use it.
+__global__ __launch_bounds__(256) void k_s1_prepare(u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words,
                                                     uint4 *__restrict__ zero2, u64 zero2_quads) {
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, gsz = (u64)gridDim.x * 256;
     if (gid < sizeof(Stage1State) / 8) state[gid] = 0;
     for (u64 i = gid; i < desc_words; i += gsz) desc[i] = 0;
     for (u64 i = gid; i < zero2_quads; i += gsz) zero2[i] = make_uint4(0u, 0u, 0u, 0u);  // stage-2 state and chain descriptors
-    if (blockIdx.x < 2 && nu != 0) {
-        const u64 unit = blockIdx.x == 0 ? 0 : (u64)nu - 1;
-        // 16 bytes per thread, all loads in flight together (byte loads: only message bytes are touched)
-        const u64 off = unit * 4096 + (u64)threadIdx.x * 16;
-        u32 w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
-        u8 b[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) b[i] = (off + i >= lead && off + i < end) ? base[off + i] : (u8)0x20;
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((u32)b[i] << (8 * (i & 3)));
-        *reinterpret_cast<uint4 *>(edge + blockIdx.x * 4096 + threadIdx.x * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
 }
 
 // ---- the look-back (wave 0 of a block) -------------------------------------------------------
@@ -338,7 +372,7 @@ __device__ __forceinline__ bool par_ballot_any(u64 m) { return __ballot(((u32)m 
 template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
-                                        const S1Aux &aux, const u8 *__restrict__ edge, u64 (&kp)[CH][4], uint2 *s_ucnt,
+                                        const S1Aux &aux, u64 (&kp)[CH][4], uint2 *s_ucnt,
                                         u32 &seen_st, bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
@@ -359,7 +393,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (lane == 0) s_unit[k * WAVES + wave] = 0;
             if (AUX && lane == 0) s_ucnt[k * WAVES + wave] = make_uint2(0u, 0u);
             kp[k][0] = kp[k][1] = kp[k][2] = kp[k][3] = 0;
-            if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
+            if (unit_nx != VOID_UNIT) unit_issue(base, end, unit_nx, lane, pf);
             continue;
         }
         const u64 unit_off = unit * 4096;
@@ -381,7 +415,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // the next pass goes in flight before this one is classified: a whole pass of math to arrive in (the compiler
         // keeps the chunk in its own registers; issuing the loads only after classify(), into the registers the chunk
         // dies in, measured 1-2 % slower)
-        if (unit_nx != VOID_UNIT) unit_issue(base, edge, unit_nx, tm.nu, lane, pf);
+        if (unit_nx != VOID_UNIT) unit_issue(base, end, unit_nx, lane, pf);
         __builtin_amdgcn_sched_barrier(0);
         // issue priority by progress: the SIMD arbiter prefers its oldest wave, which then finishes a pass long before
         // the others and leaves the tail of every phase to one or two waves that cannot fill the pipe; with the waves
@@ -389,7 +423,8 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // of the barrier kernel: it has the look-back to do while the others are still in this phase).
         if (k == 0 || TOP) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
-        const Classes c = classify(w);
+        Classes c = classify(w);
+        if (unit == 0 || unit + 1 == tm.nu) edge_blank(c, unit_off + (u64)lane * 64, lead, end);  // (uniform)
         if (AUX) {  // the kind of the token a byte would start, as four bit planes (flatten_tile looks them up per structural)
             kp[k][0] = c.kp[0];
             kp[k][1] = c.kp[1];
@@ -442,7 +477,6 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         if (AUX && aux.qm && unit_off < end && !SJ_S1EXP(aux, 16)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
-            aux.q[ci] = quote_bits;
             aux.st[ci] = starters;
             // (hypothesis-free: an escape outside a string makes the document invalid anyway)
             const u64 slow = __ballot(((u32)nonsimple | (u32)(nonsimple >> 32)) != 0);
@@ -658,8 +692,7 @@ template <int BLOCK, int CH, int WPE, bool NDJSON, bool AUX, bool TRACE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                         u32 *__restrict__ out_pos,
                                                                         u64 pos_cap, Stage1State *__restrict__ st,
-                                                                        u64 *__restrict__ desc, u32 num_tiles, TileMap tm, S1Aux aux,
-                                                                        const u8 *__restrict__ edge) {
+                                                                        u64 *__restrict__ desc, u32 num_tiles, TileMap tm, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;  // unit u = pass * WAVES + wave, in byte order
     static_assert(UNITS <= 32, "pre_mask is a u32");
@@ -689,17 +722,23 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // spurious "internal error", with several >256-tile parses in flight on one device.)
     const bool one_round = num_tiles <= gridDim.x;  // (uniform over the grid)
     const u32 tk_base = one_round ? gridDim.x : 0u;
-    if (tid == 0) s_ticket[0] = one_round ? blockIdx.x : atomicAdd(&st->tile_counter, 1u);
+    // (round 6) the ticket of the SECOND tile is drawn together with the first: phase A of T(0) then sends T(1)'s first unit on
+    // its way like every later phase A does for its successor, instead of behind the first barrier with the whole load
+    // latency exposed (64 MiB: 0.0384 -> 0.0370 ms, same box, alternating; nothing at 256 MiB and 1 GiB)
+    if (tid == 0) {
+        s_ticket[0] = one_round ? blockIdx.x : atomicAdd(&st->tile_counter, 1u);
+        s_ticket[1] = tk_base + atomicAdd(&st->tile_counter, 1u);
+    }
     __syncthreads();
     const u32 t_first = uniform(s_ticket[0]);
     if (t_first >= num_tiles) {
-        block_done(st, aux, base + lead, len);
+        block_done(st, aux, base + lead, len, desc, num_tiles);
         return;
     }
     UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
-        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
+        if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
     }
 
     // One loop, one copy of phase A and of the flatten in the instruction stream (a peeled first tile made every block
@@ -717,19 +756,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     for (u32 j = 0;; j++) {
         const bool first = j == 0;
         const u32 t_a = uniform(s_ticket[j & 3u]);                               // phase A runs on T(j)
-        const u32 t_an = first ? 0xffffffffu : uniform(s_ticket[(j + 1u) & 3u]);  // T(j+1): its first unit is loaded behind T(j)'s last
+        const u32 t_an = uniform(s_ticket[(j + 1u) & 3u]);  // T(j+1): its first unit is loaded behind T(j)'s last
         const bool has_a = t_a < num_tiles;
         const int ma = (int)(j & 1u), ua = (int)(j % 3u);        // mask / unit slot of T(j)
         const int mf = ma ^ 1, uf = ua == 0 ? 2 : ua - 1;        // ... of T(j-1)
-        u32 tk1 = 0, tk2 = 0;  // tickets drawn now (lane 0 of wave 0); they return while phase A runs
-        if (tid == 0) {
-            if (first) tk1 = tk_base + atomicAdd(&st->tile_counter, 1u);
-            if (has_a) tk2 = tk_base + atomicAdd(&st->tile_counter, 1u);
-        }
+        u32 tk2 = 0;  // the ticket drawn now (lane 0 of wave 0); it returns while phase A runs
+        if (tid == 0 && has_a) tk2 = tk_base + atomicAdd(&st->tile_counter, 1u);
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
-                                            s_pre[ma][wave], s_unit[ua], aux, edge, kp, s_ucnt[AUX ? ua : 0], seen_st, wave == 0 && !first);
+                                            s_pre[ma][wave], s_unit[ua], aux, kp, s_ucnt[AUX ? ua : 0], seen_st, wave == 0 && !first);
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
         }
         u32 *res = s_res2[j & 1u];
@@ -746,7 +782,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                     if (r == 1) break;
                     if (r == 0) __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
-                        if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                        if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
                         break;
                     }
                     lookback_load(desc, lb.j, lane, win);
@@ -761,8 +797,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                     res[3] = (u32)(BASE >> 32);
                     if (t_prev == num_tiles - 1)
                         __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    s_ticket[1] = tk1;
                 }
                 if (has_a) s_ticket[(j + 2u) & 3u] = tk2;
             }
@@ -773,13 +807,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             tile_aggregate<UNITS>(s_unit[ua], lane, P0, T00, T01, pm0);
             if (lane == 0) desc_store(&desc[t_a], t_a == 0 ? pack_prefix(P0, T00) : pack_agg(P0, T00, T01));
         }
-        if (first) {  // phase A of the first tile did not know the second one: its first unit goes in flight here
-            const u32 t1 = uniform(s_ticket[1]);
-            if (t1 < num_tiles) {
-                const u64 un = tile_unit<UNITS>(tm, t1, wave);
-                if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
-            }
-        } else {
+        if (!first) {
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 3);
             const u32 G = uniform(res[0]), pm = uniform(res[1]);
             const u64 BASE = ((u64)uniform(res[3]) << 32) | uniform(res[2]);
@@ -805,15 +833,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         }
         t_prev = t_a;
     }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
+    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->err_acc, 1u);
     if (AUX && aux.want_flag) {  // (uniform over the grid)
         // one look and at most one atomic per BLOCK (an atomicOr per wave -- 4096 of them on one word as the kernel ends -- cost
         // configs[1] 31 us: a word takes ~88 atomics per microsecond)
         const int any_st = __syncthreads_or((int)seen_st);
-        if (any_st && tid == 0 && __hip_atomic_load(&st->has_starter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-            __hip_atomic_store(&st->has_starter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (any_st && tid == 0 && __hip_atomic_load(&st->starter_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            __hip_atomic_store(&st->starter_acc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    block_done(st, aux, base + lead, len);
+    block_done(st, aux, base + lead, len, desc, num_tiles);
 }
 
 // ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
@@ -837,7 +865,7 @@ template <int BLOCK, int CH, int DEPTH, int WPE, bool NDJSON, bool AUX, bool TRA
 __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restrict__ base, u64 lead, u64 len,
                                                                u32 *__restrict__ out_pos, u64 pos_cap,
                                                                Stage1State *__restrict__ st, u64 *__restrict__ desc,
-                                                               u32 num_tiles, TileMap tm, S1Aux aux, const u8 *__restrict__ edge) {
+                                                               u32 num_tiles, TileMap tm, S1Aux aux) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
     constexpr u32 D = DEPTH - 1;
@@ -871,13 +899,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     __syncthreads();
     const u32 t_first = uniform(s_tk[0]);
     if (t_first >= num_tiles) {
-        block_done(st, aux, base + lead, len);
+        block_done(st, aux, base + lead, len, desc, num_tiles);
         return;
     }
     UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
-        if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
+        if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
     }
     if (tid == 0) {
         s_tk[1] = atomicAdd(&st->tile_counter, 1u);
@@ -887,14 +915,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
     u32 seen_st_nb = 0;  // (this kernel never runs the whole parse: unused)
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, edge, kp, nullptr, seen_st_nb);
+                                    aux, kp, nullptr, seen_st_nb);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();
     {
         const u32 t1 = uniform(s_tk[1]);
         if (t1 < num_tiles) {
             const u64 un = tile_unit<UNITS>(tm, t1, wave);
-            if (un != VOID_UNIT) unit_issue(base, edge, un, tm.nu, lane, pf);
+            if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
         }
     }
     if (wave == 0) {
@@ -919,7 +947,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             if (!wait) return false;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) {  // bounded: a bug must not hang the device
-                if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
                 break;
             }
         }
@@ -941,7 +969,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (++spins > (1u << 22)) {
-                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
                     break;
                 }
                 lookback_load(desc, lb.j, lane, win);
@@ -970,7 +998,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             while (__hip_atomic_load(&s_tkn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 3u) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {
-                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
                     break;
                 }
             }
@@ -983,7 +1011,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
-                                            s_unit[ua], aux, edge, kp, nullptr, seen_st_nb, wave == 0);
+                                            s_unit[ua], aux, kp, nullptr, seen_st_nb, wave == 0);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             u32 arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1021,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             while (__hip_atomic_load(&s_resflag[f & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1u) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {
-                    if (lane == 0) atomicOr(&st->error, 0x80000000u);
+                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
                     break;
                 }
             }
@@ -1040,8 +1068,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
                 (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->error, 1u);
-    block_done(st, aux, base + lead, len);
+    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->err_acc, 1u);
+    block_done(st, aux, base + lead, len, desc, num_tiles);
 }
 
 // ---- launcher --------------------------------------------------------------------------
@@ -1127,28 +1155,28 @@ static S1Plan s1_plan(size_t len, size_t lead) {
     return p;
 }
 
-// workspace: Stage1State | the two edge units (k_s1_prepare) | tile descriptors
+// workspace: Stage1State | tile descriptors
 size_t stage1_workspace_bytes(size_t len) {
     const size_t tiles = (len + 128) / (256 * 2 * 64) + 2 + 2048;  // smallest tile of any variant + one round of small tiles
-    return sizeof(Stage1State) + S1_EDGE_BYTES + tiles * sizeof(u64);
+    return sizeof(Stage1State) + tiles * sizeof(u64);
 }
 
-// zero the Stage1State and the tile descriptors, copy the edge units (must precede every launch)
+// Zero the Stage1State and the tile descriptors of this message's plan.  A parse does not need it (a launch leaves the
+// workspace the way it found it, block_done; a fresh workspace is zeroed once by its owner): the timing and tracing entry
+// points call it so that each of their launches stands alone.
 hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2, size_t zero2_bytes) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
-    const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
     const S1Plan plan = s1_plan(len, lead);
     u8 *w = reinterpret_cast<u8 *>(ws);
-    u8 *edge = w + sizeof(Stage1State);
-    u64 *desc = reinterpret_cast<u64 *>(edge + S1_EDGE_BYTES);
+    u64 *desc = reinterpret_cast<u64 *>(w + sizeof(Stage1State));
     // the state and the descriptors are not adjacent: two ranges, one kernel (state first: 8 words)
     const u64 desc_words = plan.tiles;
     const u64 zq = zero2 ? (u64)zero2_bytes / 16 : 0;  // (a multiple of 16 bytes, 16-byte aligned: stage2_zero_bytes)
     const u64 work = (desc_words > zq / 4 ? desc_words : zq / 4);  // ~4 quads per thread
     const u32 blocks = (u32)((work + 255) / 256 < 2 ? 2 : ((work + 255) / 256 > 256 ? 256 : (work + 255) / 256));
-    hipLaunchKernelGGL(k_s1_prepare, dim3(blocks), dim3(256), 0, stream, base, lead, lead + (u64)len, plan.tm.nu, edge,
-                       reinterpret_cast<u64 *>(w), desc, desc_words, reinterpret_cast<uint4 *>(zero2), zq);
+    hipLaunchKernelGGL(k_s1_prepare, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<u64 *>(w), desc, desc_words,
+                       reinterpret_cast<uint4 *>(zero2), zq);
     return hipGetLastError();
 }
 
@@ -1161,20 +1189,22 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
     return (size_t)tiles * (size_t)(v.block / 64) * TRACE_WORDS;
 }
 
-// d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be prepared.
+// d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be clean: zeroed once, then only used
+// by launches of this function, each of which has run to its end (sj_device.h Stage1State).
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
 hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                                   hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
-                                  unsigned long long *h_state) {
+                                  unsigned long long *h_state, void *zero2, size_t zero2_bytes) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
     const S1Plan plan = s1_plan(len, lead);
     const u32 tiles = plan.tiles;
     Stage1State *st = reinterpret_cast<Stage1State *>(ws);
-    const u8 *edge = reinterpret_cast<const u8 *>(st + 1);
-    u64 *desc = reinterpret_cast<u64 *>(const_cast<u8 *>(edge) + S1_EDGE_BYTES);
-    if (tiles == 0) return hipSuccess;
+    u64 *desc = reinterpret_cast<u64 *>(st + 1);
+    if (tiles == 0) {  // (nothing is launched: the stage-2 state of an empty message is zeroed the plain way)
+        return zero2 && zero2_bytes ? hipMemsetAsync(zero2, 0, zero2_bytes, stream) : hipSuccess;
+    }
     const S1Variant v = s1_variant();
     const u32 nd = (u32)((ndjson & 1) != 0);
     S1Aux aux = {};
@@ -1183,13 +1213,14 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     aux.trace = reinterpret_cast<u64 *>(d_trace);
     aux.host = h_state;
     aux.want_flag = (ndjson & S1_WANT_STARTER_FLAG) != 0;
+    aux.zero2 = reinterpret_cast<uint4 *>(zero2);
+    aux.zero2_quads = zero2 ? (u64)zero2_bytes / 16 : 0;  // (a multiple of 16 bytes, 16-byte aligned: stage2_zero_bytes)
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) aux.exp = (u32)strtoul(e, nullptr, 0);
 #endif
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = SJ_ARR(a.qm, a.chunks, A_S1_QM);
-        aux.q = SJ_ARR(a.q, a.chunks, A_S1_Q);
         aux.st = SJ_ARR(a.st, a.chunks, A_S1_ST);
         aux.unit_h = SJ_ARR(a.unit_h, a.units, A_S1_UNIT_H);
         aux.unit_slow = SJ_ARR(a.unit_slow, a.units, A_S1_UNIT_SLOW);
@@ -1199,7 +1230,7 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     }
 #define S1_LAUNCHK(K, B)                                                                                            \
     hipLaunchKernelGGL((K), dim3(grid_for(K, B, tiles)), dim3(B), 0, stream, base, lead, (u64)len, d_pos, (u64)pos_cap, \
-                       st, desc, tiles, plan.tm, aux, edge)
+                       st, desc, tiles, plan.tm, aux)
 #define S1_LAUNCH(KERNEL, B, C, W)                                                    \
     do {                                                                              \
         const bool ax = aux_buf || d_kind;                                            \
@@ -1242,12 +1273,12 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     return hipGetLastError();
 }
 
+// one launch: the workspace is clean (see stage1_launch_prepared), the kernel's last block zeroes zero2
 hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
                          hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
                          size_t zero2_bytes) {
-    hipError_t e = stage1_prepare(d_msg, len, ws, stream, zero2, zero2_bytes);
-    if (e != hipSuccess) return e;
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state);
+    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state, zero2,
+                                  zero2_bytes);
 }
 
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses of the stage-1 kernels since the

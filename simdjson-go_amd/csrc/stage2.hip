@@ -182,6 +182,14 @@ __device__ __forceinline__ u32 gen_unit_list(GenUnit *gu, u64 le, u64 foreign, i
     return (u32)__shfl((int)incl, 63, 64);
 }
 
+// The unescaped quotes of this lane's chunk from the in-string masks of a whole unit, one chunk per lane, every lane active
+// (sj_strings.h StrView::quotes: stage 1 does not store them -- a quote sits where the unit-relative mask changes; the bit in
+// front of a chunk is the last bit of the lane below, 0 in front of lane 0)
+__device__ __forceinline__ u64 wave_quotes(u64 qm) {
+    const u32 prev_hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(qm >> 32), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return qm ^ ((qm << 1) | (u64)(prev_hi >> 31));
+}
+
 // ---- WithCopyStrings(false): which strings are copied, decided 64 bytes at a time (sj_strings.h chunk_sel) ---------------
 // The state at a unit's ends: does the string that is open at the start of unit u hold an escape starter in FRONT of the
 // unit (the starters behind the last quote of the nearest unit in front that holds a quote, and all starters of the units
@@ -212,7 +220,7 @@ __device__ __forceinline__ u32 sel_unit_in(const S2Dev &p, u64 u, int lane, bool
         acc |= (sb & ((1ull << near) - 1ull)) != 0 ? 1u : 0u;
         const u64 v = u - 1 - (u64)near;
         const u64 c = v * 64 + lane;
-        const u64 q = p.sv.q[c];
+        const u64 q = wave_quotes(p.sv.qm[c]);
         const u64 st = (sb >> near) & 1ull ? p.sv.st[c] : 0ull;
         const u64 qc = __ballot(q != 0);
         if (qc != 0) {  // (always: the flag says so)
@@ -249,7 +257,7 @@ __device__ __forceinline__ u32 sel_unit_out(const S2Dev &p, u64 u, int lane, boo
         acc |= (sb & ((1ull << near) - 1ull)) != 0 ? 1u : 0u;
         const u64 v = w + (u64)near;
         const u64 c = v * 64 + lane;
-        const u64 q = p.sv.q[c];
+        const u64 q = wave_quotes(p.sv.qm[c]);
         const u64 st = (sb >> near) & 1ull ? p.sv.st[c] : 0ull;
         const u64 qc = __ballot(q != 0);
         if (qc != 0) {
@@ -325,7 +333,7 @@ __device__ __forceinline__ void str_masks_body(const S2Dev &p, u32 block, u32 nb
                 continue;
             }
         }
-        const u64 qm = p.sv.qm[c], q = p.sv.q[c];
+        const u64 qm = p.sv.qm[c], q = wave_quotes(qm);
         const u64 st = (uh & 2u) ? p.sv.st[c] : 0ull;
         const u64 stp = (c && ((lane ? uh : uhp) & 2u)) ? p.sv.st[c - 1] >> 63 : 0ull;
         const ChunkFast cf = chunk_fast(qm, q, st, stp << 63, h);
@@ -649,7 +657,7 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
     const u64 nwaves = (u64)gridDim.x * 4;
     u64 unit = (u64)blockIdx.x * 4 + wave;
     struct Raw {   // what is requested two units ahead
-        u64 qm, q, st;       // the masks of the lane's chunk
+        u64 qm, st;          // the masks of the lane's chunk
         u32 stp_hi;          // ... and the upper half of st of the chunk in front (bit 31: its last byte starts an escape)
         ChunkRec r;          // record units
         u32 g, sb;           // exclusive prefixes of the unit: Strings.B offset, string ordinal
@@ -689,7 +697,7 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
     };
     auto load_raw = [&](u64 u, const Sc &sc) {
         Raw x;
-        x.qm = x.q = x.st = 0;
+        x.qm = x.st = 0;
         x.stp_hi = 0;
         x.r = ChunkRec{0, 0, 0};
         x.g = sc.g;
@@ -702,7 +710,6 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
         if (!x.live) return x;
         const u64 c = u * 64 + lane;
         x.qm = p.sv.qm[c];
-        x.q = p.sv.q[c];
         // (the st masks of a unit without an escape starter are zero and stay unread: parking-citations has none at all)
         if (sc.flags & 2u) x.st = p.sv.st[c];
         if (c && (sc.flags & (lane ? 2u : 4u))) x.stp_hi = reinterpret_cast<const u32 *>(arr_at(p.sv.st, c - 1, 1))[1];
@@ -723,7 +730,8 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
         v.esc = 0;
         v.g = x.g;
         const u32 h = x.h & 1u;
-        const ChunkFast f = chunk_fast(x.qm, x.q, x.st, (u64)x.stp_hi << 32, h);
+        const u64 xq = wave_quotes(x.qm);  // (a unit that is not live holds zeros)
+        const ChunkFast f = chunk_fast(x.qm, xq, x.st, (u64)x.stp_hi << 32, h);
         u32 flags;
         if (x.rec) {  // (uniform) emit mask and flags from k_measure's general routine
             v.esc = ((x.st << 1) | (u64)(x.stp_hi >> 31)) & v.em;
@@ -737,12 +745,12 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
         if (SEL && !NE) {  // only the bytes of strings that hold an escape starter
             u64 sel = 0;
             if ((x.h & 2u) || x.uf)  // (uniform)
-                sel = sel_wave_mask(chunk_sel(x.qm, x.q, x.st, h), (x.uf & USEL_IN) ? 1u : 0u, (x.uf & USEL_OUT) ? 1u : 0u, lane);
+                sel = sel_wave_mask(chunk_sel(x.qm, xq, x.st, h), (x.uf & USEL_IN) ? 1u : 0u, (x.uf & USEL_OUT) ? 1u : 0u, lane);
             v.em &= sel;
             v.esc &= sel;
             // (the flags stay: a chunk without an escaped character of its own may still receive the bytes of a \u escape that
             // begins in the chunk in front -- it must park its bytes for the patch like in the other mode)
-            cq = x.q & ~f.oq;
+            cq = xq & ~f.oq;
         }
         const u32 n = (u32)popc64(v.em);
         const u32 ns = (u32)popc64(f.oq);
@@ -2016,7 +2024,7 @@ static S2Dev stage2_view(const S2Args &a) {
     p.sv.end = p.sv.lead + a.len;
     // (k_str_emit reads whole 64-byte chunks: the arenas and the callers' device buffers carry that much slack)
     p.sv.base = SJ_ARR(reinterpret_cast<const u8 *>(addr & ~(uintptr_t)63), (p.sv.end + 63) / 64 * 64, A_SV_BASE);
-    p.sv.qm = p.sv.q = p.sv.st = nullptr;
+    p.sv.qm = p.sv.st = nullptr;
     p.sv.unit_h = nullptr;
     p.sv.unit_slow = nullptr;
     p.rec = nullptr;
@@ -2036,7 +2044,6 @@ static S2Dev stage2_view(const S2Args &a) {
     if (a.str_aux) {
         const StrAux x = str_aux_layout(a.str_aux, (size_t)p.sv.end);
         p.sv.qm = SJ_ARR((const u64 *)x.qm, x.chunks, A_SV_QM);
-        p.sv.q = SJ_ARR((const u64 *)x.q, x.chunks, A_SV_Q);
         p.sv.st = SJ_ARR((const u64 *)x.st, x.chunks, A_SV_ST);
         p.sv.unit_h = SJ_ARR((const u8 *)x.unit_h, x.units, A_SV_UNIT_H);
         p.sv.unit_slow = SJ_ARR((const u64 *)x.unit_slow, x.units, A_SV_UNIT_SLOW);
