@@ -210,11 +210,13 @@ static void invalidate_result(sjhip_ctx *ctx) {
 // stream has been synchronised, collect (the reference's end-of-document verdict).  (Polling the word instead of
 // synchronising -- going on while the kernel's caches are written back -- measured no gain for the whole parse and
 // would hand positions to other streams before they are visible there.)
-// Stage 1 runs without a preparation kernel: a launch leaves the state's control words and the tile descriptors it used
-// zeroed for the next one (stage1.hip block_done).  A workspace that has just been allocated is zeroed here, once.
+// Stage 1 runs without a preparation kernel: every launch zeroes, for the next one, the control slot and the descriptor set
+// the one before it used (sj_device.h Stage1State).  A workspace that has just been allocated is zeroed here, once.
 static int stage1_workspace_clean(sjhip_ctx *ctx) {
     if (ctx->d_ws.p && ctx->ws_clean_gen != ctx->d_ws.gen) {
-        HIPCHK(hipMemsetAsync(ctx->d_ws.p, 0, ctx->d_ws.cap, ctx->stream), "stage-1 workspace memset");
+        ctx->s1ws.p = ctx->d_ws.p;
+        ctx->s1ws.bytes = ctx->d_ws.cap;
+        HIPCHK(stage1_prepare(ctx->s1ws, ctx->stream), "stage-1 workspace memset");
         ctx->ws_clean_gen = ctx->d_ws.gen;
     }
     return SJHIP_OK;
@@ -233,8 +235,9 @@ int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson
     rc = stage1_workspace_clean(ctx);
     if (rc) return rc;
     if (len > 0) {
-        *(volatile unsigned long long *)ctx->h_scratch = 0;
-        HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, str_aux, d_kind,
+        for (int k = 0; k < S1_HOST_WORDS; k++) ((volatile unsigned long long *)ctx->h_scratch)[k] = 0;
+        ctx->s1_par = ctx->s1ws.epoch & 1u;
+        HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->s1ws, ctx->stream, str_aux, d_kind,
                              (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
                "stage1 launch");
     }
@@ -252,7 +255,8 @@ int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_l
             return SJHIP_ERR_HIP;
         }
         hs->total = word & S1_HOST_TOTAL_MASK;
-        hs->error = ((word & S1_HOST_ERROR) ? 1u : 0u) | ((word & S1_HOST_INTERNAL) ? 0x80000000u : 0u);
+        const volatile unsigned long long *hw = (const volatile unsigned long long *)ctx->h_scratch;
+        hs->error = (hw[1] ? 1u : 0u) | (hw[2] ? 0x80000000u : 0u);
         hs->ends_in_quote = (word & S1_HOST_IN_QUOTE) ? 1u : 0u;
         hs->last_byte = (uint32_t)((word >> S1_HOST_LAST_SHIFT) & 0xffu);
     }
@@ -324,16 +328,14 @@ int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson,
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc = arena_reserve(ctx, ctx->d_ws, stage1_workspace_bytes(len + 64));
     if (rc) return rc;
-    // The workspace preparation (zeroed descriptors, the two edge units) is part of every launch, but only the
-    // kernel itself is bracketed by the events: preparation k+1 is issued before event pair k+1.
+    rc = stage1_workspace_clean(ctx);
+    if (rc) return rc;
+    // The launches of a parse, one behind the other on the context's workspace (each cleans up for the next: there is nothing
+    // else to a launch), each bracketed by a pair of events.
     float total = 0.f;
     for (int i = 0; i < iters; i++) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
-        (void)a;
-        HIPCHK(stage1_prepare(d_msg, len, ctx->d_ws.p, ctx->stream), "stage1 prepare");
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream), "event");
-        HIPCHK(stage1_launch_prepared(d_msg, len, ndjson != 0, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream),
-               "stage1 launch");
+        HIPCHK(stage1_launch(d_msg, len, ndjson != 0, (uint32_t *)d_pos, pos_cap, ctx->s1ws, ctx->stream), "stage1 launch");
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream), "event");
         HIPCHK(hipEventSynchronize(ctx->ev1), "event sync");
         float ms = 0.f;
@@ -363,9 +365,10 @@ int sjhip_stage1_trace(sjhip_ctx *ctx, const void *d_msg, size_t len, void *d_po
     rc = arena_reserve(ctx, ctx->d_kat, nw * sizeof(uint64_t));
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_kat.p, 0, nw * sizeof(uint64_t), ctx->stream), "trace memset");
-    HIPCHK(stage1_prepare(d_msg, len, ctx->d_ws.p, ctx->stream), "stage1 prepare");
-    HIPCHK(stage1_launch_prepared(d_msg, len, 0, (uint32_t *)d_pos, pos_cap, ctx->d_ws.p, ctx->stream, nullptr, nullptr,
-                                  (unsigned long long *)ctx->d_kat.p),
+    rc = stage1_workspace_clean(ctx);
+    if (rc) return rc;
+    HIPCHK(stage1_launch(d_msg, len, 0, (uint32_t *)d_pos, pos_cap, ctx->s1ws, ctx->stream, nullptr, nullptr, nullptr, nullptr, 0,
+                         (unsigned long long *)ctx->d_kat.p),
            "stage1 launch (trace)");
     HIPCHK(hipMemcpyAsync(trace_out, ctx->d_kat.p, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "D2H trace");
     HIPCHK(hipStreamSynchronize(ctx->stream), "trace sync");

@@ -45,7 +45,7 @@ static S2Args s2_args(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_base,
     a.n_dev = ctx->p_deferred ? (const unsigned long long *)((const char *)ctx->d_ws.p + offsetof(Stage1State, total)) : nullptr;
     a.flags = ctx->p_flags;
     // (stage 1 of this parse ran in the context's stage-1 workspace, whose first line is its state)
-    a.s1_has_starter = ctx->p_aux ? (const uint32_t *)((const char *)ctx->d_ws.p + offsetof(Stage1State, has_starter)) : nullptr;
+    a.s1_has_starter = ctx->p_aux ? (const uint32_t *)((const char *)ctx->d_ws.p + offsetof(Stage1State, c) + ctx->s1_par * sizeof(Stage1Ctrl) + offsetof(Stage1Ctrl, has_starter)) : nullptr;
     a.ws_zero = ctx->d_s2z.p;
     a.ws = ctx->d_s2.p;
     a.d_tape = (uint64_t *)ctx->d_tape.p;
@@ -272,7 +272,7 @@ static int parse_finish(sjhip_ctx *ctx, uint64_t tape_base, uint64_t strings_bas
             memcpy(hs, ctx->h_pack, sizeof(S2State));
             ctx->pack_valid = *(const unsigned long long *)(ctx->h_pack + 64) != 0;
         } else {
-            HIPCHK(hipMemcpyAsync(hs, ctx->d_s2z.p, sizeof(S2State), hipMemcpyDeviceToHost, ctx->stream), "D2H stage2 state");
+            HIPCHK(stage2_launch_state_out(a, hs), "stage2 state");
             HIPCHK(hipStreamSynchronize(ctx->stream), "stage2 sync");
         }
         if (hs->bignum_count && !(hs->err & S2_ERR_SERIAL_STRINGS)) {  // rare: >19-digit mantissas that need the exact tie-break

@@ -37,6 +37,8 @@ struct sjhip_ctx {
     sj::DevBuf d_scol, d_stab;         // serializer with de-duplication: the string column, the hash table
     sj::DevBuf d_q, d_qtape, d_qstrings;  // queries over the last result (query.hip): work arrays, filtered tape / Strings.B
     unsigned ws_clean_gen = 0;         // d_ws.gen of the allocation that has been zeroed for stage 1 (0: none; stage1_enqueue)
+    sj::S1Ws s1ws;                     // ... and its launch count (sj_device.h: a launch cleans up for the next one)
+    unsigned s1_par = 0;               // control slot of the last stage-1 launch (Stage1State::c[]: stage 2 reads has_starter there)
     sj::Stage1State s1;                // last stage-1 state (host copy)
     // last parse (kept on the device until sjhip_fetch)
     size_t tape_len = 0, strings_len = 0;

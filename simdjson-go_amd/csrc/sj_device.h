@@ -6,28 +6,33 @@
 
 namespace sj {
 
-// Lives at the start of the stage-1 workspace, the tile descriptors behind it.  Round 6: no preparation kernel in front of
-// every launch any more -- the control words (tile_counter, done, err_acc, starter_acc) and the descriptors a launch used are
-// zero again when it ends (its last block cleans up: stage1.hip block_done), the result words (error, total, ends_in_quote,
-// has_starter) are overwritten by every launch and stay for whoever reads them behind it.  A fresh workspace is zeroed once.
-struct Stage1State {
+// Lives at the start of the stage-1 workspace; two sets of tile descriptors behind it.  Round 6: no preparation kernel in front
+// of a launch any more.  The launches on a workspace are counted (their owner keeps the epoch); launch k works on control
+// slot k & 1 and on descriptor set k & 1 -- both zero when it begins -- and zeroes slot and set (k + 1) & 1, which launch
+// k - 1 used and nobody looks at any more: cleaning needs no ordering inside the launch, every block does a slice when it
+// starts.  The result words are overwritten by every launch.  A fresh workspace is zeroed once (epoch 0).
+struct Stage1Ctrl {
     uint32_t tile_counter;   // dynamic tile id dispenser
-    uint32_t error;          // OR of (control char inside string)   -> reference error_mask != 0
-    uint64_t total;          // number of structural indexes
-    uint32_t ends_in_quote;  // reference prev_iter_inside_quote != 0 at the end
-    uint32_t done;           // blocks that have finished: the last one copies this record to pinned host memory
-    uint32_t last_byte;      // msg[len - 1] (host copy only: the end-of-document verdict needs it)
+    uint32_t error;          // OR of (control char inside string)   -> reference error_mask != 0; bit 31: a bounded spin ran out
     uint32_t has_starter;    // whole parse: some unit holds a backslash that starts an escape (stage 2 reads it on the device:
                              // WithCopyStrings(false) of a message without one copies nothing and measures nothing)
-    uint32_t err_acc;        // control: the blocks OR their error bits here; the last block moves them to `error`
-    uint32_t starter_acc;    // control: ... and the starter flag to `has_starter`
-    uint32_t pad[6];
+    uint32_t pad;
+};
+struct Stage1State {
+    Stage1Ctrl c[2];
+    uint64_t total;          // number of structural indexes
+    uint32_t ends_in_quote;  // reference prev_iter_inside_quote != 0 at the end
+    uint32_t error;          // host copy only: c[].error as the host records deliver it
+    uint32_t last_byte;      // host copy only: msg[len - 1] (the end-of-document verdict needs it)
+    uint32_t pad[3];
 };
 static_assert(sizeof(Stage1State) == 64, "Stage1State must stay one 64-byte line");
-// the packed result word the last block of stage 1 stores to pinned host memory
-static constexpr uint64_t S1_HOST_VALID = 1ull << 63, S1_HOST_INTERNAL = 1ull << 62, S1_HOST_ERROR = 1ull << 61,
-                          S1_HOST_IN_QUOTE = 1ull << 60, S1_HOST_TOTAL_MASK = (1ull << 40) - 1;
+// The host record of stage 1: three 8-byte words of pinned host memory, zeroed by the caller.  Word 0 is stored by the block that
+// flattens the last tile (count, state at the end, the last message byte); word 1 / word 2 are set to 1 by any block that met a
+// control character inside a string / whose bounded spin ran out.  The host reads them after it has synchronised with the stream.
+static constexpr uint64_t S1_HOST_VALID = 1ull << 63, S1_HOST_IN_QUOTE = 1ull << 60, S1_HOST_TOTAL_MASK = (1ull << 40) - 1;
 static constexpr int S1_HOST_LAST_SHIFT = 48;  // 8 bits: msg[len - 1]
+static constexpr int S1_HOST_WORDS = 3;
 
 // stage-2 totals and flags (zeroed before every launch)
 struct S2State {
@@ -83,6 +88,8 @@ hipError_t stage2_launch_bignum(const S2Args &a);
 // says whether the payload is there.  h_dst is pinned host memory mapped into the device (one launch, no copy commands).
 constexpr size_t STAGE2_PACK_HEAD = 128;
 hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap);
+// the 64-byte state alone to h_dst (pinned, device-mapped): a one-wave kernel instead of a device-to-host copy command
+hipError_t stage2_launch_state_out(const S2Args &a, void *h_dst);
 
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses since the last call (cleared);
 // 0 in the product build.  _selftest: -1 in the product build, else the violations recorded for two deliberate ones
@@ -91,10 +98,16 @@ int stage1_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index,
 int stage2_debug_bounds_selftest();
 
 size_t stage1_workspace_bytes(size_t len);
-// Zeroes the state and the descriptors of a workspace whose contents are unknown (a parse does not need it: every launch
-// leaves the workspace clean, and whoever allocates one zeroes it once).  zero2 / zero2_bytes: a second region to zero in
-// the same kernel, or null
-hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2 = nullptr, size_t zero2_bytes = 0);
+// A stage-1 workspace and what its owner keeps about it: the launches on it are counted (Stage1State above).
+struct S1Ws {
+    void *p = nullptr;
+    size_t bytes = 0;
+    unsigned epoch = 0;       // launches since the workspace was zeroed
+    unsigned prev_tiles = 0;  // descriptors the last launch used (the next one zeroes them)
+};
+// Zeroes a workspace whose contents are unknown and resets its epoch (a parse does not need it: every launch leaves the
+// workspace ready for the next one).  zero2 / zero2_bytes: a second region to zero, or null
+hipError_t stage1_prepare(S1Ws &ws, hipStream_t stream, void *zero2 = nullptr, size_t zero2_bytes = 0);
 // String-mask workspace of the whole parse (copy_strings): stage 1 fills qm / st / unit_h, the string
 // kernels of stage 2 add one 16-byte record per chunk (sj_strings.h ChunkRec) and unit_cnt.  `span` = lead + len (bytes from the 64-byte aligned
 // base of the message); everything is sized in whole 4 KiB units.
@@ -137,18 +150,16 @@ inline size_t str_aux_bytes(size_t span) { return str_aux_layout(nullptr, span).
 // `ndjson` of the launch functions: bit 0 NDJSON | S1_WANT_STARTER_FLAG (whole parse with WithCopyStrings(false): the kernel also
 // leaves Stage1State::has_starter -- one look and at most one store per block; nobody else pays for it)
 static constexpr int S1_WANT_STARTER_FLAG = 0x100;
-// aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions
-hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap,
-                                  void *ws, hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                                  unsigned long long *d_trace = nullptr, unsigned long long *h_state = nullptr,
-                                  void *zero2 = nullptr, size_t zero2_bytes = 0);
+// aux_buf: string masks for the whole parse (str_aux_layout); d_kind: [pos_cap] token kinds next to the positions.
+// h_state: S1_HOST_WORDS 8-byte words of pinned host memory (device-visible, zeroed by the caller): the host record -- the
+// host needs a stream synchronisation but no copy.  zero2: a region the launch zeroes for the kernels behind it (the stage-2
+// state of this parse).  d_trace: profiling builds of the kernel (stage1_trace_words() zeroed u64)
+hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, S1Ws &ws,
+                         hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
+                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0,
+                         unsigned long long *d_trace = nullptr);
 // kernel variant for A/B runs (-1: SJHIP_S1_VARIANT or the default); per-phase trace size of one launch
 int stage1_set_variant(int v);
 size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *waves_out);
-// h_state: one 8-byte word of pinned host memory (device-visible, zeroed by the caller); the last block to finish stores
-// the packed result there (S1_HOST_*) in one store: the host needs a stream synchronisation but no copy
-hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, uint32_t *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf = nullptr, uint8_t *d_kind = nullptr,
-                         unsigned long long *h_state = nullptr, void *zero2 = nullptr, size_t zero2_bytes = 0);
 
 }  // namespace sj

@@ -55,7 +55,10 @@ struct S1Aux {
     Arr<u32> tile_unit;  // [units + 1] the unit that holds token 4096 T: the positions are 32 bits wide and wrap in a message of
                          // more than 4 GiB -- the token kernels rebuild a tile's positions from the unit its first token lies in
     u64 *trace;        // TRACE builds only: TRACE_WORDS s_memtime stamps per (tile, wave)
-    unsigned long long *host;  // pinned host memory or null: the last block to finish leaves the packed result there
+    unsigned long long *host;  // pinned host memory or null: the host record (sj_device.h S1_HOST_*: three words)
+    u64 *clean_desc;   // the descriptor set of the previous launch on this workspace and how many of them it used: zeroed by this
+    u32 clean_tiles;   // launch for the next one (sj_device.h Stage1State; no ordering needed: nobody reads them any more)
+    u32 par;           // epoch & 1: the control slot and the descriptor set of this launch
     bool want_flag;    // leave Stage1State::has_starter (WithCopyStrings(false): stage2.hip no_escapes)
     uint4 *zero2;      // null, or a second region the launch's last block zeroes: the stage-2 state and scan slots of THIS parse
     u64 zero2_quads;   // (every stage-2 kernel of the previous parse is through when this launch runs, none of this one has begun)
@@ -71,54 +74,29 @@ struct S1Aux {
 #else
 #define SJ_S1EXP(a, b) false
 #endif
-// End of a block (after a block barrier: every wave has issued its last update of *st).  The block that finds all the
-// others finished (a) cleans up -- round 6: there is no preparation kernel in front of a launch any more (it cost 3-4 us
-// and a kernel boundary on every parse, and the host of a device-resident small message had not enqueued stage 1 yet when
-// it was through): the tile descriptors this launch used and the control words of the state are zeroed for the NEXT launch
-// on this workspace, the stage-2 state of THIS parse (aux.zero2) for the kernels behind -- (b) moves the error bits and
-// the starter flag the blocks accumulated into the result words, and (c) publishes the state -- and the last message
-// byte -- to the host record.
-__device__ __forceinline__ void block_done(Stage1State *st, const S1Aux &aux, const u8 *msg, u64 len, u64 *__restrict__ desc,
-                                           u32 num_tiles) {
-    __shared__ u32 s_last;
-    // every update of *st is an agent-scope atomic (write-through: performed at the memory side, like the tile descriptors):
-    // once this wave's are acknowledged (the drained store counter) and the block has met, one counter tells which block is
-    // the last -- the guide's hand-off form "sc1 payload -> vmcnt(0) -> sc1 flag", the one the look-back and the scan slots
-    // of stage 2 use.  (Rounds 4-5 made the counter an acquire-release operation: a write-back of the XCD's L2 and an
-    // invalidate per block, at the very end of the kernel where nothing hides them -- 6-8 us per launch, measured when the
-    // timing entry point began to run this epilogue too: 256 MiB 0.093 -> 0.101 ms.  Nothing here needs them: the last
-    // block reads state words that were written through, its own stores leave with the kernel's end like everybody's
-    // positions, and every look-back load of the descriptors it zeroes has returned before its block counted itself.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const u32 d = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = d == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last == 0u) return;  // (uniform)
-    for (u32 i = threadIdx.x; i < num_tiles; i += blockDim.x) desc[i] = 0;
-    for (u64 i = threadIdx.x; i < aux.zero2_quads; i += blockDim.x) aux.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x == 0) {
-        const u32 err = __hip_atomic_load(&st->err_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 hs = __hip_atomic_load(&st->starter_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 total = __hip_atomic_load(&st->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 eiq = __hip_atomic_load(&st->ends_in_quote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st->error = err;
-        st->has_starter = hs;
-        st->err_acc = 0;
-        st->starter_acc = 0;
-        st->tile_counter = 0;
-        st->done = 0;
-        if (aux.host) {
-            // the whole result in ONE 8-byte store (several stores would need a system-scope release, i.e. an L2
-            // write-back, to be ordered among themselves): S1_HOST_* in sj_device.h
-            const u64 word = S1_HOST_VALID | ((err & 0x80000000u) ? S1_HOST_INTERNAL : 0) | ((err & 1u) ? S1_HOST_ERROR : 0) |
-                             (eiq ? S1_HOST_IN_QUOTE : 0) | ((u64)(len ? msg[len - 1] : 0u) << S1_HOST_LAST_SHIFT) |
-                             (total & S1_HOST_TOTAL_MASK);
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(aux.host), (unsigned long long)word, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+// Start of a block: its slice of the cleaning this launch does for the next one (sj_device.h Stage1State) and of the stage-2
+// state of this parse.  Order-free: the descriptors and the control slot belong to a launch that is over, the stage-2 region to
+// kernels that have not begun.  (The first half of round 6 let "the last block" clean up behind a completion counter: an
+// atomic per block and two dependent round trips at the very end of the kernel, where nothing hides them -- 256 MiB 0.0935 ->
+// 0.0955 ms, gpurun_out/r6v_s1b.txt -- and counting the blocks in front of their last flatten did not hide them either.)
+__device__ __forceinline__ void launch_clean(Stage1State *st, const S1Aux &aux) {
+    const u64 thr = (u64)blockIdx.x * blockDim.x + threadIdx.x, nthr = (u64)gridDim.x * blockDim.x;
+    for (u64 i = thr; i < aux.clean_tiles; i += nthr) aux.clean_desc[i] = 0;
+    for (u64 i = thr; i < aux.zero2_quads; i += nthr) aux.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (thr == 0) *reinterpret_cast<uint4 *>(&st->c[aux.par ^ 1u]) = make_uint4(0u, 0u, 0u, 0u);
+}
+// an error of the launch: control word (device) and host record (a store of a constant: any number of blocks may do it)
+__device__ __forceinline__ void report_error(Stage1Ctrl *ctl, const S1Aux &aux, u32 bit) {
+    atomicOr(&ctl->error, bit);
+    if (aux.host) __hip_atomic_store(&aux.host[bit == 1u ? 1 : 2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the block that flattens the last tile leaves the count: device word (stage 2 reads it) and word 0 of the host record
+__device__ __forceinline__ void report_total(Stage1State *st, const S1Aux &aux, u64 total, u32 ends_in_quote, const u8 *msg, u64 len) {
+    __hip_atomic_store(&st->total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (aux.host) {
+        const u64 word = S1_HOST_VALID | (ends_in_quote ? S1_HOST_IN_QUOTE : 0) | ((u64)(len ? msg[len - 1] : 0u) << S1_HOST_LAST_SHIFT) |
+                         (total & S1_HOST_TOTAL_MASK);
+        __hip_atomic_store(&aux.host[0], (unsigned long long)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // per-phase timeline of a tile for every wave (profiling builds of the kernels, sjhip_stage1_trace):
@@ -233,26 +211,9 @@ __device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base,
 // message the bytes outside the message count as 0x20, exactly like the reference's space-masked tail
 // (find_structural_bits_amd64.s:134-155); leading pad bytes are whitespace as well, which leaves the initial
 // pseudo_pred (=1) semantics untouched.  (Rounds 1-5: a preparation kernel left blank-padded copies of the two units
-// in the workspace.  Round 6: the units are read where they lie -- a chunk that begins behind the message is not
-// read (its lane reads the message's last chunk instead), one that holds its first or last byte is read whole: its 64-byte
-// line is the message's own -- and phase A blanks the bytes outside [lead, end) of those two units, edge_blank.)
-// the chunk at byte offset c0 (from base) of the first or the last unit: bytes outside [lead, end) count as blanks.  Done on the
-// CLASS masks, not on the bytes (a dozen 64-bit operations; blanking the sixteen dwords was 3.6 KB of code in every copy of
-// phase A): outside the message every class is empty except whitespace -- everything behind classify() reads only the masks.
-__device__ __forceinline__ void edge_blank(Classes &c, u64 c0, u64 lead, u64 end) {
-    const u32 lo = c0 < lead ? (u32)(lead - c0) : 0u;                            // (lead < 64: only chunk 0 has lo > 0)
-    const u32 hi = end > c0 ? (end - c0 < 64 ? (u32)(end - c0) : 64u) : 0u;      // bytes [lo, hi) of the chunk are message bytes
-    const u64 valid = (hi >= 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
-    c.bs &= valid;
-    c.quote &= valid;
-    c.structs &= valid;
-    c.ctrl &= valid;
-    c.nl &= valid;
-    c.esc1 &= valid;
-    c.ws |= ~valid;
-#pragma unroll
-    for (int i = 0; i < 4; i++) c.kp[i] &= valid;
-}
+// in the workspace.  Round 6: the wave that loads one of the two builds it in its registers, edge_unit_load below --
+// a branch where the loads are issued, nothing in phase A: blanking the class masks there, a dozen 64-bit operations
+// behind a uniform branch in the middle of the classification, cost 2-3 % at every size, gpurun_out/r6v_s1b.txt.)
 // a unit in flight: this lane's chunk and (every lane the same) the 8 message bytes in front of the unit, which the
 // carries into its first chunk come from -- fetched with the chunk so that nothing waits for a scalar load later
 // (measured -2.5 %).  One unit per wave is in flight; a second one (each pass loaded a whole tile ahead) measured
@@ -261,29 +222,55 @@ struct UnitRegs {
     uint4 v[4];
     u64 prev8;
 };
-__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, u64 end, u64 unit, int lane, UnitRegs &r) {
-    // (only chunks of the last unit can lie behind the message: those lanes read the message's last chunk instead -- an address
-    // clamp, not a predicated load: every lane's registers are defined by the load, so the compiler stays free to keep the unit
-    // in flight in registers of its own -- and phase A blanks what they hold)
-    const u64 last = (end - 1) & ~63ull;  // (uniform; len > 0)
-    u64 off = unit * 4096 + (u64)lane * 64;
-    off = off < last ? off : last;
-    const uint4 *p = reinterpret_cast<const uint4 *>(base + off);
+// The first or the last unit of the message (at most two units per launch).  A chunk inside the message is loaded, a chunk
+// outside is blanks, and the (at most two) chunks the message covers only partly -- the one with its first byte when the
+// message does not begin on a 64-byte boundary, the one with its last -- are fetched a byte per lane (only message bytes are
+// touched), laid down in 64 bytes of LDS and picked up by the lane that owns the chunk.
+__device__ __forceinline__ void edge_unit_load(const u8 *__restrict__ base, u64 lead, u64 end, u64 unit, int lane, UnitRegs &r,
+                                               u8 *s_edge_w) {
+    const u64 c0 = unit * 4096 + (u64)lane * 64;
+    const uint4 blank = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
 #pragma unroll
-    for (int q = 0; q < 4; q++) r.v[q] = p[q];
+    for (int q = 0; q < 4; q++) r.v[q] = blank;
+    if (c0 >= lead && c0 + 64 <= end) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + c0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) r.v[q] = p[q];
+    }
+    const u64 cl = (end - 1) & ~63ull;  // the chunk that holds the last byte (len > 0)
+    const bool head = unit == 0 && lead > 0;
+    const bool tail = (end & 63) != 0 && (cl >> 12) == unit && !(head && cl == 0);  // (one chunk may hold both ends: once)
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        if (!(k == 0 ? head : tail)) continue;  // (uniform)
+        const u64 pc = k == 0 ? 0ull : cl;
+        const u64 a = pc + (u64)lane;
+        u8 b = 0x20;
+        if (a >= lead && a < end) b = base[a];
+        s_edge_w[lane] = b;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (c0 == pc) {
+            const uint4 *e = reinterpret_cast<const uint4 *>(s_edge_w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) r.v[q] = e[q];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();  // (the window is read: the second round may write it)
+    }
+}
+__device__ __forceinline__ void unit_issue(const u8 *__restrict__ base, u64 lead, u64 end, u64 unit, u32 nu, int lane, UnitRegs &r,
+                                           u8 *s_edge_w) {
+    if (unit != 0 && unit + 1 != nu) {  // (uniform)
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + unit * 4096) + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) r.v[q] = p[q];
+    } else {
+        edge_unit_load(base, lead, end, unit, lane, r, s_edge_w);
+    }
     // (unit 0 has nothing in front of it: its own first bytes are read instead and not used)
     r.prev8 = *reinterpret_cast<const u64 *>(base + (unit ? unit * 4096 - 8 : 0));
 }
-// Zeroes the Stage1State and the tile descriptors.  Not part of a parse any more (block_done): the timing / tracing entry
-// points and a workspace whose state is unknown use it.
-__global__ __launch_bounds__(256) void k_s1_prepare(u64 *__restrict__ state, u64 *__restrict__ desc, u64 desc_words,
-                                                    uint4 *__restrict__ zero2, u64 zero2_quads) {
-    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, gsz = (u64)gridDim.x * 256;
-    if (gid < sizeof(Stage1State) / 8) state[gid] = 0;
-    for (u64 i = gid; i < desc_words; i += gsz) desc[i] = 0;
-    for (u64 i = gid; i < zero2_quads; i += gsz) zero2[i] = make_uint4(0u, 0u, 0u, 0u);  // stage-2 state and chain descriptors
-}
-
 // ---- the look-back (wave 0 of a block) -------------------------------------------------------
 // Resumable look-back: one call = one window of 256 descriptors (4 per lane, nearest first).
 struct LookBack {
@@ -373,7 +360,7 @@ template <int BLOCK, int CH, bool NDJSON, bool AUX>
 __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u64 end, TileMap tm, u32 t, u32 t_next,
                                         bool has_next, int lane, int wave, UnitRegs &pf, u64 *m, u32 *pre, u32 *s_unit,
                                         const S1Aux &aux, u64 (&kp)[CH][4], uint2 *s_ucnt,
-                                        u32 &seen_st, bool TOP = false) {
+                                        u32 &seen_st, u8 *s_edge_w, bool TOP = false) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int UNITS = WAVES * CH;
 #if defined(SJ_S1_ROLL)
@@ -393,7 +380,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             if (lane == 0) s_unit[k * WAVES + wave] = 0;
             if (AUX && lane == 0) s_ucnt[k * WAVES + wave] = make_uint2(0u, 0u);
             kp[k][0] = kp[k][1] = kp[k][2] = kp[k][3] = 0;
-            if (unit_nx != VOID_UNIT) unit_issue(base, end, unit_nx, lane, pf);
+            if (unit_nx != VOID_UNIT) unit_issue(base, lead, end, unit_nx, tm.nu, lane, pf, s_edge_w);
             continue;
         }
         const u64 unit_off = unit * 4096;
@@ -415,7 +402,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // the next pass goes in flight before this one is classified: a whole pass of math to arrive in (the compiler
         // keeps the chunk in its own registers; issuing the loads only after classify(), into the registers the chunk
         // dies in, measured 1-2 % slower)
-        if (unit_nx != VOID_UNIT) unit_issue(base, end, unit_nx, lane, pf);
+        if (unit_nx != VOID_UNIT) unit_issue(base, lead, end, unit_nx, tm.nu, lane, pf, s_edge_w);
         __builtin_amdgcn_sched_barrier(0);
         // issue priority by progress: the SIMD arbiter prefers its oldest wave, which then finishes a pass long before
         // the others and leaves the tail of every phase to one or two waves that cannot fill the pipe; with the waves
@@ -423,8 +410,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         // of the barrier kernel: it has the look-back to do while the others are still in this phase).
         if (k == 0 || TOP) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
-        Classes c = classify(w);
-        if (unit == 0 || unit + 1 == tm.nu) edge_blank(c, unit_off + (u64)lane * 64, lead, end);  // (uniform)
+        const Classes c = classify(w);
         if (AUX) {  // the kind of the token a byte would start, as four bit planes (flatten_tile looks them up per structural)
             kp[k][0] = c.kp[0];
             kp[k][1] = c.kp[1];
@@ -705,12 +691,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // tile it has just classified in registers until it has flattened the tile in front, then parks them here
     __shared__ __attribute__((aligned(16))) u64 s_kpl[AUX ? WAVES : 1][AUX ? CH * 4 * 64 : 2];
     __shared__ uint2 s_ucnt[3][AUX ? UNITS : 1];  // whole parse: string bytes / opening quotes per unit, both hypotheses (ring of s_unit)
+    __shared__ __attribute__((aligned(16))) u8 s_edge[WAVES][64];  // unit_issue: the chunk that holds the message's first / last byte
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)uniform((u32)tid >> 6);
     const u64 end = lead + len;
     u64 kp[CH][4];
+    Stage1Ctrl *const ctl = &st->c[aux.par];
+    launch_clean(st, aux);
 
     // The first tile of a block: its own index if the whole message is ONE round of tiles (num_tiles <= gridDim.x: every
     // tile in front of a block's tile then belongs to a block with a lower index, which the dispatcher started earlier, so
@@ -726,19 +715,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     // its way like every later phase A does for its successor, instead of behind the first barrier with the whole load
     // latency exposed (64 MiB: 0.0384 -> 0.0370 ms, same box, alternating; nothing at 256 MiB and 1 GiB)
     if (tid == 0) {
-        s_ticket[0] = one_round ? blockIdx.x : atomicAdd(&st->tile_counter, 1u);
-        s_ticket[1] = tk_base + atomicAdd(&st->tile_counter, 1u);
+        s_ticket[0] = one_round ? blockIdx.x : atomicAdd(&ctl->tile_counter, 1u);
+        s_ticket[1] = tk_base + atomicAdd(&ctl->tile_counter, 1u);
     }
     __syncthreads();
     const u32 t_first = uniform(s_ticket[0]);
-    if (t_first >= num_tiles) {
-        block_done(st, aux, base + lead, len, desc, num_tiles);
-        return;
-    }
+    if (t_first >= num_tiles) return;
     UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
-        if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
+        if (un != VOID_UNIT) unit_issue(base, lead, end, un, tm.nu, lane, pf, s_edge[wave]);
     }
 
     // One loop, one copy of phase A and of the flatten in the instruction stream (a peeled first tile made every block
@@ -753,6 +739,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
     u32 P0 = 0, T00 = 0, T01 = 0, pm0 = 0;  // its aggregates; meaningful in wave 0 only
     bool err = false;
     u32 seen_st = 0;                        // whole parse: a unit of this wave held an escape starter
+    u32 eiq_last = 0;                       // lane 0 of wave 0: the state at the end of the message (the block of the last tile)
     for (u32 j = 0;; j++) {
         const bool first = j == 0;
         const u32 t_a = uniform(s_ticket[j & 3u]);                               // phase A runs on T(j)
@@ -761,11 +748,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         const int ma = (int)(j & 1u), ua = (int)(j % 3u);        // mask / unit slot of T(j)
         const int mf = ma ^ 1, uf = ua == 0 ? 2 : ua - 1;        // ... of T(j-1)
         u32 tk2 = 0;  // the ticket drawn now (lane 0 of wave 0); it returns while phase A runs
-        if (tid == 0 && has_a) tk2 = tk_base + atomicAdd(&st->tile_counter, 1u);
+        if (tid == 0 && has_a) tk2 = tk_base + atomicAdd(&ctl->tile_counter, 1u);
         if (has_a) {
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_a, t_an, t_an < num_tiles, lane, wave, pf, s_mask[ma][wave],
-                                            s_pre[ma][wave], s_unit[ua], aux, kp, s_ucnt[AUX ? ua : 0], seen_st, wave == 0 && !first);
+                                            s_pre[ma][wave], s_unit[ua], aux, kp, s_ucnt[AUX ? ua : 0], seen_st, s_edge[wave], wave == 0 && !first);
             trace_put<TRACE>(aux.trace, t_a, WAVES, wave, lane, 1);
         }
         u32 *res = s_res2[j & 1u];
@@ -782,7 +769,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                     if (r == 1) break;
                     if (r == 0) __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {  // bounded: a bug must not hang the device
-                        if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
+                        if (lane == 0) report_error(ctl, aux, 0x80000000u);
                         break;
                     }
                     lookback_load(desc, lb.j, lane, win);
@@ -795,8 +782,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
                     res[1] = pm0;
                     res[2] = (u32)BASE;
                     res[3] = (u32)(BASE >> 32);
-                    if (t_prev == num_tiles - 1)
-                        __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t_prev == num_tiles - 1) {
+                        eiq_last = (G ^ P0) & 1u;
+                        __hip_atomic_store(&st->ends_in_quote, eiq_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 if (has_a) s_ticket[(j + 2u) & 3u] = tk2;
             }
@@ -815,8 +804,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
             err |= flatten_tile<BLOCK, CH, AUX>(tm, s_mask[mf][wave], s_kpl[AUX ? wave : 0], s_pre[mf][wave], s_unit[uf], pm, G, BASE, t_prev, lead, lane, wave,
                                            S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, AUX ? aux.unit_h : Arr<u8>(nullptr), len,
                                            AUX ? aux.kind : Arr<u8>(nullptr), aux, s_ucnt[AUX ? uf : 0]);
-            if (t_prev == num_tiles - 1 && tid == 0)
-                __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t_prev == num_tiles - 1 && tid == 0) report_total(st, aux, tile_end, eiq_last, base + lead, len);
             trace_put<TRACE>(aux.trace, t_prev, WAVES, wave, lane, 4);
             if (TRACE && lane == 0)
                 aux.trace[((u64)t_prev * WAVES + wave) * TRACE_WORDS + 5] =
@@ -833,15 +821,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel(const u8 *__restrict
         }
         t_prev = t_a;
     }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->err_acc, 1u);
+    if (__ballot(err) != 0 && lane == 0) report_error(ctl, aux, 1u);
     if (AUX && aux.want_flag) {  // (uniform over the grid)
-        // one look and at most one atomic per BLOCK (an atomicOr per wave -- 4096 of them on one word as the kernel ends -- cost
+        // one look and at most one store per BLOCK (an atomicOr per wave -- 4096 of them on one word as the kernel ends -- cost
         // configs[1] 31 us: a word takes ~88 atomics per microsecond)
         const int any_st = __syncthreads_or((int)seen_st);
-        if (any_st && tid == 0 && __hip_atomic_load(&st->starter_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-            __hip_atomic_store(&st->starter_acc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (any_st && tid == 0 && __hip_atomic_load(&ctl->has_starter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            __hip_atomic_store(&ctl->has_starter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    block_done(st, aux, base + lead, len, desc, num_tiles);
 }
 
 // ---- the same tile pipeline without block barriers, DEPTH tiles in flight per block ------------------------------
@@ -882,8 +869,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     __shared__ u32 s_resflag[4];    // j + 1 once s_res[j & 3] holds the result of T(j)
     __shared__ u64 s_mask[DEPTH][WAVES][CH * 2 * 64];
     __shared__ u32 s_pre[DEPTH][WAVES][CH * 64];
+    __shared__ __attribute__((aligned(16))) u8 s_edge[WAVES][64];  // unit_issue
 
     const int tid = threadIdx.x;
+    Stage1Ctrl *const ctl = &st->c[aux.par];
+    launch_clean(st, aux);
+    u32 eiq_last = 0;  // lane 0 of wave 0: the state at the end of the message (the block of the last tile)
     u64 kp[CH][4];  // (unused: plain stage 1)
     if (tid < 8) {
         s_arrive[tid] = 0;
@@ -895,34 +886,33 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
     const u64 end = lead + len;
 
     // prologue (two block barriers, once per block), as in the barrier kernel
-    if (tid == 0) s_tk[0] = atomicAdd(&st->tile_counter, 1u);
+    if (tid == 0) s_tk[0] = atomicAdd(&ctl->tile_counter, 1u);
     __syncthreads();
     const u32 t_first = uniform(s_tk[0]);
     if (t_first >= num_tiles) {
-        block_done(st, aux, base + lead, len, desc, num_tiles);
         return;
     }
     UnitRegs pf;
     {
         const u64 un = tile_unit<UNITS>(tm, t_first, wave);
-        if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
+        if (un != VOID_UNIT) unit_issue(base, lead, end, un, tm.nu, lane, pf, s_edge[wave]);
     }
     if (tid == 0) {
-        s_tk[1] = atomicAdd(&st->tile_counter, 1u);
-        s_tk[2] = atomicAdd(&st->tile_counter, 1u);
+        s_tk[1] = atomicAdd(&ctl->tile_counter, 1u);
+        s_tk[2] = atomicAdd(&ctl->tile_counter, 1u);
         s_tkn = 3;
     }
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 0);
     u32 seen_st_nb = 0;  // (this kernel never runs the whole parse: unused)
     phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, t_first, 0, false, lane, wave, pf, s_mask[0][wave], s_pre[0][wave], s_unit[0],
-                                    aux, kp, nullptr, seen_st_nb);
+                                    aux, kp, nullptr, seen_st_nb, s_edge[wave]);
     trace_put<TRACE>(aux.trace, t_first, WAVES, wave, lane, 1);
     __syncthreads();
     {
         const u32 t1 = uniform(s_tk[1]);
         if (t1 < num_tiles) {
             const u64 un = tile_unit<UNITS>(tm, t1, wave);
-            if (un != VOID_UNIT) unit_issue(base, end, un, lane, pf);
+            if (un != VOID_UNIT) unit_issue(base, lead, end, un, tm.nu, lane, pf, s_edge[wave]);
         }
     }
     if (wave == 0) {
@@ -947,7 +937,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             if (!wait) return false;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) {  // bounded: a bug must not hang the device
-                if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
+                if (lane == 0) report_error(ctl, aux, 0x80000000u);
                 break;
             }
         }
@@ -969,7 +959,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (++spins > (1u << 22)) {
-                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
+                    if (lane == 0) report_error(ctl, aux, 0x80000000u);
                     break;
                 }
                 lookback_load(desc, lb.j, lane, win);
@@ -982,7 +972,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             res[1] = pm0;
             res[2] = (u32)BASE;
             res[3] = (u32)(BASE >> 32);
-            if (tj == num_tiles - 1) __hip_atomic_store(&st->ends_in_quote, (G ^ P0) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tj == num_tiles - 1) {
+                eiq_last = (G ^ P0) & 1u;
+                __hip_atomic_store(&st->ends_in_quote, eiq_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __hip_atomic_store(&s_resflag[j & 3u], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         trace_put<TRACE>(aux.trace, tj, WAVES, wave, lane, 2);
@@ -998,7 +991,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             while (__hip_atomic_load(&s_tkn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 3u) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {
-                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
+                    if (lane == 0) report_error(ctl, aux, 0x80000000u);
                     break;
                 }
             }
@@ -1006,12 +999,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         const u32 ta = uniform(s_tk[(it + 1u) & 7u]), tn = uniform(s_tk[(it + 2u) & 7u]);
         const bool more = ta < num_tiles;
         u32 tk = 0xffffffffu;  // T(it+3): drawn now, it returns while phase A runs
-        if (more && tid == 0) tk = atomicAdd(&st->tile_counter, 1u);
+        if (more && tid == 0) tk = atomicAdd(&ctl->tile_counter, 1u);
         if (more) {
             const int ma = (int)((it + 1u) % (u32)DEPTH), ua = (int)((it + 1u) & 7u);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 0);
             phase_a<BLOCK, CH, NDJSON, AUX>(base, lead, end, tm, ta, tn, tn < num_tiles, lane, wave, pf, s_mask[ma][wave], s_pre[ma][wave],
-                                            s_unit[ua], aux, kp, nullptr, seen_st_nb, wave == 0);
+                                            s_unit[ua], aux, kp, nullptr, seen_st_nb, s_edge[wave], wave == 0);
             trace_put<TRACE>(aux.trace, ta, WAVES, wave, lane, 1);
             u32 arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[ua], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1049,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
             while (__hip_atomic_load(&s_resflag[f & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1u) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 24)) {
-                    if (lane == 0) atomicOr(&st->err_acc, 0x80000000u);
+                    if (lane == 0) report_error(ctl, aux, 0x80000000u);
                     break;
                 }
             }
@@ -1062,14 +1055,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void stage1_kernel_nb(const u8 *__restr
         u64 tile_end = 0;
         err |= flatten_tile<BLOCK, CH, false>(tm, s_mask[mf][wave], nullptr, s_pre[mf][wave], s_unit[uf], pm, G, BASE, tf, lead, lane,
                                               wave, S1_POS_VIEW(out_pos, pos_cap), pos_cap, tile_end, Arr<u8>(nullptr), len, Arr<u8>(nullptr), aux, nullptr);
-        if (tf == num_tiles - 1 && tid == 0) __hip_atomic_store(&st->total, tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tf == num_tiles - 1 && tid == 0) report_total(st, aux, tile_end, eiq_last, base + lead, len);
         trace_put<TRACE>(aux.trace, tf, WAVES, wave, lane, 4);
         if (TRACE && lane == 0)
             aux.trace[((u64)tf * WAVES + wave) * TRACE_WORDS + 5] =
                 (u64)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
-    if (__ballot(err) != 0 && lane == 0) atomicOr(&st->err_acc, 1u);
-    block_done(st, aux, base + lead, len, desc, num_tiles);
+    if (__ballot(err) != 0 && lane == 0) report_error(ctl, aux, 1u);
 }
 
 // ---- launcher --------------------------------------------------------------------------
@@ -1155,29 +1147,24 @@ static S1Plan s1_plan(size_t len, size_t lead) {
     return p;
 }
 
-// workspace: Stage1State | tile descriptors
+// workspace: Stage1State | descriptor set 0 | descriptor set 1 (each half of what is left; S1Ws in sj_device.h)
 size_t stage1_workspace_bytes(size_t len) {
     const size_t tiles = (len + 128) / (256 * 2 * 64) + 2 + 2048;  // smallest tile of any variant + one round of small tiles
-    return sizeof(Stage1State) + tiles * sizeof(u64);
+    return sizeof(Stage1State) + 2 * tiles * sizeof(u64) + 64;
+}
+static u64 *s1_desc_set(const S1Ws &ws, unsigned set) {
+    const size_t half = (ws.bytes - sizeof(Stage1State)) / 16;  // descriptors per set
+    return reinterpret_cast<u64 *>(reinterpret_cast<u8 *>(ws.p) + sizeof(Stage1State)) + (size_t)set * half;
 }
 
-// Zero the Stage1State and the tile descriptors of this message's plan.  A parse does not need it (a launch leaves the
-// workspace the way it found it, block_done; a fresh workspace is zeroed once by its owner): the timing and tracing entry
-// points call it so that each of their launches stands alone.
-hipError_t stage1_prepare(const void *d_msg, size_t len, void *ws, hipStream_t stream, void *zero2, size_t zero2_bytes) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
-    const u64 lead = a & 63;
-    const S1Plan plan = s1_plan(len, lead);
-    u8 *w = reinterpret_cast<u8 *>(ws);
-    u64 *desc = reinterpret_cast<u64 *>(w + sizeof(Stage1State));
-    // the state and the descriptors are not adjacent: two ranges, one kernel (state first: 8 words)
-    const u64 desc_words = plan.tiles;
-    const u64 zq = zero2 ? (u64)zero2_bytes / 16 : 0;  // (a multiple of 16 bytes, 16-byte aligned: stage2_zero_bytes)
-    const u64 work = (desc_words > zq / 4 ? desc_words : zq / 4);  // ~4 quads per thread
-    const u32 blocks = (u32)((work + 255) / 256 < 2 ? 2 : ((work + 255) / 256 > 256 ? 256 : (work + 255) / 256));
-    hipLaunchKernelGGL(k_s1_prepare, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<u64 *>(w), desc, desc_words,
-                       reinterpret_cast<uint4 *>(zero2), zq);
-    return hipGetLastError();
+// A workspace whose contents are unknown (just allocated), or a launch that is to stand alone (the timing and tracing entry
+// points): everything zero, epoch 0.  zero2 / zero2_bytes: a second region to zero, or null
+hipError_t stage1_prepare(S1Ws &ws, hipStream_t stream, void *zero2, size_t zero2_bytes) {
+    hipError_t e = hipMemsetAsync(ws.p, 0, ws.bytes, stream);
+    if (e == hipSuccess && zero2 && zero2_bytes) e = hipMemsetAsync(zero2, 0, zero2_bytes, stream);
+    ws.epoch = 0;
+    ws.prev_tiles = 0;
+    return e;
 }
 
 // words of trace a launch of the current variant writes (sjhip_stage1_trace): tiles x waves x TRACE_WORDS
@@ -1189,19 +1176,21 @@ size_t stage1_trace_words(size_t len, size_t lead, unsigned *tiles_out, int *wav
     return (size_t)tiles * (size_t)(v.block / 64) * TRACE_WORDS;
 }
 
-// d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be clean: zeroed once, then only used
-// by launches of this function, each of which has run to its end (sj_device.h Stage1State).
+// d_msg may be any device pointer; ws must hold stage1_workspace_bytes(len + 64) and be clean: zeroed once (stage1_prepare),
+// then only used by launches of this function in stream order (sj_device.h Stage1State, S1Ws).
 // d_trace (profiling only, plain stage 1 of a non-ND message): stage1_trace_words() zeroed u64.
-hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                                  hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *d_trace,
-                                  unsigned long long *h_state, void *zero2, size_t zero2_bytes) {
+hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, S1Ws &ws,
+                         hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
+                         size_t zero2_bytes, unsigned long long *d_trace) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_msg);
     const u8 *base = reinterpret_cast<const u8 *>(a & ~(uintptr_t)63);
     const u64 lead = a & 63;
     const S1Plan plan = s1_plan(len, lead);
     const u32 tiles = plan.tiles;
-    Stage1State *st = reinterpret_cast<Stage1State *>(ws);
-    u64 *desc = reinterpret_cast<u64 *>(st + 1);
+    Stage1State *st = reinterpret_cast<Stage1State *>(ws.p);
+    const unsigned par = ws.epoch & 1u;
+    u64 *desc = s1_desc_set(ws, par);
+    if ((size_t)tiles > (ws.bytes - sizeof(Stage1State)) / 16) return hipErrorInvalidValue;  // (the workspace is too small)
     if (tiles == 0) {  // (nothing is launched: the stage-2 state of an empty message is zeroed the plain way)
         return zero2 && zero2_bytes ? hipMemsetAsync(zero2, 0, zero2_bytes, stream) : hipSuccess;
     }
@@ -1213,6 +1202,11 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
     aux.trace = reinterpret_cast<u64 *>(d_trace);
     aux.host = h_state;
     aux.want_flag = (ndjson & S1_WANT_STARTER_FLAG) != 0;
+    aux.par = par;
+    aux.clean_desc = s1_desc_set(ws, par ^ 1u);
+    aux.clean_tiles = ws.prev_tiles;
+    ws.prev_tiles = tiles;
+    ws.epoch++;
     aux.zero2 = reinterpret_cast<uint4 *>(zero2);
     aux.zero2_quads = zero2 ? (u64)zero2_bytes / 16 : 0;  // (a multiple of 16 bytes, 16-byte aligned: stage2_zero_bytes)
 #if defined(SJ_EXP)
@@ -1271,14 +1265,6 @@ hipError_t stage1_launch_prepared(const void *d_msg, size_t len, int ndjson, u32
 #undef S1_LAUNCH_NB
 #undef S1_LAUNCHK
     return hipGetLastError();
-}
-
-// one launch: the workspace is clean (see stage1_launch_prepared), the kernel's last block zeroes zero2
-hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, size_t pos_cap, void *ws,
-                         hipStream_t stream, void *aux_buf, u8 *d_kind, unsigned long long *h_state, void *zero2,
-                         size_t zero2_bytes) {
-    return stage1_launch_prepared(d_msg, len, ndjson, d_pos, pos_cap, ws, stream, aux_buf, d_kind, nullptr, h_state, zero2,
-                                  zero2_bytes);
 }
 
 // debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): 1 and the record of the out-of-bounds accesses of the stage-1 kernels since the

@@ -2165,6 +2165,17 @@ hipError_t stage2_launch_pack(const S2Args &a, void *h_dst, size_t cap) {
     return hipGetLastError();
 }
 
+// ---- the 64-byte state to pinned host memory: one wave instead of a copy command (the runtime's blit kernel for 64 bytes
+// takes 4.2-4.4 us in every trace of the round; this one is a load, eight 8-byte stores and the end of a kernel) ----------
+__global__ __launch_bounds__(64) void k_state_out(const unsigned long long *st, unsigned long long *dst) {
+    if (threadIdx.x < sizeof(S2State) / 8)
+        __hip_atomic_store(&dst[threadIdx.x], st[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t stage2_launch_state_out(const S2Args &a, void *h_dst) {
+    hipLaunchKernelGGL(k_state_out, dim3(1), dim3(64), 0, a.stream, (const unsigned long long *)a.ws_zero, (unsigned long long *)h_dst);
+    return hipGetLastError();
+}
+
 // ---- debug build (-DSJ_DEBUG_BOUNDS, sj_bounds.h): the record of the first out-of-bounds access, read and cleared -------
 // returns 0 in the product build; 1 in the debug build with *hits = accesses that were out of bounds since the last call
 int stage2_debug_bounds(unsigned *hits, unsigned *id, unsigned long long *index, unsigned long long *size) {
