@@ -460,7 +460,9 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
         }
         m[(k * 2 + 0) * 64 + lane] = a;
         m[(k * 2 + 1) * 64 + lane] = b;
-        if (AUX && aux.qm && unit_off < end && !SJ_S1EXP(aux, 16)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
+        // (AUX: the mask arrays are there -- stage1_launch refuses kinds without them -- and a unit that is not void begins in
+        // front of `end`: no tests here, each one would be a branch in the middle of the pass)
+        if (AUX && !SJ_S1EXP(aux, 16)) {  // whole parse: stage 2 unescapes the strings from these masks (stage2.hip)
             const u64 ci = unit * 64 + (u64)lane;
             aux.qm[ci] = qm;  // relative to the state at the start of the unit: resolved with aux.unit_h
             aux.st[ci] = starters;
@@ -473,7 +475,7 @@ __device__ __forceinline__ void phase_a(const u8 *__restrict__ base, u64 lead, u
             // the fast formula; units with a \u escape are counted again by k_measure) and opening quotes of the unit under
             // hypothesis 0, and under either hypothesis together (the two sets are disjoint: the other one is the difference)
             uint2 tot = make_uint2(0u, 0u);
-            if (aux.unit_str && unit_off < end && !SJ_S1EXP(aux, 18)) {  // (uniform)
+            if (!SJ_S1EXP(aux, 18)) {
                 const u64 nqst = ~quote_bits & ~starters;
                 const u32 cnt = wave_incl_scan((u32)popc64(qm & nqst) | ((u32)popc64(nqst) << 16));
                 const u32 opn = wave_incl_scan((u32)popc64(qm & quote_bits) | ((u32)popc64(quote_bits) << 16));
@@ -558,7 +560,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         if (unit_h && lane == 0 && un * 4096 < lead + len_) {  // (a void unit lies behind everything)
             // bit 0: the state at the start of the unit; bit 1: the unit holds an escape starter; bit 2: it holds an unescaped quote
             unit_h[un] = (u8)(h | (((s_unit[k * WAVES + wave] >> 28) & 3u) << 1));
-            if (KIND && aux.unit_str) {  // whole parse: the unit's counts under the state that is now known
+            if (KIND) {  // whole parse: the unit's counts under the state that is now known
                 const uint2 c = s_ucnt[k * WAVES + wave];
                 aux.unit_cnt[un] = h ? (c.x >> 16) - (c.x & 0xffffu) : c.x & 0xffffu;
                 aux.unit_str[un] = h ? (c.y >> 16) - (c.y & 0xffffu) : c.y & 0xffffu;
@@ -572,7 +574,7 @@ __device__ __forceinline__ bool flatten_tile(TileMap tm, u64 *m, const u64 *kpl,
         else __builtin_amdgcn_s_setprio(1);
         const u32 C = (u32)__builtin_amdgcn_readlane((int)cl, u);
         const u64 g = BASE + ((u32)__builtin_amdgcn_readlane((int)incl, u) - C);
-        if (KIND && aux.tile_unit && lane == 0 && C != 0) {  // (a unit holds at most 4096 tokens: at most one 4096-token tile begins in it)
+        if (KIND && lane == 0 && C != 0) {  // (a unit holds at most 4096 tokens: at most one 4096-token tile begins in it)
             const u64 T = (g + 4095) >> 12;
             if (T * 4096 < g + C) aux.tile_unit[T] = (u32)tile_unit<UNITS>(tm, t, u);
         }
@@ -1212,6 +1214,7 @@ hipError_t stage1_launch(const void *d_msg, size_t len, int ndjson, u32 *d_pos, 
 #if defined(SJ_EXP)
     if (const char *e = getenv("SJHIP_EXP")) aux.exp = (u32)strtoul(e, nullptr, 0);
 #endif
+    if ((d_kind != nullptr) != (aux_buf != nullptr)) return hipErrorInvalidValue;  // (the whole-parse kernel writes kinds AND masks: no tests on the device)
     if (aux_buf) {
         const StrAux a = str_aux_layout(aux_buf, (size_t)lead + len);
         aux.qm = SJ_ARR(a.qm, a.chunks, A_S1_QM);

@@ -813,3 +813,68 @@ def test_large_documents_of_changing_density():
             pj = c.parse(doc, ndjson=is_nd, copy_strings=copy)
             assert ref.rc == 0 and np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), (len(doc), copy)
     c.close()
+
+
+def test_launches_follow_each_other_without_a_preparation_kernel():
+    """Round 6: a stage-1 launch has nothing in front of it -- every launch zeroes the control slot and the tile descriptors
+    the launch BEFORE it used (csrc/sj_device.h Stage1State), and the first / last 4 KiB unit are assembled by the wave that
+    loads them.  One context, launches of very different sizes and outcomes in a row (more tiles than the one before, fewer,
+    an error, stage 1 alone, the timing entry point, a growing workspace, odd alignments of both message ends): every result
+    must be the oracle's whatever ran before it."""
+    import sjhip
+    import torch
+    c = sjhip.Context(0)
+    small = fixtures.load("twitter")
+    big = workloads.c2_twitter_array(48)          # ~30 MB: several rounds of tiles
+    mid = fixtures.load("parking-citations") * 9   # ND, a few MB
+    bad = small[:40000] + b'"\x01"' + small[40000:]          # a control character inside a string: stage-1 error
+    open_str = small[:len(small) - 3]                         # ends inside ... something: not a document
+    seq = [(small, False), (big, False), (small, False), (bad, False), (small, False), (mid, True), (open_str, False),
+           (b"[]", False), (big, False), (b'{"a":"b\\n"}', False), (mid, True)]
+    refs = {}
+    for rep in range(2):
+        for data, nd in seq:
+            for copy in (True, False):
+                key = (id(data), nd, copy)
+                if key not in refs:
+                    refs[key] = O.parse(data, ndjson=nd, copy_strings=copy)
+                ref = refs[key]
+                rc, pj = gpu_parse(c, data, nd, copy)
+                assert rc == ref.rc, (len(data), nd, copy, rc, ref.rc)
+                if rc == 0:
+                    assert np.array_equal(pj.Tape, ref.tape) and np.array_equal(pj.Strings, ref.strings), (len(data), nd, copy)
+            # stage 1 alone in between (its own launch on the same workspace), then the timing entry point
+            ok, pos = c.stage1(data, ndjson=nd)
+            ok_ref, pos_ref = O.stage1(data, ndjson=nd)
+            assert ok == ok_ref and (not ok or np.array_equal(pos, pos_ref)), (len(data), nd)
+        d = torch.empty(len(big) + 4096, dtype=torch.uint8, device="cuda:0")
+        p = torch.empty(len(big) // 4 + 4096, dtype=torch.int32, device="cuda:0")
+        ok_ref, pos_ref = O.stage1(big)
+        for lead in (0, 1, 63):  # the message's first byte anywhere in its 64-byte line; its last one wherever that puts it
+            d[lead:lead + len(big)].copy_(torch.frombuffer(bytearray(big), dtype=torch.uint8))
+            torch.cuda.synchronize()
+            assert c.stage1_time(d.data_ptr() + lead, len(big), p.data_ptr(), p.numel(), 3) > 0
+            ok, n = c.stage1_device(d.data_ptr() + lead, len(big), p.data_ptr(), p.numel())
+            assert ok == ok_ref and n == len(pos_ref)
+            assert np.array_equal(p[:n].cpu().numpy().view(np.uint32), pos_ref)
+        if rep == 0:
+            c.trim()  # a fresh workspace in the middle of the sequence
+    # short messages at every alignment and length around the chunk and unit sizes: both ends of the message in one chunk, in
+    # neighbouring chunks, the last byte on the last byte of a unit
+    d = torch.empty(3 * 4096 + 256, dtype=torch.uint8, device="cuda:0")
+    p = torch.empty(3 * 4096 + 256, dtype=torch.int32, device="cuda:0")
+    for n_items in (1, 7, 9, 10, 400, 578, 579, 580, 1160):
+        doc = b"[" + b",".join(b'"a\\"%d"' % (k % 10) for k in range(n_items)) + b"]"
+        ok_ref, pos_ref = O.stage1(doc)
+        for lead in (0, 3, 60, 63):
+            d.fill_(0x22)  # quotes all around the message: a byte taken from outside it would change the result
+            d[lead:lead + len(doc)].copy_(torch.frombuffer(bytearray(doc), dtype=torch.uint8))
+            torch.cuda.synchronize()
+            ok, n = c.stage1_device(d.data_ptr() + lead, len(doc), p.data_ptr(), p.numel())
+            assert ok == ok_ref and n == len(pos_ref), (n_items, lead)
+            assert np.array_equal(p[:n].cpu().numpy().view(np.uint32), pos_ref), (n_items, lead)
+            ref = O.parse(doc)
+            tl, sl = c.parse_device(d.data_ptr() + lead, len(doc))
+            tape, strings = c.fetch(tl, sl)
+            assert np.array_equal(tape, ref.tape) and np.array_equal(strings, ref.strings), (n_items, lead)
+    c.close()
