@@ -6,8 +6,8 @@ import sys
 con = sqlite3.connect(sys.argv[1])
 want = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-# a chain begins with the preparation kernel of stage 1
-starts = [i for i, r in enumerate(rows) if "k_s1_prepare" in r[0]]
+# a chain begins with stage 1 (until the middle of round 6: with its preparation kernel)
+starts = [i for i, r in enumerate(rows) if "k_s1_prepare" in r[0]] or [i for i, r in enumerate(rows) if "stage1_kernel" in r[0]]
 for ci in starts[-want:]:
     nxt = [s for s in starts if s > ci]
     chain = rows[ci:(nxt[0] if nxt else len(rows))]
