@@ -654,8 +654,10 @@ __device__ __forceinline__ void str_emit_body(const S2Dev &p) {
     s_esc[threadIdx.x] = c_esc.v[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the unit's scalars stay in SGPRs)
     const bool NE = SEL && no_escapes(p);  // nothing is copied: the strings are only numbered (offsets of the full compaction in soff[])
-    const u64 nwaves = (u64)gridDim.x * 4;
-    u64 unit = (u64)blockIdx.x * 4 + wave;
+    // (SJ_EXP bit 20: the units from the last to the first; every comparison below is on u64 and a unit in front of 0 is "behind the end")
+    const bool REV = SJ_EXPBIT(p, 20);
+    const u64 nwaves = REV ? (u64)0 - (u64)gridDim.x * 4 : (u64)gridDim.x * 4;
+    u64 unit = REV ? p.units - 1 - ((u64)blockIdx.x * 4 + wave) : (u64)blockIdx.x * 4 + wave;
     struct Raw {   // what is requested two units ahead
         u64 qm, st;          // the masks of the lane's chunk
         u32 stp_hi;          // ... and the upper half of st of the chunk in front (bit 31: its last byte starts an escape)
@@ -1299,10 +1301,12 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 n = token_count(p);
     if ((u64)blockIdx.x * S2_TILE >= n) return;  // (the grid is sized for the upper bound)
-    const u32 t0 = blockIdx.x * S2_TILE;
+    // (SJ_EXP bit 21: the tiles from the last to the first -- the order of a sweep decides what the Infinity Cache still holds of the sweep in front)
+    const u32 bid = SJ_EXPBIT(p, 21) ? (u32)(((u64)n + S2_TILE - 1) / S2_TILE) - 1u - blockIdx.x : blockIdx.x;
+    const u32 t0 = bid * S2_TILE;
     const u64 tape_len = p.st->tape_len;
     if (tape_len > p.tape_cap) return;  // cannot happen: the launcher sizes the tape for 2n+2 words
-    const Agg tp = p.agg[blockIdx.x].a;  // prefix of the tile (needed behind the scan: requested first)
+    const Agg tp = p.agg[bid].a;  // prefix of the tile (needed behind the scan: requested first)
     // The positions are 32 bits wide: in a message of more than 4 GiB they are the true offsets modulo 2^32.  A tile keeps them
     // relative to the true offset of its first token -- which follows from the unit that token lies in (stage 1's tile_unit) --
     // and adds the 64-bit base where a byte of the message is addressed (tokens of a tile less than 4 GiB apart: else the parse fails)
@@ -1311,12 +1315,12 @@ __global__ __launch_bounds__(S2_TILE / ITEMS, ITEMS == 8 ? 8 : 4) void k_s2_emit
     u64 tbase = 0;
     if (MASKS && WIDE) {
         const u32 first = p.pos[t0];
-        tbase = (u64)p.tile_unit[blockIdx.x] * 4096u + (((u64)first + p.sv.lead) & 4095u) - p.sv.lead;
+        tbase = (u64)p.tile_unit[bid] * 4096u + (((u64)first + p.sv.lead) & 4095u) - p.sv.lead;
     }
     const u32 endpos = (u32)(p.len - tbase);
     if (MASKS && WIDE && tid == 0) {  // the tile's offsets are 32-bit differences from its first token: a tile that spans 4 GiB or more cannot be rebuilt
         const u64 nb = (u64)t0 + S2_TILE < n
-                           ? (u64)p.tile_unit[blockIdx.x + 1] * 4096u + (((u64)p.pos[t0 + S2_TILE] + p.sv.lead) & 4095u) - p.sv.lead
+                           ? (u64)p.tile_unit[bid + 1] * 4096u + (((u64)p.pos[t0 + S2_TILE] + p.sv.lead) & 4095u) - p.sv.lead
                            : p.len;
         if (nb - tbase >= (1ull << 32)) atomicOr(&p.st->err, 4u);
     }

@@ -41,7 +41,7 @@ def main(summary, out_k, out_p):
             continue
         per_parse = {}
         calls = [v["calls"] for v in kern[wl].values()]
-        parses = max(1, min(c for c in calls if c > 0)) if calls else 1
+        parses = max(calls) if calls else 1  # one launch of each parse kernel per parse (a context's first-use fills run less often)
         for k, v in kern[wl].items():
             per_parse[k] = round(v["avg_us"] * v["calls"] / parses, 1)
         kern[wl] = {"parses_traced": parses, "us_per_parse": dict(sorted(per_parse.items(), key=lambda kv: -kv[1])),
