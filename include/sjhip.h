@@ -293,6 +293,18 @@ int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uin
 /* device-resident variant: d_pos must hold pos_cap uint32; nothing is copied back but the counts */
 int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,
                         size_t pos_cap, size_t *n, int *ok);
+/* Queued form of sjhip_stage1_device for a caller that keeps several messages (or blocks of a stream) in flight, as
+ * ParseNDStream's reader does with its 10 MB blocks (simdjson_amd64.go:127-215: the next block is read and indexed while the
+ * previous one is parsed): _queue launches behind what is already on the context's stream and returns at once; the launch
+ * leaves count, end state and error bits in record `slot` (0 .. SJHIP_STAGE1_QUEUE_SLOTS-1) of the context's pinned host
+ * memory.  _wait synchronises with the stream; _result turns a record into (*n, *ok) exactly like sjhip_stage1_device and must
+ * only be called for a slot whose launch _wait has covered (else SJHIP_ERR_HIP "left no result").  A slot is free again once
+ * its result has been taken.  d_msg / d_pos of a queued launch must stay untouched until then. */
+#define SJHIP_STAGE1_QUEUE_SLOTS 64
+int sjhip_stage1_device_queue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,
+                              size_t pos_cap, int slot);
+int sjhip_stage1_device_wait(sjhip_ctx *ctx);
+int sjhip_stage1_device_result(sjhip_ctx *ctx, int slot, size_t len, size_t *n, int *ok);
 /* launches the stage-1 kernel `iters` times back to back on the context's stream and returns the
  * average kernel duration in milliseconds measured with hipEvents on that stream */
 int sjhip_stage1_time(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos,

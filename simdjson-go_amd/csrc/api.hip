@@ -223,7 +223,8 @@ static int stage1_workspace_clean(sjhip_ctx *ctx) {
 }
 
 int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                       uint8_t *d_kind, void *zero2, size_t zero2_bytes) {
+                       uint8_t *d_kind, void *zero2, size_t zero2_bytes, unsigned long long *host_rec) {
+    if (!host_rec) host_rec = (unsigned long long *)ctx->h_scratch;
     // (plain stage 1 hands out 32-bit positions: up to 4 GiB - 64; the whole parse -- str_aux -- lets them wrap, parse_api.hip)
     if (len >= 0xffffffc0ull && !str_aux) {
         ctx_set_error(ctx, "message too long for uint32 positions");
@@ -235,27 +236,29 @@ int sj::stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson
     rc = stage1_workspace_clean(ctx);
     if (rc) return rc;
     if (len > 0) {
-        for (int k = 0; k < S1_HOST_WORDS; k++) ((volatile unsigned long long *)ctx->h_scratch)[k] = 0;
+        for (int k = 0; k < S1_HOST_WORDS; k++) ((volatile unsigned long long *)host_rec)[k] = 0;
         ctx->s1_par = ctx->s1ws.epoch & 1u;
         HIPCHK(stage1_launch(d_msg, len, ndjson, (uint32_t *)d_pos, pos_cap, ctx->s1ws, ctx->stream, str_aux, d_kind,
-                             (unsigned long long *)ctx->h_scratch, zero2, zero2_bytes),
+                             host_rec, zero2, zero2_bytes),
                "stage1 launch");
     }
     return SJHIP_OK;
 }
 
-int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok) {
+int sj::stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok,
+                       const unsigned long long *host_rec) {
+    if (!host_rec) host_rec = (const unsigned long long *)ctx->h_scratch;
     Stage1State hs_v;
     Stage1State *hs = &hs_v;
     memset(hs, 0, sizeof *hs);
     if (len > 0) {
-        const unsigned long long word = *(volatile unsigned long long *)ctx->h_scratch;
+        const unsigned long long word = *(const volatile unsigned long long *)host_rec;
         if (!(word & S1_HOST_VALID)) {
             ctx_set_error(ctx, "stage-1 kernel left no result");
             return SJHIP_ERR_HIP;
         }
         hs->total = word & S1_HOST_TOTAL_MASK;
-        const volatile unsigned long long *hw = (const volatile unsigned long long *)ctx->h_scratch;
+        const volatile unsigned long long *hw = (const volatile unsigned long long *)host_rec;
         hs->error = (hw[1] ? 1u : 0u) | (hw[2] ? 0x80000000u : 0u);
         hs->ends_in_quote = (word & S1_HOST_IN_QUOTE) ? 1u : 0u;
         hs->last_byte = (uint32_t)((word >> S1_HOST_LAST_SHIFT) & 0xffu);
@@ -294,6 +297,33 @@ int sjhip_stage1_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjso
     if (!ctx || !n || !ok) return SJHIP_ERR_ARG;
     invalidate_result(ctx);
     return stage1_run_device(ctx, d_msg, len, ndjson != 0, d_pos, pos_cap, 0, 0, n, ok);
+}
+
+// Queued form: launches behind one another on the context's stream, no synchronisation of their own; every launch has its
+// own record in pinned host memory (the upper half of h_scratch: SJHIP_STAGE1_QUEUE_SLOTS records of 32 bytes).
+static inline unsigned long long *s1q_record(sjhip_ctx *ctx, int slot) {
+    return (unsigned long long *)(ctx->h_scratch + 2048 + (size_t)slot * 32);
+}
+int sjhip_stage1_device_queue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, int slot) {
+    if (!ctx || slot < 0 || slot >= SJHIP_STAGE1_QUEUE_SLOTS) return SJHIP_ERR_ARG;
+    static_assert(SJHIP_STAGE1_QUEUE_SLOTS * 32 <= 2048 && S1_HOST_WORDS * 8 <= 32, "the records fill the upper half of h_scratch");
+    invalidate_result(ctx);
+    if (len == 0) {  // (no launch: the record says so)
+        unsigned long long *r = s1q_record(ctx, slot);
+        r[0] = r[1] = r[2] = 0;
+        return SJHIP_OK;
+    }
+    return stage1_enqueue(ctx, d_msg, len, ndjson != 0, d_pos, pos_cap, nullptr, nullptr, nullptr, 0, s1q_record(ctx, slot));
+}
+int sjhip_stage1_device_wait(sjhip_ctx *ctx) {
+    if (!ctx) return SJHIP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stage1 sync");
+    return SJHIP_OK;
+}
+int sjhip_stage1_device_result(sjhip_ctx *ctx, int slot, size_t len, size_t *n, int *ok) {
+    if (!ctx || !n || !ok || slot < 0 || slot >= SJHIP_STAGE1_QUEUE_SLOTS) return SJHIP_ERR_ARG;
+    return stage1_collect(ctx, len, 0, 0, n, ok, s1q_record(ctx, slot));
 }
 
 int sjhip_stage1(sjhip_ctx *ctx, const uint8_t *msg, size_t len, int ndjson, uint32_t *pos_out, size_t pos_cap,

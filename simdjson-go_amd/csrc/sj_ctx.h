@@ -97,8 +97,10 @@ size_t nd_big_device_bytes(const sjhip_ctx *ctx);  // arenas of the shard contex
 int nd_big_shards(const sjhip_ctx *ctx);
 sjhip_ctx *nd_big_shard(const sjhip_ctx *ctx, int k);
 int stage1_enqueue(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap, void *str_aux,
-                   uint8_t *d_kind, void *zero2, size_t zero2_bytes);
-int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok);
+                   uint8_t *d_kind, void *zero2, size_t zero2_bytes, unsigned long long *host_rec = nullptr);
+// host_rec: the launch's record in pinned host memory (S1_HOST_WORDS words; null: the context's own at h_scratch)
+int stage1_collect(sjhip_ctx *ctx, size_t len, uint8_t last_byte, int have_last, size_t *n, int *ok,
+                   const unsigned long long *host_rec = nullptr);
 int stage1_run_device(sjhip_ctx *ctx, const void *d_msg, size_t len, int ndjson, void *d_pos, size_t pos_cap,
                       uint8_t last_byte, int have_last, size_t *n, int *ok, void *str_aux = nullptr, uint8_t *d_kind = nullptr,
                       void *zero2 = nullptr, size_t zero2_bytes = 0);

@@ -49,6 +49,9 @@ SYMBOLS = {
     "sjhip_stage1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, intp]),
     "sjhip_stage1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp,
                                       intp]),
+    "sjhip_stage1_device_queue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int]),
+    "sjhip_stage1_device_wait": (C.c_int, [C.c_void_p]),
+    "sjhip_stage1_device_result": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, szp, intp]),
     "sjhip_stage1_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_float)]),
     "sjhip_count_where": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u64p]),

@@ -118,6 +118,23 @@ class Context:
         self._check(rc)
         return bool(ok.value), n.value
 
+    STAGE1_QUEUE_SLOTS = 64
+
+    def stage1_queue(self, d_msg_ptr, length, d_pos_ptr, pos_cap, slot, ndjson=False):
+        """sjhip_stage1_device without the synchronisation: the launch goes behind what the stream holds; its result is
+        taken with stage1_result(slot, length) after stage1_wait()."""
+        self._check(_lib.lib().sjhip_stage1_device_queue(self._h, C.c_void_p(d_msg_ptr), length, int(ndjson),
+                                                         C.c_void_p(d_pos_ptr), pos_cap, int(slot)))
+
+    def stage1_wait(self):
+        self._check(_lib.lib().sjhip_stage1_device_wait(self._h))
+
+    def stage1_result(self, slot, length):
+        n = C.c_size_t(0)
+        ok = C.c_int(0)
+        self._check(_lib.lib().sjhip_stage1_device_result(self._h, int(slot), length, C.byref(n), C.byref(ok)))
+        return bool(ok.value), n.value
+
     def stage1_time(self, d_msg_ptr, length, d_pos_ptr, pos_cap, iters, ndjson=False):
         ms = C.c_float(0)
         rc = _lib.lib().sjhip_stage1_time(self._h, C.c_void_p(d_msg_ptr), length, int(ndjson), C.c_void_p(d_pos_ptr),

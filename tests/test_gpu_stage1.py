@@ -240,3 +240,36 @@ def test_unaligned_device_pointer_and_full_size_property(ctx):
         k = 300
         assert np.array_equal(p[1 + k * per: 1 + k * per + 55263].astype(np.int64), first + k * tw)
         del dev, pos
+
+
+def test_queued_launches_keep_their_own_results(ctx):
+    """sjhip_stage1_device_queue / _wait / _result: launches of different messages (valid, rejected by stage 1, ending
+    inside a string, empty) behind one another without a synchronisation in between; every slot's count and verdict
+    are the oracle's and the positions of every message are intact afterwards (each launch has its own buffers)."""
+    import torch
+    tw = fixtures.load("twitter")
+    docs = [workloads.c2_twitter_array(3), b'{"a":"\x01"}', tw, b'{"open":"never closed', b"", b'[1,2,3]',
+            workloads.c5_parking_nd(40).rstrip(b"\n"), b'{"k":[true,false,null]}', tw * 2]  # (TrimSpace'd, like every message of the API)
+    nd = [False, False, False, False, False, False, True, False, False]
+    bufs = []
+    for d in docs:
+        dev = torch.empty(len(d) + 256, dtype=torch.uint8, device="cuda:0")
+        if d:
+            dev[:len(d)].copy_(torch.frombuffer(bytearray(d), dtype=torch.uint8))
+        bufs.append((dev, torch.empty(len(d) + 64, dtype=torch.int32, device="cuda:0")))
+    torch.cuda.synchronize()
+    for rounds in range(2):  # (a slot is free again once its result has been taken)
+        order = list(range(len(docs))) if rounds == 0 else list(reversed(range(len(docs))))
+        for slot, i in enumerate(order):
+            ctx.stage1_queue(bufs[i][0].data_ptr(), len(docs[i]), bufs[i][1].data_ptr(), bufs[i][1].numel(), slot, ndjson=nd[i])
+        ctx.stage1_wait()
+        for slot, i in enumerate(order):
+            ok, n = ctx.stage1_result(slot, len(docs[i]))
+            ok_ref, pos_ref = O.stage1(docs[i], nd[i])
+            assert ok == ok_ref, (rounds, i)
+            if ok_ref:
+                assert n == len(pos_ref), (rounds, i)
+                got = bufs[i][1][:n].cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, pos_ref), (rounds, i)
+    with pytest.raises(Exception):
+        ctx.stage1_queue(bufs[0][0].data_ptr(), len(docs[0]), bufs[0][1].data_ptr(), bufs[0][1].numel(), 64)
