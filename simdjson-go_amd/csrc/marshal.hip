@@ -63,7 +63,13 @@ struct MsView {
     unsigned long long *desc;
     u32 *ticket;
     u64 text_cap;
+    u32 exp;  // SJ_EXP builds only (SJHIP_MS_EXP): parts of k_ms_tile to leave out (A/B timing; the text is wrong)
 };
+#if defined(SJ_EXP)
+#define MS_EXPBIT(p, b) ((((p).exp >> (b)) & 1u) != 0)
+#else
+#define MS_EXPBIT(p, b) false
+#endif
 
 struct KeyView {
     const u8 *kind;  // [n] token kinds (stage 1)
@@ -90,7 +96,8 @@ __device__ __forceinline__ const u8 *ms_string(const MsView &p, bool inbuf, u64 
 
 // e: queue entry of a string (its ordinal inside the tile in bits 11..20), at: its tape index
 __device__ __forceinline__ bool entry_is_key(const MsView &p, u64 key_base, u32 e, u64 at) {
-    return (p.kf_tape ? p.kf_tape[at >> 1] : p.keyflag[key_base + ((e >> 11) & 0x3ffu)]) != 0;
+    (void)at;
+    return p.kf_tape ? ((e >> 29) & 1u) != 0 : p.keyflag[key_base + ((e >> 11) & 0x3ffu)] != 0;
 }
 
 // escapeBytes: bytes below 0x20, '"' and '\\' are escaped (shouldEscape, parsed_json.go:1171-1186)
@@ -223,6 +230,7 @@ __device__ __forceinline__ u64 str_load8(const u8 *s, u64 k, u64 len, const u8 *
         memcpy(&w, s + k, 8);
     } else {
         w = 0;
+#pragma unroll 1
         for (u32 j = 0; j < 8 && s + k + j < lim; j++) w |= (u64)s[k + j] << (8 * j);
     }
     const u64 rem = len - k;
@@ -232,6 +240,12 @@ __device__ __forceinline__ u64 str_load8(const u8 *s, u64 k, u64 len, const u8 *
     }
     return w;
 }
+// (the same padding for a word that comes from elsewhere: `rem` bytes of it belong to the string)
+__device__ __forceinline__ u64 pad_a(u64 w, u64 rem) {
+    if (rem >= 8) return w;
+    const u64 keep = (1ull << (8 * rem)) - 1;
+    return (w & keep) | (0x6161616161616161ull & ~keep);
+}
 // escaped size of the (up to) eight valid bytes of such a word
 __device__ __forceinline__ u32 esc_size8(u64 w, u32 valid) {
     const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
@@ -239,6 +253,7 @@ __device__ __forceinline__ u32 esc_size8(u64 w, u32 valid) {
     const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);  // '"' '\\'
     if ((ctl | q) == 0) return valid;
     u32 n = 0;
+#pragma unroll 1  // (the rare path: one copy of the loop body per call site -- the kernel is larger than the instruction cache as it is)
     for (u32 j = 0; j < valid; j++) n += escaped_size((u8)(w >> (8 * j)));
     return n;
 }
@@ -250,16 +265,70 @@ __device__ __forceinline__ u8 *write_esc8(u8 *o, u64 w, u32 valid) {
         for (u32 j = 0; j < valid; j++) o[j] = (u8)(w >> (8 * j));  // (the destination has no alignment: byte stores)
         return o + valid;
     }
+#pragma unroll 1
     for (u32 j = 0; j < valid; j++) o = write_escaped_byte(o, (u8)(w >> (8 * j)));
     return o;
 }
+
+// ---- text into the LDS window eight bytes at a time (round 6) ------------------------------------------------------------
+// The window is zeroed when the block starts and a string's text -- quote, bytes, quote, separator -- is shifted together in
+// a 64-bit accumulator that is ORed into the window slot by slot with ALIGNED 8-byte LDS atomics (ds_or_b64; the neighbours'
+// bytes of a shared slot are zeros in this lane's word): one LDS operation per eight bytes of text instead of one byte store
+// -- and a shift, an address and a trip of a data-dependent loop -- per byte (the byte loop was 0.31 of configs[4]'s 1.30 ms,
+// gpurun_out/r6m_exp.txt).  Plain byte stores of other entries into the same slots mix freely with the atomics: the LDS
+// executes both one operation at a time.  A word with a byte to escape leaves through the byte path (acc_flush, write_esc8,
+// acc_init behind it).
+struct TextAcc {
+    u64 v;                     // bytes not yet in the window, at their place inside the slot
+    u32 n;                     // of them (plus the bytes in front of the entry in the first slot): 0..7
+    unsigned long long *slot;  // the aligned slot they belong to
+};
+__device__ __forceinline__ void acc_init(TextAcc &a, u8 *win, u32 off) {
+    a.slot = reinterpret_cast<unsigned long long *>(win + (off & ~7u));
+    a.n = off & 7u;
+    a.v = 0;
+}
+// the low m bytes of x (1 <= m <= 8; the bytes above them are zero)
+__device__ __forceinline__ void acc_push(TextAcc &a, u64 x, u32 m) {
+    a.v |= x << (8u * a.n);
+    const u32 t = a.n + m;
+    if (t >= 8u) {
+        atomicOr(a.slot, (unsigned long long)a.v);
+        a.slot++;
+        a.v = a.n ? x >> (8u * (8u - a.n)) : 0ull;
+        a.n = t - 8u;
+    } else {
+        a.n = t;
+    }
+}
+__device__ __forceinline__ void acc_flush(TextAcc &a) {
+    if (a.v) atomicOr(a.slot, (unsigned long long)a.v);
+    a.v = 0;
+}
+__device__ __forceinline__ u32 acc_offset(const TextAcc &a, const u8 *win) {  // window offset of the next byte
+    return (u32)(reinterpret_cast<const u8 *>(a.slot) - win) + a.n;
+}
+__device__ __forceinline__ bool word_is_clean(u64 w) {  // no byte of w is escaped in the text (bytes behind a string's end read as 'a')
+    const u64 lo = (w & 0x7f7f7f7f7f7f7f7full);
+    const u64 ctl = ~((lo + 0x6060606060606060ull) | w) & 0x8080808080808080ull;
+    const u64 q = zero_bytes(w ^ 0x2222222222222222ull) | zero_bytes(w ^ 0x5c5c5c5c5c5c5c5cull);
+    return (ctl | q) == 0;
+}
+__device__ __forceinline__ u64 low_bytes(u64 w, u32 valid) { return valid >= 8u ? w : w & ((1ull << (8u * valid)) - 1ull); }
 
 // WPE: waves per SIMD the register allocation aims at (launch bound), WINDOW: bytes of text a tile stages in LDS
 // MODE 0: the counting pass (per-tile sizes; escaped lengths of the strings kept in slen), MODE 1: the writing pass of that
 // pair (sizes scanned by k_ms_scan in between), MODE 2: both in ONE pass -- a tile measures, publishes its size in a
 // descriptor, takes the sum of the tiles in front of it from their descriptors (decoupled look-back, tiles numbered by a
 // ticket so that every predecessor is running or done) and writes; the text buffer is sized by a bound (ms_text_bound).
-template <int MODE, int WPE, u32 WINDOW>
+// STAGE (round 6): bytes of Strings.B a tile reads into LDS with coalesced 16-byte loads before it looks at its short strings --
+// the strings of a tile lie side by side there (every string copied, in tape order), ~6.6 KB per tile on configs[4].  A thread
+// fetching the first sixteen bytes of ITS strings from memory is a gather of 64 different cache lines per load instruction: the
+// texture addresser works through them one line at a time, and those gathers alone were 0.24 of configs[4]'s 1.21 ms
+// (gpurun_out/r6m_exp.txt: 1.045 -> 0.806 without them, everything else in place).  From LDS the same sixteen bytes are three
+// aligned 8-byte reads and two funnel shifts.  A string outside the staged range (a long stretch, a string in the message) is
+// read from memory as before.
+template <int MODE, int WPE, u32 WINDOW, u32 STAGE = 0>
 __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     constexpr bool EMIT = MODE != 0, ONEPASS = MODE == 2;
     __shared__ long long s_l[TW_THREADS / 64];
@@ -270,6 +339,8 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     __shared__ u64 s_qs[MS_QCAP];
     __shared__ uint16_t s_qn[MS_QCAP];  // numbers: integers from the front, floats from the back; idx | sep << 11 (12 bits)
     __shared__ __attribute__((aligned(16))) u8 s_text[EMIT ? WINDOW : 16];
+    __shared__ __attribute__((aligned(16))) u8 s_str[STAGE ? STAGE + 32 : 16];
+    __shared__ u32 s_lo;  // STAGE: the lowest Strings.B offset among the tile's short strings
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ u32 s_tile;
     if (ONEPASS) {
@@ -306,6 +377,11 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     // 1.75 ms, configs[1] 1.32 instead of 1.34, tools/gpu_ab_marshal.sh.)
     __shared__ u32 s_cnt[4];         // short strings, long strings, integers, floats
     if (tid < 4) s_cnt[tid] = 0;
+    if (STAGE && tid == 4) s_lo = 0xffffffffu;
+    if (EMIT) {  // the window starts as zeros (TextAcc); the barriers of the scans below lie between this and the first byte of text
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (u32 i = (u32)tid; i < WINDOW / 16; i += TW_THREADS) reinterpret_cast<uint4 *>(s_text)[i] = z;
+    }
     long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0)
     if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
         if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
@@ -341,6 +417,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     unsigned long long tot_s = 0;
     u32 ord = (u32)block_excl_sum(nstr, s_s, tid, &tot_s);  // ordinal of the thread's first string inside the tile
     const u64 slen_base = (u64)tile * MS_QCAP;
+    u32 my_lo = 0xffffffffu;  // STAGE: the lowest Strings.B offset among this thread's short strings
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++) {
         const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
@@ -353,7 +430,11 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 const u64 vr = w[k] & TW_PAYLOAD;
                 const u64 inbuf = (vr & STRINGBUFBIT) ? 1u : 0u;
                 const u64 v = inbuf ? (vr & ~STRINGBUFBIT) - p.strings_base : vr - p.msg_base;  // (inside this context's buffers)
-                s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) |
+                // (the key flag of the parser rides in the entry: read here, neighbouring threads read neighbouring bytes; read
+                // when the string is written it was one more gather per string)
+                const u64 key = p.kf_tape ? (p.kf_tape[(tb + idx) >> 1] != 0 ? 1ull : 0ull) : 0ull;
+                if (STAGE && inbuf && !lng && (u32)v < my_lo) my_lo = (u32)v;
+                s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) | (key << 29) |
                              (v << 32);
                 l = 2 + sep + (MODE == 1 ? p.slen[slen_base + ord] : 0u);
                 ord++;
@@ -380,11 +461,33 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         }
         s_len[idx] = l;
     }
+    if (STAGE) {  // one LDS atomic per wave (256 atomics on one address are executed one after the other -- by the LDS all four
+        // blocks of the CU share: the first version of the staging was 0.29 ms SLOWER for it)
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const u32 o = (u32)__shfl_xor((int)my_lo, sft, 64);
+            my_lo = o < my_lo ? o : my_lo;
+        }
+        if (lane == 0 && my_lo != 0xffffffffu) atomicMin(&s_lo, my_lo);
+    }
     __syncthreads();
     const u32 n_short = s_cnt[0], n_long = s_cnt[1], n_int = s_cnt[2], n_flt = s_cnt[3];
+    u64 st_base = 0;   // STAGE: bytes [st_base, st_base + st_avail) of Strings.B are in s_str
+    u32 st_avail = 0;
+    if (STAGE) {
+        const u32 lo = s_lo;
+        if (lo != 0xffffffffu) {
+            st_base = (u64)(lo & ~15u);
+            const u64 have = (u64)(p.strings_end - p.strings);
+            const u64 left = have > st_base ? have - st_base : 0;
+            st_avail = (u32)(left < STAGE ? left & ~15ull : (u64)STAGE);
+            for (u32 i = (u32)tid * 16u; i < st_avail; i += TW_THREADS * 16u)
+                *reinterpret_cast<uint4 *>(s_str + i) = *reinterpret_cast<const uint4 *>(p.strings + st_base + i);
+        }
+    }
 
     // ---- 2. measure (numbers in both passes: their digits are not kept; strings in the counting pass only)
-    for (u32 j = (u32)tid; j < n_int; j += TW_THREADS) {
+    for (u32 j = (u32)tid; j < (MS_EXPBIT(p, 2) ? 0u : n_int); j += TW_THREADS) {
         const u32 idx = s_qn[j] & 0x7ffu;
         const u64 tw = p.tape[tb + idx], v = p.tape[tb + idx + 1];
         s_len[idx] += (u32)(tw >> 56) == 'l' ? int_text_len(v) : digit_count(v);
@@ -395,8 +498,52 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         if (nl == 0) bad = true;  // Inf / NaN: "INF or NaN number found"
         s_len[idx] += nl;
     }
+    // The first sixteen bytes of the thread's short strings (thread t owns queue slots t, t + 256, ...: at most four) are
+    // requested TOGETHER and stay in registers from the measuring to the writing: a string of up to 16 bytes -- nearly all of
+    // configs[4]'s -- is read once, and the round trips of a thread's strings overlap instead of following one another inside
+    // two loops with data-dependent inner loops (what the byte-store experiment really measured: without the loads of the writing
+    // loop configs[4] took 0.99 instead of 1.30 ms, without those of the measuring loop 1.09; with the byte stores replaced by
+    // 8-byte LDS operations and the loads left alone 1.25).
+    constexpr int SPT = MS_QCAP / TW_THREADS;
+    u64 sw0[SPT], sw1[SPT];
+    if (STAGE) __syncthreads();  // s_str is loaded (the number loops above ran beside the loads)
+    auto heads = [&]() {
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            sw0[k] = sw1[k] = 0;
+            const u32 j = (u32)tid + (u32)k * TW_THREADS;
+            if (j < n_short && !MS_EXPBIT(p, 1)) {
+                const u64 e64 = s_qs[j];
+                const u32 e = (u32)e64;
+                const u64 len = (e >> 23) & 0x3fu;
+                const bool inbuf = (e >> 22) & 1u;
+                const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
+                const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+                const u64 off = e64 >> 32;
+                if (STAGE && inbuf && off >= st_base && off - st_base + 24 <= (u64)st_avail) {
+                    const u32 a = (u32)(off - st_base), sh = 8u * (a & 7u);
+                    const u64 *q = reinterpret_cast<const u64 *>(s_str + (a & ~7u));
+                    const u64 q0 = q[0], q1 = q[1], q2 = q[2];
+                    sw0[k] = pad_a(sh ? (q0 >> sh) | (q1 << (64u - sh)) : q0, len);
+                    sw1[k] = len > 8 ? pad_a(sh ? (q1 >> sh) | (q2 << (64u - sh)) : q1, len - 8) : 0ull;
+                    continue;
+                }
+                if (len > 0) sw0[k] = str_load8(sp, 0, len, lim);
+                if (len > 8) sw1[k] = str_load8(sp, 8, len, lim);
+            }
+        }
+    };
+    heads();
+    static_assert(SPT == 4, "head() selects among four");
+    auto head = [&](int k, bool second) -> u64 {  // (k is a loop counter of a loop that is NOT unrolled: selects, not indexing)
+        const u64 a = second ? sw1[0] : sw0[0], b = second ? sw1[1] : sw0[1], c = second ? sw1[2] : sw0[2], d = second ? sw1[3] : sw0[3];
+        return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+    };
     if (MODE != 1) {
-        for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
+#pragma unroll 1
+        for (int k = 0; k < SPT; k++) {
+            const u32 j = (u32)tid + (u32)k * TW_THREADS;
+            if (j >= n_short) continue;
             const u64 e64 = s_qs[j];
             const u32 e = (u32)e64, idx = e & 0x7ffu;
             const u64 len = (e >> 23) & 0x3fu;
@@ -404,7 +551,10 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
             const u8 *lim = inbuf ? p.strings_end : p.msg_end;
             u32 el = 0;
-            for (u64 q = 0; q < len; q += 8) el += esc_size8(str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
+            if (MS_EXPBIT(p, 1)) el = (u32)len;
+            else
+            for (u64 q = 0; q < len; q += 8)
+                el += esc_size8(q < 16 ? head(k, q == 8) : str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
             s_len[idx] += el;
             if (MODE == 0) p.slen[slen_base + ((e >> 11) & 0x3ffu)] = el;
         }
@@ -488,7 +638,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
             const u32 l = s_len[idx];
             s_len[idx] = run;
-            if (isent[k]) {  // literals, brackets and record separators are written here
+            if (isent[k] && !MS_EXPBIT(p, 5)) {  // literals, brackets and record separators are written here
                 const u32 t = (u32)(w[k] >> 56);
                 u8 *o = tbase + run;
                 if (t == 't') {
@@ -515,7 +665,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     __syncthreads();
 
     // ---- 4. write, queue by queue
-    for (u32 j = (u32)tid; j < n_int; j += TW_THREADS) {
+    for (u32 j = (u32)tid; j < (MS_EXPBIT(p, 2) ? 0u : n_int); j += TW_THREADS) {
         const u32 e = s_qn[j], idx = e & 0x7ffu;
         const u64 tw = p.tape[tb + idx], v = p.tape[tb + idx + 1];
         u8 *o = tbase + s_len[idx];
@@ -529,16 +679,47 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         if ((e >> 11) & 1u) o[nl] = ',';
     }
     const u64 key_base = p.kf_tape ? 0 : p.cnt_s[tile];
-    for (u32 j = (u32)tid; j < n_short; j += TW_THREADS) {
+#pragma unroll 1
+    for (int k = 0; k < SPT; k++) {
+        const u32 j = (u32)tid + (u32)k * TW_THREADS;
+        if (j >= (MS_EXPBIT(p, 4) ? 0u : n_short)) continue;
         const u64 e64 = s_qs[j];
         const u32 e = (u32)e64, idx = e & 0x7ffu;
         const u64 len = (e >> 23) & 0x3fu;
         const bool inbuf = (e >> 22) & 1u;
         const u8 *sp = ms_string(p, inbuf, e64 >> 32, len);
         const u8 *lim = inbuf ? p.strings_end : p.msg_end;
+        if (staged) {  // (block-uniform) the text goes into the window eight bytes at a time
+            TextAcc a;
+            acc_init(a, s_text, s_len[idx]);
+            acc_push(a, (u64)'"', 1);
+            for (u64 q = 0; q < len && !MS_EXPBIT(p, 0); q += 8) {
+                const u32 valid = (u32)(len - q < 8 ? len - q : 8);
+                const u64 x = q < 16 ? head(k, q == 8) : str_load8(sp, q, len, lim);
+                if (word_is_clean(x)) {
+                    acc_push(a, low_bytes(x, valid), valid);
+                } else {
+                    acc_flush(a);
+                    const u32 at = acc_offset(a, s_text);
+                    acc_init(a, s_text, (u32)(write_esc8(s_text + at, x, valid) - s_text));
+                }
+            }
+            u64 tail = (u64)'"';
+            u32 nt = 1;
+            if ((e >> 21) & 1u) {
+                tail |= (u64)(entry_is_key(p, key_base, e, tb + idx) ? ':' : ',') << 8;
+                nt = 2;
+            }
+            acc_push(a, tail, nt);
+            acc_flush(a);
+            continue;
+        }
         u8 *o = tbase + s_len[idx];
         *o++ = '"';
-        for (u64 q = 0; q < len; q += 8) o = write_esc8(o, str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
+        if (MS_EXPBIT(p, 0)) o += len;
+        else
+        for (u64 q = 0; q < len; q += 8)
+            o = write_esc8(o, q < 16 ? head(k, q == 8) : str_load8(sp, q, len, lim), (u32)(len - q < 8 ? len - q : 8));
         *o++ = '"';
         if ((e >> 21) & 1u) *o = entry_is_key(p, key_base, e, tb + idx) ? ':' : ',';
     }
@@ -567,7 +748,17 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 const u32 up = (u32)__shfl_up((int)incl, sft, 64);
                 if (lane >= sft) incl += up;
             }
-            if (valid) write_esc8(o + (incl - sz), x, valid);
+            if (valid) {
+                if (staged && word_is_clean(x)) {  // eight bytes, two aligned slots
+                    const u32 at = (u32)(o - s_text) + (incl - sz), sh = 8u * (at & 7u);
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(s_text + (at & ~7u));
+                    const u64 piece = low_bytes(x, valid);
+                    atomicOr(slot, (unsigned long long)(piece << sh));
+                    if (sh && (piece >> (64u - sh))) atomicOr(slot + 1, (unsigned long long)(piece >> (64u - sh)));
+                } else {
+                    write_esc8(o + (incl - sz), x, valid);
+                }
+            }
             o += (u32)__shfl((int)incl, 63, 64);
         }
         if (lane == 0) {
@@ -581,7 +772,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             if (!resolve()) return;
             gdst = p.text + s_off;
         }
-        const u32 nb = (u32)tile_bytes, nw = nb >> 2;
+        const u32 nb = MS_EXPBIT(p, 3) ? 0u : (u32)tile_bytes, nw = nb >> 2;
         for (u32 i = (u32)tid; i < nw; i += TW_THREADS)  // unaligned 4-byte global stores are fine on gfx950
             *reinterpret_cast<u32 *>(gdst + 4 * i) = *reinterpret_cast<const u32 *>(s_text + 4 * i);
         const u32 tail = nw * 4 + (u32)tid;
@@ -593,7 +784,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
 static int ms_variant() {
     static const int v = [] {
         const char *e = getenv("SJHIP_MS_VARIANT");
-        return e ? atoi(e) : 6;
+        return e ? atoi(e) : 8;
     }();
     return v;
 }
@@ -619,9 +810,17 @@ static void launch_ms_tile(const MsView &p, hipStream_t st) {
         case 0:
         case 1: hipLaunchKernelGGL((k_ms_tile<MODE, 3, MS_WINDOW>), g, b, 0, st, p); break;
         case 3: hipLaunchKernelGGL((k_ms_tile<MODE, 4, MS_WINDOW / 2>), g, b, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((k_ms_tile<MODE, 6, MS_WINDOW / 4>), g, b, 0, st, p); break;
         case 5: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 19456u>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 21504u>), g, b, 0, st, p); break;  // the largest window with four blocks per CU
+        case 7: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 13312u, 8192u>), g, b, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_ms_tile<MODE, 4, 21504u>), g, b, 0, st, p); break;  // the largest window with four blocks per CU
+        default:
+            // Window + stage share what four blocks per CU leave (21.5 KB).  A tape whose tiles average at most ~6.5 KB of
+            // Strings.B and ~11 KB of text (configs[4]: 6.6 / 9.5) takes the staged form; twitter.json's (15 / 19 KB) the large window.
+            if (p.tiles && (u64)(p.strings_end - p.strings) / p.tiles <= 7168u && p.msg_len / p.tiles <= 11264u)
+                hipLaunchKernelGGL((k_ms_tile<MODE, 4, 13312u, 8192u>), g, b, 0, st, p);
+            else
+                hipLaunchKernelGGL((k_ms_tile<MODE, 4, 21504u>), g, b, 0, st, p);
+            break;
     }
 }
 }  // namespace
@@ -704,6 +903,10 @@ static int marshal_part(sjhip_ctx *ctx, sjhip_ctx *part, size_t *text_len) {
     p.slen = (u32 *)w;
     p.text = nullptr;
     p.text_cap = 0;
+    p.exp = 0;
+#if defined(SJ_EXP)
+    if (const char *e = getenv("SJHIP_MS_EXP")) p.exp = (u32)strtoul(e, nullptr, 0);
+#endif
     HIPCHK(hipMemsetAsync(p.totals, 0, 256, part->stream), "marshal memset");
     // keys: the flags the parser left (SJHIP_FLAG_KEY_FLAGS), or from the token array of the parse (three launches)
     p.kf_tape = (part->kf_valid) ? (const u8 *)part->d_keyflag.p : nullptr;

@@ -131,7 +131,7 @@ def test_key_flags_on_every_parse_path(ctx):
 
 
 @pytest.mark.parametrize("env", [{"SJHIP_MS_TEST_BOUND": "4096"}, {"SJHIP_MS_ONEPASS": "0"}, {"SJHIP_MS_VARIANT": "0"},
-                                 {"SJHIP_MS_VARIANT": "4"}, {"SJHIP_MS_VARIANT": "3"}])
+                                 {"SJHIP_MS_VARIANT": "7"}, {"SJHIP_MS_VARIANT": "6"}, {"SJHIP_MS_VARIANT": "3"}])
 def test_one_pass_fallbacks_and_variants(env):
     """The single-pass MarshalJSON (key flags from the parser, text buffer sized by a bound) must fall back to the two-pass
     form when a tile would write past the bound (forced here with a bound of 4 KiB) and give the same text with the

@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${1:-marshal_var}
 mkdir -p $OUT
 cd $REPO
-for v in 0 1 3 4; do
+for v in 0 1 3 6 7; do
   for w in twitter parking; do
     echo "variant $v $w" | tee -a $OUT/times.txt
     SJHIP_MS_VARIANT=$v timeout 120 python tools/marshal_loop.py $w 5 kf 2>&1 | grep -E "marshal_json" | tee -a $OUT/times.txt
