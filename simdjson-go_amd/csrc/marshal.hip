@@ -67,7 +67,17 @@ struct MsView {
 };
 #if defined(SJ_EXP)
 #define MS_EXPBIT(p, b) ((((p).exp >> (b)) & 1u) != 0)
+// bit 31: thread 0 of every block adds the time since its previous stamp to totals[8 + k] (phase profile of k_ms_tile)
+#define MS_STAMP(k)                                                                              \
+    do {                                                                                         \
+        if (MS_EXPBIT(p, 31) && threadIdx.x == 0 && (blockIdx.x & 63u) == 0) {                   \
+            const unsigned long long t_now = __builtin_readcyclecounter();                       \
+            atomicAdd(&p.totals[8 + (k)], t_now - t_prev);                                       \
+            t_prev = t_now;                                                                      \
+        }                                                                                        \
+    } while (0)
 #else
+#define MS_STAMP(k) do { } while (0)
 #define MS_EXPBIT(p, b) false
 #endif
 
@@ -342,11 +352,15 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     __shared__ __attribute__((aligned(16))) u8 s_str[STAGE ? STAGE + 32 : 16];
     __shared__ u32 s_lo;  // STAGE: the lowest Strings.B offset among the tile's short strings
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(SJ_EXP)
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     __shared__ u32 s_tile;
     if (ONEPASS) {
         if (tid == 0) s_tile = atomicAdd(p.ticket, 1u);
         __syncthreads();
     }
+    MS_STAMP(0);  // ticket
     const u32 tile = ONEPASS ? s_tile : blockIdx.x;
     const u64 tb = (u64)tile * TW_TILE;
     const u64 base = tb + (u64)tid * TW_ITEMS;
@@ -382,7 +396,9 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         for (u32 i = (u32)tid; i < WINDOW / 16; i += TW_THREADS) reinterpret_cast<uint4 *>(s_text)[i] = z;
     }
+    MS_STAMP(1);  // tape words, local anchor
     long long anchor = block_excl_max(last, s_l, tid);  // (its barriers also publish s_cnt = 0)
+    MS_STAMP(2);  // block max-scan
     if (carry == -2) {  // (block-uniform) nothing of this tile can be classified: report and leave -- with a wrong anchor
         if (tid == 0) {  // raw words would be read as tags, their neighbours as string lengths
             atomicOr(&p.totals[2], 4ull);
@@ -414,8 +430,10 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         sepf[k] = (!last_entry && nt != '}' && nt != ']' && nt != 'r') ? 1 : 0;
         if ((u32)(w[k] >> 56) == '"') nstr++;
     }
+    MS_STAMP(3);  // classify (flags)
     unsigned long long tot_s = 0;
-    u32 ord = (u32)block_excl_sum(nstr, s_s, tid, &tot_s);  // ordinal of the thread's first string inside the tile
+    u32 ord = (u32)block_excl_sum(nstr, s_s, tid, &tot_s);
+    MS_STAMP(4);  // string ordinals (block scan)  // ordinal of the thread's first string inside the tile
     const u64 slen_base = (u64)tile * MS_QCAP;
     u32 my_lo = 0xffffffffu;  // STAGE: the lowest Strings.B offset among this thread's short strings
 #pragma unroll
@@ -471,6 +489,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         if (lane == 0 && my_lo != 0xffffffffu) atomicMin(&s_lo, my_lo);
     }
     __syncthreads();
+    MS_STAMP(5);  // queues
     const u32 n_short = s_cnt[0], n_long = s_cnt[1], n_int = s_cnt[2], n_flt = s_cnt[3];
     u64 st_base = 0;   // STAGE: bytes [st_base, st_base + st_avail) of Strings.B are in s_str
     u32 st_avail = 0;
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     __syncthreads();
 
+    MS_STAMP(6);  // measure
     // ---- 3. positions
     u64 bytes = 0;
 #pragma unroll
@@ -603,7 +623,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     const bool staged = tile_bytes <= WINDOW;  // block-uniform
     auto resolve = [&]() -> bool {  // block-uniform; false: nothing may be written
         if (wave == 0) {
-            const unsigned long long off = ms_lookback(p.desc, tile, tot, lane, &p.totals[2]);
+            const unsigned long long off = MS_EXPBIT(p, 6) ? (unsigned long long)tile * 9600ull : ms_lookback(p.desc, tile, tot, lane, &p.totals[2]);
             if (lane == 0) {
                 s_off = off;
                 if ((u64)tile + 1 == p.tiles) p.totals[0] = off + tot;           // the length of the whole text
@@ -629,6 +649,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     // The text of a tile is one contiguous range.  When it fits the window the block writes it into LDS (byte stores
     // that cost a fraction of scattered global ones) and copies the window out with coalesced 4-byte stores; a tile
     // with more text (long strings) writes straight to memory.
+    MS_STAMP(7);  // positions scan, descriptor
     u8 *gdst = ONEPASS ? (staged ? nullptr : p.text + s_off) : p.text + p.cnt_b[tile];
     u8 *const tbase = staged ? s_text : gdst;
     {
@@ -664,6 +685,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     __syncthreads();
 
+    MS_STAMP(8);  // offsets, literals
     // ---- 4. write, queue by queue
     for (u32 j = (u32)tid; j < (MS_EXPBIT(p, 2) ? 0u : n_int); j += TW_THREADS) {
         const u32 e = s_qn[j], idx = e & 0x7ffu;
@@ -768,15 +790,18 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     }
     if (staged) {
         __syncthreads();
+        MS_STAMP(9);  // numbers and strings written
         if (ONEPASS) {
             if (!resolve()) return;
             gdst = p.text + s_off;
         }
+        MS_STAMP(10);  // look-back
         const u32 nb = MS_EXPBIT(p, 3) ? 0u : (u32)tile_bytes, nw = nb >> 2;
         for (u32 i = (u32)tid; i < nw; i += TW_THREADS)  // unaligned 4-byte global stores are fine on gfx950
             *reinterpret_cast<u32 *>(gdst + 4 * i) = *reinterpret_cast<const u32 *>(s_text + 4 * i);
         const u32 tail = nw * 4 + (u32)tid;
         if (tail < nb) gdst[tail] = s_text[tail];
+        MS_STAMP(11);  // copy-out
     }
 }
 
@@ -948,6 +973,18 @@ static int marshal_part(sjhip_ctx *ctx, sjhip_ctx *part, size_t *text_len) {
         HIPCHK(hipGetLastError(), "marshal launch (one pass)");
         HIPCHK(hipMemcpyAsync(h, p.totals, 24, hipMemcpyDeviceToHost, part->stream), "D2H totals");
         HIPCHK(hipStreamSynchronize(part->stream), "marshal sync");
+#if defined(SJ_EXP)
+        if (p.exp >> 31) {
+            unsigned long long t[32];
+            if (hipMemcpy(t, p.totals, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long sum = 0;
+                for (int k = 0; k < 12; k++) sum += t[8 + k];
+                fprintf(stderr, "k_ms_tile phases (share of thread 0's time, %u tiles):", p.tiles);
+                for (int k = 0; k < 12; k++) fprintf(stderr, " %d:%.1f%%", k, sum ? 100.0 * (double)t[8 + k] / (double)sum : 0.0);
+                fprintf(stderr, "  avg per sampled tile %.0f ticks\n", p.tiles ? (double)sum / ((p.tiles + 63) / 64) : 0.0);
+            }
+        }
+#endif
         if (h[2] & 16ull) {
             ctx_set_error(ctx, "MarshalJSON: look-back aborted (internal synchronisation timeout)");
             return SJHIP_ERR_HIP;
