@@ -364,6 +364,14 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     const u32 tile = ONEPASS ? s_tile : blockIdx.x;
     const u64 tb = (u64)tile * TW_TILE;
     const u64 base = tb + (u64)tid * TW_ITEMS;
+    // requested with the tile's words, used later: the word the local anchor search of this thread looks at (64 words in front of the
+    // tile, one per thread of wave 0) and the key flags of the thread's entries -- one aligned 4-byte load (tb and base are multiples
+    // of eight words, a flag per two words) instead of a byte load per string in the middle of the classification
+    u64 aw = 0;
+    const bool a_have = tid < 64 && !p.tile_last && tb >= 1 + (u64)tid;
+    if (a_have) aw = p.tape[tb - 1 - (u64)tid];
+    u32 kf4 = 0;
+    if (p.kf_tape && base < p.n) kf4 = *reinterpret_cast<const u32 *>(p.kf_tape + (base >> 1));
     u64 w[TW_ITEMS + 2];  // the thread's words and the two behind them (an entry's second word, the next entry's tag)
     if (base + TW_ITEMS + 2 <= p.n) {  // five 16-byte loads (the tape arena is 256-byte aligned, base a multiple of 8 words)
         const uint4 *q4 = reinterpret_cast<const uint4 *>(p.tape + base);
@@ -385,10 +393,21 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
     // tape -- the closest of the 64 words in front of the tile that is not a two-word tag; a tile that finds none
     // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
     __shared__ long long s_carry;
-    const long long carry = p.tile_last ? p.tile_last[tile] : tw_local_anchor(p.tape, tb, tid, &s_carry);
+    long long carry;
+    if (p.tile_last) {
+        carry = p.tile_last[tile];
+    } else {  // (sj_tapewalk.h tw_local_anchor, with the word already in a register)
+        if (tid < 64) {
+            const u64 b = __ballot(a_have && !two_word_tag(aw));
+            if (tid == 0) s_carry = b ? (long long)(tb - 1 - (u64)ctz64(b)) : (tb > 64 ? -2ll : -1ll);
+        }
+        __syncthreads();
+        carry = s_carry;
+    }
     // queue slots are drawn with LDS atomics, in whatever order the lanes arrive.  (Slots in document order from one packed
-    // block scan -- no atomics, adjacent lanes on adjacent strings -- were measured twice: configs[4] 2.01 instead of
-    // 1.75 ms, configs[1] 1.32 instead of 1.34, tools/gpu_ab_marshal.sh.)
+    // block scan -- no atomics, adjacent lanes on adjacent strings -- were measured in round 4: configs[4] 2.01 instead of
+    // 1.75 ms, tools/gpu_ab_marshal.sh; and again in round 6, with the text leaving in aligned 8-byte pieces: 1.30 instead of
+    // 1.14 ms, 1.33 with the lanes of a wave spread over distant slots of the ordered queue -- profiles/r06_marshal_parts_ab.txt.)
     __shared__ u32 s_cnt[4];         // short strings, long strings, integers, floats
     if (tid < 4) s_cnt[tid] = 0;
     if (STAGE && tid == 4) s_lo = 0xffffffffu;
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 const u64 v = inbuf ? (vr & ~STRINGBUFBIT) - p.strings_base : vr - p.msg_base;  // (inside this context's buffers)
                 // (the key flag of the parser rides in the entry: read here, neighbouring threads read neighbouring bytes; read
                 // when the string is written it was one more gather per string)
-                const u64 key = p.kf_tape ? (p.kf_tape[(tb + idx) >> 1] != 0 ? 1ull : 0ull) : 0ull;
+                const u64 key = ((kf4 >> (8 * (k >> 1))) & 0xffu) != 0 ? 1ull : 0ull;  // (flag of word pair k / 2; 0 without parser flags)
                 if (STAGE && inbuf && !lng && (u32)v < my_lo) my_lo = (u32)v;
                 s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) | (key << 29) |
                              (v << 32);
