@@ -280,6 +280,28 @@ __device__ __forceinline__ u8 *write_esc8(u8 *o, u64 w, u32 valid) {
     return o;
 }
 
+// ---- entry classes (round 6) ----------------------------------------------------------------------------------------------
+// One byte per value of a tape word's top byte, in a 256-byte LDS table every thread fills one entry of when the block starts: the
+// classification asks the table instead of walking a chain of tag comparisons for every word (eight words per thread, twice, and
+// two_word_tag four more comparisons on ten words: the kernel is bound by instruction issue at four waves per SIMD, and ~35 % of a
+// tile's time went into those chains, profiles/r06_marshal_parts_ab.txt).  bits 0-2: bytes of text the entry itself brings (without
+// separator, string bytes and digits), bit 3: the entry closes something (no separator in front of it), bit 4: a separator may
+// follow it, bits 5-7: kind.
+static constexpr u32 CLS_CLOSES = 8u, CLS_SEP = 16u, CLS_KIND = 0xe0u, CLS_PLAIN = 0x00u, CLS_STR = 0x20u, CLS_INT = 0x40u, CLS_FLT = 0x60u,
+                     CLS_ROOT = 0x80u, CLS_BAD = 0xe0u;
+__device__ __forceinline__ u32 tag_class(u32 t) {
+    if (t == '"') return CLS_STR | CLS_SEP | 2u;
+    if (t == 'l' || t == 'u') return CLS_INT | CLS_SEP;
+    if (t == 'd') return CLS_FLT | CLS_SEP;
+    if (t == 't' || t == 'n') return CLS_PLAIN | CLS_SEP | 4u;
+    if (t == 'f') return CLS_PLAIN | CLS_SEP | 5u;
+    if (t == '{' || t == '[') return CLS_PLAIN | 1u;
+    if (t == '}' || t == ']') return CLS_PLAIN | CLS_SEP | CLS_CLOSES | 1u;
+    if (t == 'r') return CLS_ROOT | CLS_CLOSES;
+    return CLS_BAD;
+}
+__device__ __forceinline__ bool cls_two_word(u32 c) { return ((c >> 5) - 1u) < 3u; }  // string, integer, float
+
 // ---- text into the LDS window eight bytes at a time (round 6) ------------------------------------------------------------
 // The window is zeroed when the block starts and a string's text -- quote, bytes, quote, separator -- is shifted together in
 // a 64-bit accumulator that is ORed into the window slot by slot with ALIGNED 8-byte LDS atomics (ds_or_b64; the neighbours'
@@ -355,11 +377,12 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
 #if defined(SJ_EXP)
     unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
+    __shared__ u8 s_cls[256];
+    static_assert(TW_THREADS == 256, "one table entry per thread");
+    s_cls[tid] = (u8)tag_class((u32)tid);
     __shared__ u32 s_tile;
-    if (ONEPASS) {
-        if (tid == 0) s_tile = atomicAdd(p.ticket, 1u);
-        __syncthreads();
-    }
+    if (ONEPASS && tid == 0) s_tile = atomicAdd(p.ticket, 1u);
+    __syncthreads();  // (the ticket and the table)
     MS_STAMP(0);  // ticket
     const u32 tile = ONEPASS ? s_tile : blockIdx.x;
     const u64 tb = (u64)tile * TW_TILE;
@@ -385,10 +408,17 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
 #pragma unroll
         for (int k = 0; k < TW_ITEMS + 2; k++) w[k] = base + k < p.n ? p.tape[base + k] : 0;
     }
+    u32 clp[3] = {0u, 0u, 0u};  // the classes of the ten words, a byte each (ten LDS reads in flight, one wait)
+#pragma unroll
+    for (int k = 0; k < TW_ITEMS + 2; k++) clp[k >> 2] |= (u32)s_cls[(u32)(w[k] >> 56)] << (8 * (k & 3));
+    u32 tgp[2] = {0u, 0u};  // ... and the tags of the thread's own eight
+#pragma unroll
+    for (int k = 0; k < TW_ITEMS; k++) tgp[k >> 2] |= (u32)(w[k] >> 56) << (8 * (k & 3));
+    auto CL = [&](int k) -> u32 { return (clp[k >> 2] >> (8 * (k & 3))) & 0xffu; };  // (k is a constant wherever this is called)
     long long last = -1;
 #pragma unroll
     for (int k = 0; k < TW_ITEMS; k++)
-        if (base + k < p.n && !two_word_tag(w[k])) last = (long long)(base + k);
+        if (base + k < p.n && !cls_two_word(CL(k))) last = (long long)(base + k);
     // the anchor in front of the tile: from the global scan (tile_last), or -- the common case, no extra pass over the
     // tape -- the closest of the 64 words in front of the tile that is not a two-word tag; a tile that finds none
     // (64 raw words that all look like string / number tags) reports it and the host repeats the walk with tile_last
@@ -439,15 +469,15 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         sepf[k] = 0;
         if (i >= p.n) continue;
         const bool raw = anchor >= 0 && ((((long long)i - anchor - 1) & 1) != 0);
-        if (!two_word_tag(w[k])) anchor = (long long)i;
+        const bool two = cls_two_word(CL(k));
+        if (!two) anchor = (long long)i;
         if (raw) continue;
         isent[k] = 1;
-        const bool two = two_word_tag(w[k]);
         // separator behind a completed value: ',' unless the next entry closes something (for a key: ':', same length)
-        const u32 nt = (u32)((two ? w[k + 2] : w[k + 1]) >> 56);
+        const u32 nc = two ? CL(k + 2) : CL(k + 1);
         const bool last_entry = i + (two ? 2 : 1) >= p.n;
-        sepf[k] = (!last_entry && nt != '}' && nt != ']' && nt != 'r') ? 1 : 0;
-        if ((u32)(w[k] >> 56) == '"') nstr++;
+        sepf[k] = (!last_entry && !(nc & CLS_CLOSES)) ? 1 : 0;
+        if ((CL(k) & CLS_KIND) == CLS_STR) nstr++;
     }
     MS_STAMP(3);  // classify (flags)
     unsigned long long tot_s = 0;
@@ -460,8 +490,9 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
         const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
         u32 l = 0;
         if (isent[k]) {
-            const u32 t = (u32)(w[k] >> 56), sep = sepf[k];
-            if (t == '"') {
+            const u32 c = CL(k), kind = c & CLS_KIND, sep = sepf[k];
+            l = (c & 7u) + ((c & CLS_SEP) ? sep : 0u);  // literals and brackets are done with this
+            if (kind == CLS_STR) {
                 const bool lng = w[k + 1] >= MS_LONG;
                 const u32 slot = lng ? MS_QCAP - 1 - atomicAdd(&s_cnt[1], 1u) : atomicAdd(&s_cnt[0], 1u);
                 const u64 vr = w[k] & TW_PAYLOAD;
@@ -473,26 +504,16 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
                 if (STAGE && inbuf && !lng && (u32)v < my_lo) my_lo = (u32)v;
                 s_qs[slot] = (u64)(idx | (ord << 11) | (sep << 21)) | (inbuf << 22) | ((lng ? 0ull : w[k + 1]) << 23) | (key << 29) |
                              (v << 32);
-                l = 2 + sep + (MODE == 1 ? p.slen[slen_base + ord] : 0u);
+                if (MODE == 1) l += p.slen[slen_base + ord];
                 ord++;
-            } else if (t == 'l' || t == 'u') {
+            } else if (kind == CLS_INT) {
                 s_qn[atomicAdd(&s_cnt[2], 1u)] = (uint16_t)(idx | (sep << 11));
-                l = sep;
-            } else if (t == 'd') {
+            } else if (kind == CLS_FLT) {
                 s_qn[MS_QCAP - 1 - atomicAdd(&s_cnt[3], 1u)] = (uint16_t)(idx | (sep << 11));
-                l = sep;
-            } else if (t == 't' || t == 'n') {
-                l = 4 + sep;
-            } else if (t == 'f') {
-                l = 5 + sep;
-            } else if (t == '{' || t == '[') {
-                l = 1;
-            } else if (t == '}' || t == ']') {
-                l = 1 + sep;
-            } else if (t == 'r') {
+            } else if (kind == CLS_ROOT) {
                 const bool is_open = (w[k] & TW_PAYLOAD) > p.tape_base + base + k;  // isOpenRoot (:441)
                 l = (!is_open && base + k + 1 < p.n) ? 1u : 0u;       // '\n' between records
-            } else {
+            } else if (kind == CLS_BAD) {
                 bad = true;
             }
         }
@@ -678,25 +699,22 @@ __global__ __launch_bounds__(TW_THREADS, WPE) void k_ms_tile(MsView p) {
             const u32 idx = (u32)tid * TW_ITEMS + (u32)k;
             const u32 l = s_len[idx];
             s_len[idx] = run;
-            if (isent[k] && !MS_EXPBIT(p, 5)) {  // literals, brackets and record separators are written here
-                const u32 t = (u32)(w[k] >> 56);
-                u8 *o = tbase + run;
-                if (t == 't') {
-                    o[0] = 't'; o[1] = 'r'; o[2] = 'u'; o[3] = 'e';
-                    if (sepf[k]) o[4] = ',';
-                } else if (t == 'n') {
-                    o[0] = 'n'; o[1] = 'u'; o[2] = 'l'; o[3] = 'l';
-                    if (sepf[k]) o[4] = ',';
-                } else if (t == 'f') {
-                    o[0] = 'f'; o[1] = 'a'; o[2] = 'l'; o[3] = 's'; o[4] = 'e';
-                    if (sepf[k]) o[5] = ',';
-                } else if (t == '{' || t == '[') {
-                    o[0] = (u8)t;
-                } else if (t == '}' || t == ']') {
-                    o[0] = (u8)t;
-                    if (sepf[k]) o[1] = ',';
-                } else if (t == 'r') {
-                    if (l) o[0] = '\n';
+            const u32 c = CL(k), kind = c & CLS_KIND;
+            if (isent[k] && l != 0 && (kind == CLS_PLAIN || kind == CLS_ROOT) && !MS_EXPBIT(p, 5)) {
+                // literals, brackets and record separators are written here: the text is a constant selected by the tag (a bracket
+                // stands for itself), the separator behind it, and the whole leaves as one piece
+                const u32 t = (tgp[k >> 2] >> (8 * (k & 3))) & 0xffu;  // (the words themselves are dead by now: 20 registers less)
+                u64 piece = t == 't' ? 0x65757274ull : t == 'n' ? 0x6c6c756eull : t == 'f' ? 0x65736c6166ull : t == 'r' ? 0x0aull : (u64)t;
+                const u32 nb = c & 7u;  // (a root word brings no byte of its own: its '\n' is the whole text, l == 1)
+                if (kind == CLS_PLAIN && sepf[k] && (c & CLS_SEP)) piece |= (u64)',' << (8u * nb);
+                if (staged) {
+                    const u32 sh = 8u * (run & 7u);
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(s_text + (run & ~7u));
+                    atomicOr(slot, (unsigned long long)(piece << sh));
+                    if (sh && (piece >> (64u - sh))) atomicOr(slot + 1, (unsigned long long)(piece >> (64u - sh)));
+                } else {
+                    u8 *o = tbase + run;
+                    for (u32 j = 0; j < l; j++) o[j] = (u8)(piece >> (8u * j));
                 }
             }
             run += l;
