@@ -275,17 +275,19 @@ __device__ __forceinline__ u32 sel_unit_out(const S2Dev &p, u64 u, int lane, boo
 // The selected bytes of this lane's chunk: the two scans over the wave's 64 chunks (function composition, sel_then) applied
 // to the states at the unit's ends.
 __device__ __forceinline__ u64 sel_wave_mask(const ChunkSel &cs, u32 fin, u32 gout, int lane) {
-    u32 f = cs.fwd, g = cs.bwd;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 tf = (u32)__shfl_up((int)f, d, 64), tg = (u32)__shfl_down((int)g, d, 64);
-        if (lane >= d) f = sel_then(tf, f);         // chunks lane-2d+1 .. lane-d first, then lane-d+1 .. lane
-        if (lane + d < 64) g = sel_then(tg, g);     // the chunks behind first (the backward scan starts at the unit's end)
-    }
-    u32 fe = (u32)__shfl_up((int)f, 1, 64), ge = (u32)__shfl_down((int)g, 1, 64);
-    if (lane == 0) fe = 1u;   // identity
-    if (lane == 63) ge = 1u;
-    return chunk_sel_mask(cs, sel_apply(fe, fin), sel_apply(ge, gout));
+    // A scan element is x -> (x & a) | b on ONE bit of state: "b generates, a propagates" -- the carry chain of an addition.  With the
+    // a and b bits of the 64 chunks in two 64-bit ballots, the state entering every chunk is the carry into its bit of b + (a | b) + fin
+    // (carry out of bit i = b_i | c_i (a_i | b_i) = b_i | c_i a_i), i.e. sum ^ b ^ (a | b): four ballots and a dozen scalar
+    // instructions for both directions (the backward chain on the bit-reversed words).  Until the end of round 6 these were two
+    // Hillis-Steele scans by function composition (sj_strings.h sel_then; still what the host replay runs): twelve dependent
+    // cross-lane shuffles per unit, in k_measure and again in k_str_emit.
+    const u64 fa = __ballot((cs.fwd & 1u) != 0), fb = __ballot((cs.fwd & 2u) != 0);
+    const u64 ga = brev64(__ballot((cs.bwd & 1u) != 0)), gb = brev64(__ballot((cs.bwd & 2u) != 0));
+    const u64 fp = fa | fb, gp = ga | gb;
+    const u64 fc = (fb + fp + (u64)(fin & 1u)) ^ fb ^ fp;            // bit i: the state at the start of chunk i
+    const u64 gc = brev64((gb + gp + (u64)(gout & 1u)) ^ gb ^ gp);   // bit i: the state at the end of chunk i (coming from behind)
+    (void)lane;
+    return chunk_sel_mask(cs, (u32)(fc >> lane) & 1u, (u32)(gc >> lane) & 1u);
 }
 // unit flags of the selective copy (S2Dev::unit_copy): the states at the unit's ends, left by k_measure for k_str_emit
 static constexpr u8 USEL_IN = 1u, USEL_OUT = 2u;
