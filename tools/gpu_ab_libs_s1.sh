@@ -11,4 +11,4 @@ for r in $(seq 1 ${ROUNDS:-2}); do
     echo
   done
 done
-} 2>&1 | tee gpurun_out/${OUTNAME:-r6t_ab}.txt
+} 2>&1 | tee gpurun_out/${OUTNAME:-ab_libs_s1}.txt

@@ -12,4 +12,4 @@ for r in 1 2 3; do
     done
   done
 done
-} 2>&1 | tee gpurun_out/${OUTNAME:-r6n}.txt
+} 2>&1 | tee gpurun_out/${OUTNAME:-ab_marshal_libs}.txt

@@ -9,4 +9,4 @@ for bits in 0 1 2 4 8 16 32 3 19 0; do
   SJHIP_MS_EXP=$bits timeout 200 python tools/marshal_loop.py $w 5 kf 2>&1 | grep marshal_json
 done
 done
-} 2>&1 | tee gpurun_out/r6m_exp.txt
+} 2>&1 | tee gpurun_out/exp_marshal.txt
