@@ -307,7 +307,7 @@ __device__ __forceinline__ bool cls_two_word(u32 c) { return ((c >> 5) - 1u) < 3
 // a 64-bit accumulator that is ORed into the window slot by slot with ALIGNED 8-byte LDS atomics (ds_or_b64; the neighbours'
 // bytes of a shared slot are zeros in this lane's word): one LDS operation per eight bytes of text instead of one byte store
 // -- and a shift, an address and a trip of a data-dependent loop -- per byte (the byte loop was 0.31 of configs[4]'s 1.30 ms,
-// gpurun_out/r6m_exp.txt).  Plain byte stores of other entries into the same slots mix freely with the atomics: the LDS
+// profiles/r06_marshal_parts_ab.txt).  Plain byte stores of other entries into the same slots mix freely with the atomics: the LDS
 // executes both one operation at a time.  A word with a byte to escape leaves through the byte path (acc_flush, write_esc8,
 // acc_init behind it).
 struct TextAcc {
@@ -357,7 +357,7 @@ __device__ __forceinline__ u64 low_bytes(u64 w, u32 valid) { return valid >= 8u 
 // the strings of a tile lie side by side there (every string copied, in tape order), ~6.6 KB per tile on configs[4].  A thread
 // fetching the first sixteen bytes of ITS strings from memory is a gather of 64 different cache lines per load instruction: the
 // texture addresser works through them one line at a time, and those gathers alone were 0.24 of configs[4]'s 1.21 ms
-// (gpurun_out/r6m_exp.txt: 1.045 -> 0.806 without them, everything else in place).  From LDS the same sixteen bytes are three
+// (profiles/r06_marshal_parts_ab.txt: 1.045 -> 0.806 without them, everything else in place).  From LDS the same sixteen bytes are three
 // aligned 8-byte reads and two funnel shifts.  A string outside the staged range (a long stretch, a string in the message) is
 // read from memory as before.
 template <int MODE, int WPE, u32 WINDOW, u32 STAGE = 0>

@@ -78,7 +78,7 @@ struct S1Aux {
 // state of this parse.  Order-free: the descriptors and the control slot belong to a launch that is over, the stage-2 region to
 // kernels that have not begun.  (The first half of round 6 let "the last block" clean up behind a completion counter: an
 // atomic per block and two dependent round trips at the very end of the kernel, where nothing hides them -- 256 MiB 0.0935 ->
-// 0.0955 ms, gpurun_out/r6v_s1b.txt -- and counting the blocks in front of their last flatten did not hide them either.)
+// 0.0955 ms, profiles/r06_stage1_no_prepare_ab.txt -- and counting the blocks in front of their last flatten did not hide them either.)
 __device__ __forceinline__ void launch_clean(Stage1State *st, const S1Aux &aux) {
     const u64 thr = (u64)blockIdx.x * blockDim.x + threadIdx.x, nthr = (u64)gridDim.x * blockDim.x;
     for (u64 i = thr; i < aux.clean_tiles; i += nthr) aux.clean_desc[i] = 0;
@@ -213,7 +213,7 @@ __device__ __forceinline__ u32 pseudo_pred_from_prev8(u64 prev8, const u8 *base,
 // pseudo_pred (=1) semantics untouched.  (Rounds 1-5: a preparation kernel left blank-padded copies of the two units
 // in the workspace.  Round 6: the wave that loads one of the two builds it in its registers, edge_unit_load below --
 // a branch where the loads are issued, nothing in phase A: blanking the class masks there, a dozen 64-bit operations
-// behind a uniform branch in the middle of the classification, cost 2-3 % at every size, gpurun_out/r6v_s1b.txt.)
+// behind a uniform branch in the middle of the classification, cost 2-3 % at every size, profiles/r06_stage1_no_prepare_ab.txt.)
 // a unit in flight: this lane's chunk and (every lane the same) the 8 message bytes in front of the unit, which the
 // carries into its first chunk come from -- fetched with the chunk so that nothing waits for a scalar load later
 // (measured -2.5 %).  One unit per wave is in flight; a second one (each pass loaded a whole tile ahead) measured
